@@ -1,0 +1,329 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/*.npz.
+
+Runs ONLY in the build container: imports the reference (read-only, /root/reference) through the
+shims in _refshim.py, executes its CPU PyTorch path on small seeded inputs, ASSERTS that the
+oracle (oracle/contrad_oracle.py) reproduces every output, and stores inputs + explicit random
+parameters + reference outputs as small .npz fixtures.  The reference never travels; the fixtures
+are data only.
+
+    python tests/golden/make_golden.py            # regenerate everything
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import _refshim  # noqa: E402
+
+_refshim.install()
+from oracle import contrad_oracle as O  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def _np(d):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, torch.Tensor):
+            out[k] = v.detach().cpu().numpy()
+        elif isinstance(v, (bool, int, float)):
+            out[k] = np.asarray(v)
+        elif v is None:
+            continue
+        else:
+            out[k] = np.asarray(v)
+    return out
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **_np(arrays))
+    print('wrote %-28s %7.1f KiB' % (name + '.npz', os.path.getsize(path) / 1024))
+
+
+def check(a, b, tol, what):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    err = (a - b).abs().max().item()
+    ref = max(b.abs().max().item(), 1e-30)
+    assert err <= tol * max(ref, 1.0), '%s: max err %.3e (ref max %.3e)' % (what, err, ref)
+    return err
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_losses():
+    from training.criterion import nt_xent
+    from training.gan.contrad import supcon_fake
+    # the SURVEY known-answer smoke values
+    torch.manual_seed(0)
+    z = F.normalize(torch.randn(12, 16))
+    a = nt_xent(z[:4], z[4:8], temperature=0.1).item()
+    b = supcon_fake(z[:4], z[4:8], z[8:], temperature=0.1).item()
+    assert abs(a - 4.954558372497559) < 1e-6 and abs(b - 3.962817430496216) < 1e-6, (a, b)
+
+    out = {}
+    for tag, (N, d, temp) in {'small': (4, 16, 0.1), 'mid': (24, 128, 0.1), 'hot': (16, 128, 0.5)}.items():
+        g = torch.Generator().manual_seed(7 + N)
+        u1 = torch.randn(3 * N, d, generator=g, requires_grad=True)     # un-normalised projection
+        u2 = torch.randn(3 * N, d, generator=g, requires_grad=True)     # un-normalised projection2
+        v = F.normalize(u1)
+        r = F.normalize(u2)
+        l1 = nt_xent(v[:N], v[N:2 * N], temperature=temp)
+        l2 = supcon_fake(r[:N], r[N:2 * N], r[2 * N:], temperature=temp)
+        (l1 + l2).backward()
+        # oracle
+        o1 = u1.detach().clone().requires_grad_()
+        o2 = u2.detach().clone().requires_grad_()
+        ov, orr = F.normalize(o1), F.normalize(o2)
+        ol1 = O.nt_xent(ov[:N], ov[N:2 * N], temp)
+        ol2 = O.supcon_fake(orr[:N], orr[N:2 * N], orr[2 * N:], temp)
+        (ol1 + ol2).backward()
+        check(ol1, l1, 1e-6, 'nt_xent ' + tag)
+        check(ol2, l2, 1e-6, 'supcon ' + tag)
+        check(o1.grad, u1.grad, 1e-6, 'nt_xent grad ' + tag)
+        check(o2.grad, u2.grad, 1e-6, 'supcon grad ' + tag)
+        out.update({tag + '_u1': u1, tag + '_u2': u2, tag + '_temp': temp, tag + '_N': N,
+                    tag + '_nt_xent': l1, tag + '_supcon': l2,
+                    tag + '_g1': u1.grad, tag + '_g2': u2.grad})
+    out['known_nt_xent'] = a
+    out['known_supcon'] = b
+    save('losses', **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def _param_dict(p):
+    return {('p_' + k): (v if v is not None else None) for k, v in p.items()}
+
+
+def gen_augment():
+    import augment as A
+    out = {}
+    # --- CIFAR simclr, B=12 (enough samples that every branch of every mask occurs) -------------
+    _refshim.bind_cifar_defaults()
+    for tag, seed in (('c10a', 0), ('c10b', 3)):
+        B = 12
+        g = torch.Generator().manual_seed(100 + seed)
+        x = torch.rand(B, 3, 32, 32, generator=g)
+        torch.manual_seed(seed); np.random.seed(seed)
+        ref = A.simclr()(x)
+        torch.manual_seed(seed); np.random.seed(seed)
+        p = O.sample_simclr_params(B, 32, 32, O.SIMCLR_CIFAR)
+        mine = O.simclr_apply(x, p)
+        check(mine, ref, 1e-6, 'simclr ' + tag)
+        out.update({tag + '_x': x, tag + '_out': ref, tag + '_seed': seed})
+        out.update({tag + '_' + k: v for k, v in _param_dict(p).items()})
+        # per-stage outputs with the same explicit parameters (reference layers driven directly)
+        st1 = O.resized_crop(x, p['theta'])
+        st2 = O.hflip(st1, p['flip_sign'])
+        out.update({tag + '_stage_crop': st1, tag + '_stage_flip': st2})
+
+    # --- stage-level checks against the reference layers with injected randomness --------------
+    g = torch.Generator().manual_seed(55)
+    x = torch.rand(6, 3, 32, 32, generator=g)
+    from augment.color_jitter import RandomHSVFunction
+    from augment.utils import rgb2hsv, hsv2rgb
+    f_h = torch.tensor([-0.1, 0.05, 0.0, 0.1, -0.03, 0.07]).view(6, 1, 1)
+    f_s = torch.tensor([0.6, 1.4, 1.0, 0.9, 1.2, 0.7]).view(6, 1, 1)
+    f_v = torch.tensor([1.4, 0.6, 1.0, 1.1, 0.8, 1.3]).view(6, 1, 1)
+    xe = x.clone()
+    xe[0, :, 0, 0] = 0.0                       # black pixel  -> Cmax = 0 path
+    xe[0, :, 0, 1] = 0.5                       # gray pixel   -> atan2(0,0)
+    xe[0, :, 0, 2] = torch.tensor([1.0, 0.0, 0.0])
+    xe[0, :, 0, 3] = torch.tensor([0.0, 0.0, 1.0])
+    ref_hsv = rgb2hsv(xe)
+    ref_rt = hsv2rgb(ref_hsv)
+    ref_adj = RandomHSVFunction.apply(xe, f_h, f_s, f_v)
+    check(O.rgb2hsv(xe), ref_hsv, 1e-7, 'rgb2hsv')
+    check(O.hsv2rgb(ref_hsv), ref_rt, 1e-7, 'hsv2rgb')
+    check(O.adjust_hsv(xe, f_h.view(6), f_s.view(6), f_v.view(6)), ref_adj, 1e-7, 'adjust_hsv')
+    out.update({'hsv_x': xe, 'hsv_fh': f_h.view(6), 'hsv_fs': f_s.view(6), 'hsv_fv': f_v.view(6),
+                'hsv_hsv': ref_hsv, 'hsv_roundtrip': ref_rt, 'hsv_adjusted': ref_adj})
+
+    cj = A.ColorJitterLayer()
+    fc = torch.tensor([0.6, 1.4, 1.0, 0.8, 1.25, 1.1])
+
+    class _Fixed(object):
+        def __init__(self, vals): self.vals = list(vals)
+    # contrast via the reference method with the factor injected through the RNG hook
+    orig_uniform = torch.Tensor.uniform_
+    try:
+        torch.Tensor.uniform_ = lambda self, *a, **k: self.copy_(fc.view_as(self))
+        ref_con = cj.adjust_contrast(x)
+    finally:
+        torch.Tensor.uniform_ = orig_uniform
+    check(O.adjust_contrast(x, fc), ref_con, 1e-7, 'contrast')
+    ref_gray = A.RandomColorGrayLayer()(x)
+    check(O.color_gray(x), ref_gray, 1e-7, 'gray')
+    out.update({'con_x': x, 'con_f': fc, 'con_out': ref_con, 'gray_out': ref_gray})
+
+    # --- flip is an exact permutation ---------------------------------------
+    sign = torch.tensor([1., -1., -1., 1., -1., 1.])
+    fl = O.hflip(x, sign)
+    for i in range(6):
+        exp = x[i] if sign[i] > 0 else x[i].flip(-1)
+        assert torch.equal(fl[i], exp), 'flip not exact'
+
+    # --- simclr_hq on a small "hq-like" image (64x64 -> ksize 7) with AFHQ strengths ----------
+    _refshim.bind_afhq()
+    B = 8
+    g = torch.Generator().manual_seed(321)
+    x = torch.rand(B, 3, 64, 64, generator=g)
+    torch.manual_seed(5); np.random.seed(5)
+    ref = A.simclr_hq()(x)
+    torch.manual_seed(5); np.random.seed(5)
+    p = O.sample_simclr_params(B, 64, 64, O.SIMCLR_HQ_AFHQ)
+    mine = O.simclr_apply(x, p)
+    check(mine, ref, 1e-6, 'simclr_hq')
+    out.update({'hq_x': x, 'hq_out': ref, 'hq_seed': 5})
+    out.update({'hq_' + k: v for k, v in _param_dict(p).items()})
+    _refshim.bind_cifar_defaults()
+    save('augment', **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def _load_sd(module, sd):
+    missing = module.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    return missing
+
+
+def gen_sndcgan():
+    from models.gan import get_architecture
+    from training.gan import contrad as ref_contrad
+    from argparse import Namespace
+    G, D = get_architecture('sndcgan', (32, 32, 3))
+    D.train(); G.train()
+
+    # state-dict key contract: names + shapes must match the oracle's table
+    shapes = O.sndcgan_d_param_shapes()
+    ref_shapes = {k: tuple(v.shape) for k, v in D.state_dict().items()}
+    assert ref_shapes == shapes, 'D state-dict mismatch'
+    gshapes = O.sndcgan_g_param_shapes()
+    ref_gshapes = {k: tuple(v.shape) for k, v in G.state_dict().items() if 'num_batches' not in k}
+    assert ref_gshapes == gshapes, (set(ref_gshapes) ^ set(gshapes))
+
+    sd = O.det_fill(shapes, seed=1234)
+    _load_sd(D, sd)
+    gsd = O.det_fill(gshapes, seed=4321)
+    gfull = dict(G.state_dict())
+    gfull.update({k: v.clone() for k, v in gsd.items()})
+    G.load_state_dict(gfull)
+
+    N = 4
+    g = torch.Generator().manual_seed(99)
+    x = torch.rand(N, 3, 32, 32, generator=g)
+    z = torch.rand(N, 128, generator=g) * 2 - 1
+
+    # ---- G forward (train-mode BN) ----
+    with torch.no_grad():
+        fake = G(z)
+    osd = {k: v.clone() for k, v in gsd.items()}
+    with torch.no_grad():
+        ofake = O.sndcgan_g_forward(osd, z)
+    check(ofake, fake, 1e-6, 'G forward')
+    gafter = G.state_dict()
+    for k in osd:
+        check(osd[k], gafter[k], 1e-6, 'G buffer ' + k)
+
+    # ---- contrad D loss with explicit augmentation = identity-free: feed pre-augmented images ----
+    torch.manual_seed(11); np.random.seed(11)
+    p = O.sample_simclr_params(3 * N, 32, 32, O.SIMCLR_CIFAR)
+    cat = torch.cat([x, x, fake], 0)
+    aug = O.simclr_apply(cat, p)
+
+    P = Namespace(augment_fn=lambda t: aug, temp=0.1, lbd_a=1.0, distributed=False)
+    D.zero_grad()
+    d_loss, aux = ref_contrad.loss_D_fn(P, D, {'loss': 'nonsat'}, x, fake)
+    (d_loss + aux['penalty']).backward()
+    ref_grads = {k: v.grad.clone() for k, v in D.named_parameters()}
+    ref_after = {k: v.clone() for k, v in D.state_dict().items()}
+
+    # oracle
+    osd = {k: v.clone() for k, v in sd.items()}
+    for k in osd:
+        if k.endswith('weight_orig') or k.endswith('bias'):
+            osd[k].requires_grad_()
+    fwd = lambda t: O.sndcgan_d_forward(osd, t, sg_linear=True)[:3]
+    closs, gloss, dr, dg = O.contrad_loss_d(fwd, aug, N)
+    (closs + gloss).backward()
+    check(closs, d_loss, 1e-6, 'contrad loss')
+    check(gloss, aux['penalty'], 1e-6, 'gan loss')
+    gerr = 0.0
+    for k, gref in ref_grads.items():
+        gerr = max(gerr, check(osd[k].grad, gref, 2e-5, 'grad ' + k))
+    for k in osd:
+        if k.endswith('weight_u') or k.endswith('weight_v'):
+            check(osd[k], ref_after[k], 1e-6, 'sn buffer ' + k)
+    print('  sndcgan D: max grad err vs reference %.2e' % gerr)
+
+    # forward outputs at the three heads
+    with torch.no_grad():
+        D2 = get_architecture('sndcgan', (32, 32, 3))[1]
+        D2.train(); _load_sd(D2, sd)
+        logit, auxo = D2(aug, sg_linear=True, projection=True, projection2=True, penultimate=True)
+
+    # ---- one Adam step on D (lr 2e-4, betas (.5,.999)) ----
+    opt = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    opt.step()
+    ref_post = {k: v.detach().clone() for k, v in D.named_parameters()}
+    omax = 0.0
+    for k, pref in ref_post.items():
+        pp = osd[k].detach().clone()
+        O.adam_step(pp, osd[k].grad, torch.zeros_like(pp), torch.zeros_like(pp), 1, 2e-4, 0.5, 0.999)
+        omax = max(omax, check(pp, pref, 1e-6, 'adam ' + k))
+
+    out = {'x': x, 'z': z, 'fake': fake, 'aug': aug, 'N': N,
+           'logit': logit, 'projection': auxo['projection'], 'projection2': auxo['projection2'],
+           'penultimate_head': auxo['penultimate'][:, :64], 'penultimate_sum': auxo['penultimate'].sum(1),
+           'contrad_loss': d_loss, 'gan_loss': aux['penalty'], 'd_real': aux['d_real'], 'd_gen': aux['d_gen']}
+    for k, gref in ref_grads.items():
+        out['gradnorm/' + k] = gref.norm()
+        if gref.numel() <= 4096:
+            out['grad/' + k] = gref
+        else:
+            out['gradhead/' + k] = gref.reshape(-1)[:512]
+    for k, v in ref_after.items():
+        if k.endswith('weight_u'):
+            out['after/' + k] = v
+        elif k.endswith('weight_v'):
+            out['afterhead/' + k] = v[:512]
+    for k, pref in ref_post.items():
+        out['adamsum/' + k] = pref.double().sum()
+        out['adamhead/' + k] = pref.reshape(-1)[:256]
+    for k in ('norm_init.running_mean', 'main.1.running_mean', 'main.1.running_var', 'main.7.running_var'):
+        out['gbuf/' + k] = gafter[k][:256]
+    out.update({'p_' + k: v for k, v in p.items() if v is not None})
+    save('sndcgan', **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_adam():
+    g = torch.Generator().manual_seed(5)
+    p = torch.randn(1000, generator=g)
+    grads = [torch.randn(1000, generator=g) * (10.0 ** (-i)) for i in range(4)]
+    for tag, (lr, b1, b2) in {'c10': (2e-4, 0.5, 0.999), 'sg2': (2e-3, 0.0, 0.99)}.items():
+        pr = torch.nn.Parameter(p.clone())
+        opt = torch.optim.Adam([pr], lr=lr, betas=(b1, b2))
+        po = p.clone(); m = torch.zeros_like(po); v = torch.zeros_like(po)
+        traj = []
+        for t, gr in enumerate(grads, 1):
+            pr.grad = gr.clone()
+            opt.step()
+            O.adam_step(po, gr, m, v, t, lr, b1, b2)
+            check(po, pr.detach(), 1e-6, 'adam traj')
+            traj.append(pr.detach().clone())
+        save('adam_' + tag, p0=p, grads=torch.stack(grads), traj=torch.stack(traj), lr=lr, b1=b1, b2=b2)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['losses', 'augment', 'sndcgan', 'adam']
+    for w in which:
+        globals()['gen_' + w]()
+    print('golden vectors OK')
