@@ -1,0 +1,154 @@
+"""GPU parity: implicit-GEMM conv engine (fwd / dgrad / wgrad) through the C ABI vs PyTorch-CPU fp32
+(the reference's arithmetic for F.conv2d / F.linear / ConvTranspose2d lives in PyTorch).
+Tolerance: 1e-3 relative to the tensor's max magnitude (north_star), typically ~1e-6 observed."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from contrad_amd import ops
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+# (N, H, W, C, K, k, stride, pad)
+CASES = [
+    (6, 32, 32, 64, 128, 4, 2, 1),     # SNDCGAN main.2
+    (6, 16, 16, 128, 128, 3, 1, 1),    # main.4
+    (6, 16, 16, 128, 256, 4, 2, 1),    # main.6
+    (6, 8, 8, 256, 256, 3, 1, 1),      # main.8
+    (6, 8, 8, 256, 512, 4, 2, 1),      # main.10
+    (6, 4, 4, 512, 512, 3, 1, 1),      # main.12
+    (5, 33, 33, 32, 64, 3, 2, 0),      # StyleGAN2 blurred 3x3 stride-2 (odd input)
+    (5, 17, 17, 64, 128, 1, 2, 0),     # StyleGAN2 skip: blurred 1x1 stride-2
+    (3, 9, 7, 8, 12, 3, 1, 1),         # ragged everything, K % 4 == 0
+    (2, 5, 5, 3, 64, 3, 1, 1),         # Cin = 3 (scalar gather fallback)
+    (7, 1, 1, 512, 1, 1, 1, 0),        # linear 512 -> 1 (Cout = 1)
+    (70, 1, 1, 8192, 384, 1, 1, 0),    # wide linear (heads)
+    (3, 6, 6, 516, 32, 3, 1, 1),       # Cin = 513 padded to 516 (last_conv)
+]
+
+
+def rel(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def lrelu_ref(y, slope, gain):
+    return F.leaky_relu(y, slope) * gain
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_fwd_dgrad_wgrad(case):
+    N, H, W, C, K, k, s, p = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, k, k, generator=g) * 0.1
+    b = torch.randn(K, generator=g)
+    slope, gain = 0.2, 2 ** 0.5
+
+    xr = x.clone().requires_grad_()
+    wr = w.clone().requires_grad_()
+    y_lin = F.conv2d(xr, wr, b, stride=s, padding=p)
+    y_ref = lrelu_ref(y_lin, slope, gain)
+    gy = torch.randn(y_ref.shape, generator=g)
+    # gradient wrt the pre-activation conv output: feed dgrad/wgrad the same gy on the linear conv
+    gx_ref, gw_ref = torch.autograd.grad(y_lin, (xr, wr), gy)
+
+    dev = torch.device('cuda')
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wp = ops.pack_weight(w).to(dev)
+    y = ops.conv2d_fwd(x_nhwc, wp, b.to(dev), K, k, k, s, p, slope, gain)
+    assert rel(y.permute(0, 3, 1, 2).cpu(), y_ref.detach()) < TOL
+
+    gy_nhwc = gy.permute(0, 2, 3, 1).contiguous().to(dev)
+    dx = ops.conv2d_dgrad(gy_nhwc, wp, (N, H, W, C), k, k, s, p)
+    assert rel(dx.permute(0, 3, 1, 2).cpu(), gx_ref) < TOL
+
+    dwp = ops.conv2d_wgrad(x_nhwc, gy_nhwc, k, k, s, p)
+    dw = ops.unpack_weight(dwp.cpu(), K, C, k, k)
+    assert rel(dw, gw_ref) < TOL
+
+
+def test_dgrad_fused_activation_derivative():
+    """dgrad epilogue multiplies by lrelu'(act_ref) * gain -- the backward of the producer's activation."""
+    N, H, W, C, K, k, s, p = 4, 8, 8, 64, 64, 3, 1, 1
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(N, C, H, W, generator=g)             # pre-activation of the producer layer
+    w = torch.randn(K, C, k, k, generator=g) * 0.1
+    ar = a.clone().requires_grad_()
+    x = F.leaky_relu(ar, 0.1)
+    y = F.conv2d(x, w, None, stride=s, padding=p)
+    gy = torch.randn(y.shape, generator=g)
+    ga_ref, = torch.autograd.grad(y, ar, gy)
+    dev = torch.device('cuda')
+    x_nhwc = x.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+    da = ops.conv2d_dgrad(gy.permute(0, 2, 3, 1).contiguous().to(dev), ops.pack_weight(w).to(dev),
+                          (N, H, W, C), k, k, s, p, act_ref=x_nhwc, slope=0.1, gain=1.0)
+    assert rel(da.permute(0, 3, 1, 2).cpu(), ga_ref) < TOL
+
+
+def test_conv_transpose_is_dgrad():
+    """nn.ConvTranspose2d forward (G_SNDCGAN, sndcgan.py:26-38) == dgrad of the matching conv."""
+    N, Cin, Cout, k, s, p, H = 4, 64, 32, 4, 2, 1, 8
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(N, Cin, H, H, generator=g)
+    w = torch.randn(Cin, Cout, k, k, generator=g) * 0.1     # ConvTranspose2d weight layout
+    ref = F.conv_transpose2d(x, w, None, stride=s, padding=p)
+    dev = torch.device('cuda')
+    # as a conv weight this is (K=Cin, C=Cout, k, k); the transposed conv's output is that conv's input
+    wp = ops.pack_weight(w).to(dev)
+    out = ops.conv2d_dgrad(x.permute(0, 2, 3, 1).contiguous().to(dev), wp, (N, 2 * H, 2 * H, Cout), k, k, s, p)
+    assert rel(out.permute(0, 3, 1, 2).cpu(), ref) < TOL
+
+
+def test_channel_sliced_views():
+    """Leading dimensions: read a channel slice of a wider NHWC buffer, write into a slice of another."""
+    N, H, W = 3, 4, 4
+    g = torch.Generator().manual_seed(5)
+    big = torch.randn(N, H, W, 96, generator=g)
+    w = torch.randn(48, 32, 1, 1, generator=g)
+    dev = torch.device('cuda')
+    bigd = big.to(dev)
+    outbuf = torch.zeros(N, H, W, 80, device=dev)
+    ops.conv2d_fwd(bigd[..., 32:64], ops.pack_weight(w).to(dev), None, 48, 1, 1, 1, 0, out=outbuf[..., 16:64])
+    ref = F.conv2d(big[..., 32:64].permute(0, 3, 1, 2), w).permute(0, 2, 3, 1)
+    assert rel(outbuf[..., 16:64].cpu(), ref) < TOL
+    assert outbuf[..., :16].abs().max().item() == 0 and outbuf[..., 64:].abs().max().item() == 0
+
+
+def test_wgrad_is_deterministic_and_linear():
+    N, H, W, C, K = 64, 16, 16, 128, 128
+    dev = torch.device('cuda')
+    g = torch.Generator(device='cuda').manual_seed(0)
+    x = torch.randn(N, H, W, C, device=dev, generator=g)
+    gy = torch.randn(N, H, W, K, device=dev, generator=g)
+    a = ops.conv2d_wgrad(x, gy, 3, 3, 1, 1).clone()
+    b = ops.conv2d_wgrad(x, gy, 3, 3, 1, 1).clone()
+    assert torch.equal(a, b)                                   # fixed-order split reduction
+    c = ops.conv2d_wgrad(x, gy * 2.0, 3, 3, 1, 1)
+    assert torch.equal(c, a * 2.0)                             # exact power-of-two linearity
+
+
+def test_full_size_sndcgan_layer_linearity():
+    """BASELINE size (3N = 1536 images, main.4 128->128 3x3 at 16x16): size-independent properties."""
+    dev = torch.device('cuda')
+    g = torch.Generator(device='cuda').manual_seed(1)
+    x = torch.randn(1536, 16, 16, 128, device=dev, generator=g)
+    w = torch.randn(128, 128, 3, 3, device=dev, generator=g) * 0.05
+    wp = ops.pack_weight(w)
+    y = ops.conv2d_fwd(x, wp, None, 128, 3, 3, 1, 1)
+    # batch independence: the first 8 images alone give bitwise the same rows
+    y8 = ops.conv2d_fwd(x[:8].contiguous(), wp, None, 128, 3, 3, 1, 1)
+    assert torch.equal(y[:8], y8)
+    # adjoint identity <conv(x), gy> == <x, dgrad(gy)>
+    gy = torch.randn_like(y)
+    dx = ops.conv2d_dgrad(gy, wp, tuple(x.shape), 3, 3, 1, 1)
+    lhs = (y.double() * gy.double()).sum()
+    rhs = (x.double() * dx.double()).sum()
+    assert abs(lhs - rhs) / abs(lhs) < 1e-4
+    # and == <w, wgrad(x, gy)>
+    dwp = ops.conv2d_wgrad(x, gy, 3, 3, 1, 1)
+    rhs2 = (wp.double() * dwp.double()).sum()
+    assert abs(lhs - rhs2) / abs(lhs) < 1e-4
+    # spot-check 4 images against PyTorch CPU
+    ref = F.conv2d(x[:4].cpu().permute(0, 3, 1, 2), w.cpu(), padding=1).permute(0, 2, 3, 1)
+    assert rel(y[:4].cpu(), ref) < TOL

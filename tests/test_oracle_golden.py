@@ -1,0 +1,145 @@
+"""CPU suite: the oracle (oracle/contrad_oracle.py) against the committed golden vectors that
+tests/golden/make_golden.py captured from the imported reference."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import contrad_oracle as O
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(a, b, tol=1e-6):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item())
+
+
+def test_known_answers(golden):
+    g = golden('losses')
+    torch.manual_seed(0)
+    z = F.normalize(torch.randn(12, 16))
+    assert abs(O.nt_xent(z[:4], z[4:8], 0.1).item() - float(g['known_nt_xent'])) < 1e-6
+    assert abs(O.supcon_fake(z[:4], z[4:8], z[8:], 0.1).item() - float(g['known_supcon'])) < 1e-6
+    assert abs(float(g['known_nt_xent']) - 4.954558372497559) < 1e-6
+    assert abs(float(g['known_supcon']) - 3.962817430496216) < 1e-6
+
+
+def test_losses_and_grads(golden):
+    g = golden('losses')
+    for tag in ('small', 'mid', 'hot'):
+        N, temp = int(g[tag + '_N']), float(g[tag + '_temp'])
+        u1 = T(g[tag + '_u1']).requires_grad_()
+        u2 = T(g[tag + '_u2']).requires_grad_()
+        v, r = F.normalize(u1), F.normalize(u2)
+        l1 = O.nt_xent(v[:N], v[N:2 * N], temp)
+        l2 = O.supcon_fake(r[:N], r[N:2 * N], r[2 * N:], temp)
+        (l1 + l2).backward()
+        assert close(l1, g[tag + '_nt_xent']) and close(l2, g[tag + '_supcon'])
+        assert close(u1.grad, g[tag + '_g1']) and close(u2.grad, g[tag + '_g2'])
+
+
+def _params(g, tag):
+    p = {}
+    for k in g.files:
+        if k.startswith(tag + '_p_'):
+            v = g[k]
+            name = k[len(tag) + 3:]
+            p[name] = bool(v) if name == 'contrast_first' else (float(v) if name == 'sigma' else T(v))
+    return p
+
+
+def test_simclr_pipeline_and_sampler(golden):
+    g = golden('augment')
+    for tag in ('c10a', 'c10b'):
+        x = T(g[tag + '_x'])
+        p = _params(g, tag)
+        assert close(O.simclr_apply(x, p), g[tag + '_out'])
+        assert close(O.resized_crop(x, p['theta']), g[tag + '_stage_crop'])
+        # the host sampler reproduces the reference's RNG draw order
+        seed = int(g[tag + '_seed'])
+        torch.manual_seed(seed); np.random.seed(seed)
+        q = O.sample_simclr_params(x.size(0), 32, 32, O.SIMCLR_CIFAR)
+        for k, v in p.items():
+            if isinstance(v, torch.Tensor):
+                assert torch.equal(q[k], v), k
+            else:
+                assert q[k] == v, k
+    x = T(g['hq_x'])
+    p = _params(g, 'hq')
+    assert 'blur_mask' in p and 'sigma' in p
+    assert close(O.simclr_apply(x, p), g['hq_out'])
+
+
+def test_colour_stages(golden):
+    g = golden('augment')
+    x = T(g['hsv_x'])
+    assert close(O.rgb2hsv(x), g['hsv_hsv'], 1e-7)
+    assert close(O.hsv2rgb(T(g['hsv_hsv'])), g['hsv_roundtrip'], 1e-7)
+    assert close(O.adjust_hsv(x, T(g['hsv_fh']), T(g['hsv_fs']), T(g['hsv_fv'])), g['hsv_adjusted'], 1e-7)
+    assert close(O.adjust_contrast(T(g['con_x']), T(g['con_f'])), g['con_out'], 1e-7)
+    assert close(O.color_gray(T(g['con_x'])), g['gray_out'], 1e-7)
+
+
+def test_flip_is_exact_permutation():
+    x = torch.rand(4, 3, 32, 32)
+    s = torch.tensor([1., -1., 1., -1.])
+    y = O.hflip(x, s)
+    assert torch.equal(y[0], x[0]) and torch.equal(y[1], x[1].flip(-1))
+
+
+def test_gaussian_blur_properties():
+    # kornia is absent (parity unpinned): validate the restated contract by properties
+    k = O.gaussian_kernel1d(51, 1.3)
+    assert abs(k.sum().item() - 1) < 1e-6 and torch.allclose(k, k.flip(0))
+    x = torch.full((1, 3, 64, 64), 0.37)
+    assert torch.allclose(O.gaussian_blur(x, 0.9), x, atol=1e-6)
+    x = torch.rand(2, 3, 40, 40)
+    g1 = O.gaussian_kernel1d(5, 0.7)
+    xp = F.pad(x, [2, 2, 2, 2], mode='reflect')
+    sep = F.conv2d(F.conv2d(xp, g1.view(1, 1, 5, 1).repeat(3, 1, 1, 1), groups=3),
+                   g1.view(1, 1, 1, 5).repeat(3, 1, 1, 1), groups=3)
+    assert torch.allclose(O.gaussian_blur(x, 0.7), sep, atol=1e-6)
+
+
+def test_sndcgan_step(golden):
+    g = golden('sndcgan')
+    N = int(g['N'])
+    sd = O.det_fill(O.sndcgan_d_param_shapes(), seed=1234)
+    gsd = O.det_fill(O.sndcgan_g_param_shapes(), seed=4321)
+    with torch.no_grad():
+        fake = O.sndcgan_g_forward(gsd, T(g['z']))
+    assert close(fake, g['fake'])
+    assert close(gsd['main.1.running_var'][:256], g['gbuf/main.1.running_var'])
+    for k in sd:
+        if k.endswith('weight_orig') or k.endswith('bias'):
+            sd[k].requires_grad_()
+    aug = T(g['aug'])
+    closs, gloss, dr, dg = O.contrad_loss_d(lambda t: O.sndcgan_d_forward(sd, t, sg_linear=True)[:3], aug, N)
+    (closs + gloss).backward()
+    assert close(closs, g['contrad_loss']) and close(gloss, g['gan_loss'])
+    assert close(dr, g['d_real']) and close(dg, g['d_gen'])
+    for k in g.files:
+        if k.startswith('gradnorm/'):
+            name = k[len('gradnorm/'):]
+            assert close(sd[name].grad.norm(), g[k], 2e-5), name
+        if k.startswith('after/'):
+            assert close(sd[k[len('after/'):]], g[k]), k
+    # Adam (lr 2e-4, betas (.5,.999), step 1)
+    for k in g.files:
+        if k.startswith('adamhead/'):
+            name = k[len('adamhead/'):]
+            p = sd[name].detach().clone()
+            O.adam_step(p, sd[name].grad, torch.zeros_like(p), torch.zeros_like(p), 1, 2e-4, 0.5, 0.999)
+            assert close(p.reshape(-1)[:256], g[k]), name
+
+
+def test_adam_trajectory(golden):
+    for tag in ('c10', 'sg2'):
+        g = golden('adam_' + tag)
+        p = T(g['p0']).clone(); m = torch.zeros_like(p); v = torch.zeros_like(p)
+        for t, gr in enumerate(T(g['grads']), 1):
+            O.adam_step(p, gr, m, v, t, float(g['lr']), float(g['b1']), float(g['b2']))
+            assert close(p, g['traj'][t - 1])
+    assert O.warmup_lr(0, 3000, 2e-4) == 2e-4 / 3000 and O.warmup_lr(5000, 3000, 2e-4) == 2e-4

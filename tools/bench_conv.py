@@ -1,0 +1,51 @@
+"""Per-layer timing of the conv engine at the BASELINE shape (SNDCGAN, 3N = 1536 images).  Dev tool."""
+import sys
+import os
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from contrad_amd import ops
+
+LAYERS = [(32, 64, 128, 4, 2, 1), (16, 128, 128, 3, 1, 1), (16, 128, 256, 4, 2, 1), (8, 256, 256, 3, 1, 1),
+          (8, 256, 512, 4, 2, 1), (4, 512, 512, 3, 1, 1), (1, 8192, 1536, 1, 1, 0)]
+
+
+def timeit(fn, iters=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main(B=1536):
+    dev = torch.device('cuda')
+    tot = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
+    totf = 0.0
+    for (H, C, K, k, s, p) in LAYERS:
+        x = torch.randn(B, H, H, C, device=dev)
+        wp = torch.randn(k * k * C, K, device=dev) * 0.05
+        Ho = ops.out_size(H, k, s, p)
+        gy = torch.randn(B, Ho, Ho, K, device=dev)
+        y = torch.empty(B, Ho, Ho, K, device=dev)
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(wp)
+        flops = 2.0 * B * Ho * Ho * K * C * k * k
+        t_f = timeit(lambda: ops.conv2d_fwd(x, wp, None, K, k, k, s, p, 0.1, 1.0, out=y))
+        t_d = timeit(lambda: ops.conv2d_dgrad(gy, wp, tuple(x.shape), k, k, s, p, out=dx))
+        t_w = timeit(lambda: ops.conv2d_wgrad(x, gy, k, k, s, p, out=dw))
+        print('H%-3d C%-4d K%-4d k%d s%d  %6.1f GF | fwd %7.3f ms %6.1f TF | dgrad %7.3f ms %6.1f TF | wgrad %7.3f ms %6.1f TF'
+              % (H, C, K, k, s, flops / 1e9, t_f, flops / t_f / 1e9, t_d, flops / t_d / 1e9, t_w, flops / t_w / 1e9),
+              flush=True)
+        tot['fwd'] += t_f; tot['dgrad'] += t_d; tot['wgrad'] += t_w; totf += flops
+    for k_, v in tot.items():
+        print('%-6s total %7.3f ms  %6.1f TF/s' % (k_, v, totf / v / 1e9))
+
+
+if __name__ == '__main__':
+    main()
