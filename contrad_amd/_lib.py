@@ -15,6 +15,37 @@ class ConvDesc(ctypes.Structure):
                 ('N', 'H', 'W', 'C', 'ldx', 'Ho', 'Wo', 'K', 'ldy', 'KH', 'KW', 'stride', 'pad', 'ldw')]
 
 
+SN_MAX_LAYERS = 24
+ADAM_MAX_TENSORS = 64
+ADAM_CHUNK = 16384
+AUG_NPARAM = 12
+
+
+class SnLayer(ctypes.Structure):
+    """contrad_sn_layer."""
+    _fields_ = [('w', ctypes.c_void_p), ('u', ctypes.c_void_p), ('v', ctypes.c_void_p),
+                ('u_snap', ctypes.c_void_p), ('v_snap', ctypes.c_void_p),
+                ('wp', ctypes.c_void_p), ('gwp', ctypes.c_void_p), ('gw', ctypes.c_void_p),
+                ('K', ctypes.c_int), ('C', ctypes.c_int), ('T', ctypes.c_int), ('ldw', ctypes.c_int),
+                ('fixed_scale', ctypes.c_float)]
+
+
+class SnBatch(ctypes.Structure):
+    """contrad_sn_batch."""
+    _fields_ = [('n', ctypes.c_int), ('layers', SnLayer * SN_MAX_LAYERS),
+                ('scratch_off', ctypes.c_longlong * SN_MAX_LAYERS)]
+
+
+class AdamTensor(ctypes.Structure):
+    _fields_ = [('p', ctypes.c_void_p), ('g', ctypes.c_void_p), ('m', ctypes.c_void_p), ('v', ctypes.c_void_p),
+                ('numel', ctypes.c_longlong)]
+
+
+class AdamBatch(ctypes.Structure):
+    _fields_ = [('n', ctypes.c_int), ('t', AdamTensor * ADAM_MAX_TENSORS),
+                ('block_start', ctypes.c_int * (ADAM_MAX_TENSORS + 1))]
+
+
 _CTYPES = {
     'int': ctypes.c_int,
     'float': ctypes.c_float,

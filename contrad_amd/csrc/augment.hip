@@ -1,0 +1,330 @@
+// Fused SimCLR augmentation (augment/__init__.py:106-122): RandomResizeCrop + HorizontalFlip (one bilinear
+// gather; the flip is an exact column permutation composed into the crop's sampling grid), RandomApply(
+// ColorJitter) (contrast + the reference's atan2-HSV jitter with its 255/360 hue quirk, in either order),
+// RandomApply(gray) -- ONE read and ONE write of the 3N-image batch instead of ~25 elementwise launches.
+// All random parameters are sampled on the host in the reference's RNG draw order and passed per sample:
+//   params[n][0..3]  = theta00, theta11, theta02, theta12   (augment/spatial.py:140-143)
+//   params[n][4]     = flip sign (+1 / -1)                  (spatial.py:89-90)
+//   params[n][5]     = colour-jitter mask, [6] = contrast factor, [7..9] = f_h, f_s, f_v
+//   params[n][10]    = gray mask, [11] = blur mask (used by the blur kernels only)
+//
+// Small images (3*H*W*4 B <= 64 KiB: CIFAR 32x32, up to 64x64): one block per image, the image lives in LDS
+// between stages so the per-channel contrast mean costs no extra HBM pass.
+// Large images (AFHQ 512x512): a statistics pass (gather [+HSV] -> channel sums, the source stays hot in the
+// 256 MiB Infinity Cache) followed by an apply pass that recomputes the gather; optional separable Gaussian
+// blur (GaussianBlur, augment/__init__.py:53-78) with reflect padding, tiles staged in LDS.
+#include "common.h"
+#include "../../include/contrad_hip.h"
+
+namespace {
+
+constexpr int NPARAM = CONTRAD_AUG_NPARAM;
+constexpr float TWO_PI = 6.283185307179586f;
+constexpr float SQRT3 = 1.7320508075688772f;
+
+// ATen remainder for floats: fmod, then shift into the divisor's sign
+__device__ __forceinline__ float py_mod(float a, float b) {
+  float m = fmodf(a, b);
+  if (m != 0.f && ((b < 0.f) != (m < 0.f))) m += b;
+  return m;
+}
+
+// grid_sample(..., padding_mode='reflection', align_corners=False) coordinate handling (ATen GridSampler.h)
+__device__ __forceinline__ float reflect_coord(float in, int size) {
+  // reflect over [-0.5, size-0.5]  (twice_low = -1, twice_high = 2*size - 1)
+  const float mn = -0.5f, span = (float)size;
+  in = fabsf(in - mn);
+  const float extra = fmodf(in, span);
+  const int flips = (int)floorf(in / span);
+  const float r = (flips & 1) ? (span - extra + mn) : (extra + mn);
+  return fminf((float)(size - 1), fmaxf(r, 0.f));
+}
+
+struct AugArgs {
+  const float* x;       // NCHW (B,3,H,W)
+  float* y;             // NCHW
+  const float* params;  // [B][NPARAM]
+  int B, H, W;
+  int contrast_first, has_contrast;
+};
+
+// bilinear sample of channel plane `src` (H x W) at output pixel (i, j) under the crop+flip of sample n
+struct Sampler {
+  int x0, y0, x1, y1;
+  float wx0, wx1, wy0, wy1;
+  bool vx0, vx1, vy0, vy1;
+};
+__device__ __forceinline__ Sampler make_sampler(const float* pr, int i, int j, int H, int W) {
+  const int jj = (pr[4] < 0.f) ? (W - 1 - j) : j;
+  const float xn = (2.f * jj + 1.f) / (float)W - 1.f;
+  const float yn = (2.f * i + 1.f) / (float)H - 1.f;
+  const float gx = pr[0] * xn + pr[2];
+  const float gy = pr[1] * yn + pr[3];
+  float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+  float iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+  ix = reflect_coord(ix, W);
+  iy = reflect_coord(iy, H);
+  Sampler s;
+  const float fx = floorf(ix), fy = floorf(iy);
+  s.x0 = (int)fx; s.y0 = (int)fy; s.x1 = s.x0 + 1; s.y1 = s.y0 + 1;
+  s.wx1 = ix - fx; s.wx0 = 1.f - s.wx1;
+  s.wy1 = iy - fy; s.wy0 = 1.f - s.wy1;
+  s.vx0 = (unsigned)s.x0 < (unsigned)W; s.vx1 = (unsigned)s.x1 < (unsigned)W;
+  s.vy0 = (unsigned)s.y0 < (unsigned)H; s.vy1 = (unsigned)s.y1 < (unsigned)H;
+  return s;
+}
+__device__ __forceinline__ float sample_plane(const float* src, const Sampler& s, int W) {
+  float v = 0.f;
+  if (s.vy0 && s.vx0) v += src[s.y0 * W + s.x0] * (s.wx0 * s.wy0);   // nw
+  if (s.vy0 && s.vx1) v += src[s.y0 * W + s.x1] * (s.wx1 * s.wy0);   // ne
+  if (s.vy1 && s.vx0) v += src[s.y1 * W + s.x0] * (s.wx0 * s.wy1);   // sw
+  if (s.vy1 && s.vx1) v += src[s.y1 * W + s.x1] * (s.wx1 * s.wy1);   // se
+  return v;
+}
+
+__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+
+// RandomHSVFunction.forward (augment/color_jitter.py:83-95) with rgb2hsv / hsv2rgb of augment/utils.py
+__device__ __forceinline__ void hsv_jitter(float& r, float& g, float& b, float fh, float fs, float fv) {
+  const float cmax = fmaxf(r, fmaxf(g, b)), cmin = fminf(r, fminf(g, b));
+  float hue = atan2f(SQRT3 * (g - b), 2.f * r - g - b);
+  hue = py_mod(hue, TWO_PI) / TWO_PI;
+  float sat = 1.f - cmin / (cmax + 1e-8f);
+  float val = cmax;
+  if (!isfinite(hue)) hue = 0.f;
+  if (!isfinite(sat)) sat = 0.f;
+  if (!isfinite(val)) val = 0.f;
+  float h = hue + (fh * 255.f) / 360.f;
+  h = py_mod(h, 1.f);
+  h = clamp01(h);
+  const float s = clamp01(sat * fs), v = clamp01(val * fv);
+  const float c = v * s;
+  const float h6 = h * 6.f;
+  float k, t;
+  k = py_mod(5.f + h6, 6.f); t = clamp01(fminf(k, 4.f - k)); r = v - c * t;
+  k = py_mod(3.f + h6, 6.f); t = clamp01(fminf(k, 4.f - k)); g = v - c * t;
+  k = py_mod(1.f + h6, 6.f); t = clamp01(fminf(k, 4.f - k)); b = v - c * t;
+}
+
+__device__ __forceinline__ void gray3(float& r, float& g, float& b) {
+  const float l = 0.299f * r + 0.587f * g + 0.114f * b;
+  r = l; g = l; b = l;
+}
+
+// ---------------- small images: one block per image, image resident in LDS ----------------
+__global__ __launch_bounds__(256) void simclr_small_kernel(AugArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float img[];  // [3][H*W]
+  __shared__ float red[16];
+  __shared__ float mean[3];
+  const int n = blockIdx.x;
+  const int HW = a.H * a.W;
+  const float* pr = a.params + (size_t)n * NPARAM;
+  const float* src = a.x + (size_t)n * 3 * HW;
+  const bool jitter = pr[5] != 0.f, gray = pr[10] != 0.f;
+  const float fc = pr[6], fh = pr[7], fs = pr[8], fv = pr[9];
+
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    const int i = p / a.W, j = p - i * a.W;
+    const Sampler s = make_sampler(pr, i, j, a.H, a.W);
+    float r = sample_plane(src, s, a.W), g = sample_plane(src + HW, s, a.W), b = sample_plane(src + 2 * HW, s, a.W);
+    if (jitter && !a.contrast_first) hsv_jitter(r, g, b, fh, fs, fv);
+    img[p] = r; img[HW + p] = g; img[2 * HW + p] = b;
+  }
+  __syncthreads();
+  if (jitter) {
+    if (a.has_contrast) {
+      for (int c = 0; c < 3; ++c) {
+        float s = 0.f;
+        for (int p = threadIdx.x; p < HW; p += blockDim.x) s += img[c * HW + p];
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) mean[c] = s / (float)HW;
+      }
+      __syncthreads();
+    }
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+      float r = img[p], g = img[HW + p], b = img[2 * HW + p];
+      if (a.has_contrast) {
+        r = (r - mean[0]) * fc + mean[0]; g = (g - mean[1]) * fc + mean[1]; b = (b - mean[2]) * fc + mean[2];
+      }
+      r = clamp01(r); g = clamp01(g); b = clamp01(b);
+      if (a.contrast_first) hsv_jitter(r, g, b, fh, fs, fv);
+      img[p] = r; img[HW + p] = g; img[2 * HW + p] = b;
+    }
+    __syncthreads();
+  }
+  float* dst = a.y + (size_t)n * 3 * HW;
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    float r = img[p], g = img[HW + p], b = img[2 * HW + p];
+    if (gray) gray3(r, g, b);
+    dst[p] = r; dst[HW + p] = g; dst[2 * HW + p] = b;
+  }
+}
+
+// ---------------- large images ----------------
+// pass 1: per-(image, channel) sums of the contrast input; partial[n][blockIdx.y][3]
+__global__ __launch_bounds__(256) void simclr_stats_kernel(AugArgs a, float* __restrict__ partial) {
+  __shared__ float red[16];
+  const int n = blockIdx.x;
+  const int HW = a.H * a.W;
+  const float* pr = a.params + (size_t)n * NPARAM;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  if (pr[5] != 0.f && a.has_contrast) {   // only jittered samples need the means
+    const float* src = a.x + (size_t)n * 3 * HW;
+    for (int p = blockIdx.y * blockDim.x + threadIdx.x; p < HW; p += gridDim.y * blockDim.x) {
+      const int i = p / a.W, j = p - i * a.W;
+      const Sampler s = make_sampler(pr, i, j, a.H, a.W);
+      float r = sample_plane(src, s, a.W), g = sample_plane(src + HW, s, a.W), b = sample_plane(src + 2 * HW, s, a.W);
+      if (!a.contrast_first) hsv_jitter(r, g, b, pr[7], pr[8], pr[9]);
+      s0 += r; s1 += g; s2 += b;
+    }
+  }
+  s0 = block_sum(s0, red); s1 = block_sum(s1, red); s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    float* o = partial + ((size_t)n * gridDim.y + blockIdx.y) * 3;
+    o[0] = s0; o[1] = s1; o[2] = s2;
+  }
+}
+
+// pass 2: recompute the gather and finish the colour pipeline
+__global__ __launch_bounds__(256) void simclr_apply_kernel(AugArgs a, const float* __restrict__ partial, int nparts) {
+  __shared__ float mean[3];
+  const int n = blockIdx.x;
+  const int HW = a.H * a.W;
+  const float* pr = a.params + (size_t)n * NPARAM;
+  const bool jitter = pr[5] != 0.f, gray = pr[10] != 0.f;
+  if (threadIdx.x < 3) {
+    float s = 0.f;
+    for (int q = 0; q < nparts; ++q) s += partial[((size_t)n * nparts + q) * 3 + threadIdx.x];
+    mean[threadIdx.x] = s / (float)HW;
+  }
+  __syncthreads();
+  const float* src = a.x + (size_t)n * 3 * HW;
+  float* dst = a.y + (size_t)n * 3 * HW;
+  const float fc = pr[6], fh = pr[7], fs = pr[8], fv = pr[9];
+  for (int p = blockIdx.y * blockDim.x + threadIdx.x; p < HW; p += gridDim.y * blockDim.x) {
+    const int i = p / a.W, j = p - i * a.W;
+    const Sampler s = make_sampler(pr, i, j, a.H, a.W);
+    float r = sample_plane(src, s, a.W), g = sample_plane(src + HW, s, a.W), b = sample_plane(src + 2 * HW, s, a.W);
+    if (jitter) {
+      if (!a.contrast_first) hsv_jitter(r, g, b, fh, fs, fv);
+      if (a.has_contrast) {
+        r = (r - mean[0]) * fc + mean[0]; g = (g - mean[1]) * fc + mean[1]; b = (b - mean[2]) * fc + mean[2];
+      }
+      r = clamp01(r); g = clamp01(g); b = clamp01(b);
+      if (a.contrast_first) hsv_jitter(r, g, b, fh, fs, fv);
+    }
+    if (gray) gray3(r, g, b);
+    dst[p] = r; dst[HW + p] = g; dst[2 * HW + p] = b;
+  }
+}
+
+// ---------------- separable Gaussian blur with reflect padding (masked per sample) ----------------
+// horizontal: tmp[n,c,i,j] = sum_t g[t] x[n,c,i,reflect(j+t-R)];  vertical likewise on tmp -> y.
+// Un-masked samples are copied through (RandomApply select).  One block per (plane row-tile).
+__device__ __forceinline__ int reflect_idx(int i, int n) {  // F.pad(mode='reflect'): no edge repeat
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i;
+}
+
+constexpr int BLUR_MAXK = 129;
+
+__global__ __launch_bounds__(256) void blur_h_kernel(const float* __restrict__ x, float* __restrict__ tmp,
+                                                     const float* __restrict__ params, int H, int W, int R,
+                                                     const float* __restrict__ gk) {
+  extern __shared__ __attribute__((aligned(16))) float row[];  // [W + 2R]
+  __shared__ float g[BLUR_MAXK];
+  const int plane = blockIdx.y, n = plane / 3, i = blockIdx.x;
+  if (params[(size_t)n * NPARAM + 11] == 0.f) return;  // uniform per block
+  const float* src = x + ((size_t)plane * H + i) * W;
+  for (int t = threadIdx.x; t < 2 * R + 1; t += blockDim.x) g[t] = gk[t];
+  for (int j = threadIdx.x; j < W + 2 * R; j += blockDim.x) row[j] = src[reflect_idx(j - R, W)];
+  __syncthreads();
+  float* dst = tmp + ((size_t)plane * H + i) * W;
+  for (int j = threadIdx.x; j < W; j += blockDim.x) {
+    float s = 0.f;
+    for (int t = 0; t < 2 * R + 1; ++t) s = fmaf(g[t], row[j + t], s);
+    dst[j] = s;
+  }
+}
+
+// vertical pass over a column strip of 64 columns: block (64 x 4), LDS tile [(TH + 2R)][64]
+constexpr int BLUR_TH = 64;
+__global__ __launch_bounds__(256) void blur_v_kernel(const float* __restrict__ tmp, const float* __restrict__ x,
+                                                     float* __restrict__ y, const float* __restrict__ params,
+                                                     int H, int W, int R, const float* __restrict__ gk) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [(BLUR_TH + 2R)][64]
+  __shared__ float g[BLUR_MAXK];
+  const int plane = blockIdx.z, n = plane / 3;
+  const int j0 = blockIdx.x * 64, i0 = blockIdx.y * BLUR_TH;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const bool masked = params[(size_t)n * NPARAM + 11] != 0.f;
+  const size_t pbase = (size_t)plane * H * W;
+  if (!masked) {
+    if (x != y)
+      for (int r = ty; r < BLUR_TH; r += 4) {
+        const int i = i0 + r, j = j0 + tx;
+        if (i < H && j < W) y[pbase + (size_t)i * W + j] = x[pbase + (size_t)i * W + j];
+      }
+    return;
+  }
+  for (int t = threadIdx.x; t < 2 * R + 1; t += blockDim.x) g[t] = gk[t];
+  for (int r = ty; r < BLUR_TH + 2 * R; r += 4) {
+    const int i = reflect_idx(i0 + r - R, H), j = j0 + tx;
+    tile[r * 64 + tx] = (j < W) ? tmp[pbase + (size_t)i * W + j] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < BLUR_TH; r += 4) {
+    const int i = i0 + r, j = j0 + tx;
+    if (i < H && j < W) {
+      float s = 0.f;
+      for (int t = 0; t < 2 * R + 1; ++t) s = fmaf(g[t], tile[(r + t) * 64 + tx], s);
+      y[pbase + (size_t)i * W + j] = s;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" long long contrad_simclr_workspace_bytes(int B, int H, int W) {
+  if ((long long)3 * H * W * 4 <= 64 * 1024) return 16;
+  const int nparts = cdiv(H * W, 256 * 16);
+  return (long long)B * nparts * 3 * (long long)sizeof(float);
+}
+
+extern "C" int contrad_simclr_augment(const float* x, float* y, const float* params, int B, int H, int W,
+                                      int contrast_first, int has_contrast, float* workspace,
+                                      long long workspace_bytes, contrad_stream_t stream) {
+  CONTRAD_ARG(x && y && params && B > 0 && H > 1 && W > 1 && x != y);
+  AugArgs a{x, y, params, B, H, W, contrast_first, has_contrast};
+  hipStream_t s = (hipStream_t)stream;
+  const size_t img_bytes = (size_t)3 * H * W * sizeof(float);
+  if (img_bytes <= 64 * 1024) {
+    hipLaunchKernelGGL(simclr_small_kernel, dim3(B), dim3(256), img_bytes, s, a);
+    CONTRAD_CHECK_LAUNCH();
+    return 0;
+  }
+  CONTRAD_ARG(workspace && workspace_bytes >= contrad_simclr_workspace_bytes(B, H, W));
+  const int nparts = cdiv(H * W, 256 * 16);
+  hipLaunchKernelGGL(simclr_stats_kernel, dim3(B, nparts), dim3(256), 0, s, a, workspace);
+  CONTRAD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(simclr_apply_kernel, dim3(B, nparts), dim3(256), 0, s, a, workspace, nparts);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int contrad_gaussian_blur_masked(const float* x, float* tmp, float* y, const float* params,
+                                            const float* kernel1d, int B, int H, int W, int radius,
+                                            contrad_stream_t stream) {
+  CONTRAD_ARG(x && tmp && y && params && kernel1d && B > 0 && H > 0 && W > 0);
+  CONTRAD_ARG(radius >= 0 && 2 * radius + 1 <= BLUR_MAXK && radius < H && radius < W);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t smem_h = (size_t)(W + 2 * radius) * sizeof(float);
+  hipLaunchKernelGGL(blur_h_kernel, dim3(H, B * 3), dim3(256), smem_h, s, x, tmp, params, H, W, radius, kernel1d);
+  CONTRAD_CHECK_LAUNCH();
+  const size_t smem_v = (size_t)(BLUR_TH + 2 * radius) * 64 * sizeof(float);
+  hipLaunchKernelGGL(blur_v_kernel, dim3(cdiv(W, 64), cdiv(H, BLUR_TH), B * 3), dim3(256), smem_v, s, tmp, x, y,
+                     params, H, W, radius, kernel1d);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}

@@ -20,6 +20,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+__device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 static inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }
 
 // MI355X: 256 CUs in 8 XCDs; the dispatcher is observed to place block b on XCD b % 8.  Remap the

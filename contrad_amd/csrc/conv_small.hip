@@ -1,0 +1,322 @@
+// Direct (VALU) convolutions for the RGB ends of the networks, where one GEMM dimension is 3 and the
+// layer is HBM-bound, not MFMA-bound (first conv / FromRGB AI 1.4-13 FLOP/B):
+//
+//   rgb_conv_fwd   : image NCHW (N,Cin<=4,H,W) -> NHWC (N,H,W,K); k x k, stride 1, "same" padding; fuses the
+//                    discriminators' input rescale x*2-1 (sndcgan.py:123, stylegan2/discriminator.py:226),
+//                    bias, leaky-relu and gain.  One read of the image, one write of the activation.
+//   rgb_conv_wgrad : its weight + bias gradient (packed layout), two-stage deterministic reduction.
+//   rgb_conv_dgrad : data gradient / transposed conv onto <=4 channels, NHWC (N,H,W,K) -> NCHW (N,C,H,W) with an
+//                    optional bias + tanh + affine epilogue: the generator's last ConvTranspose2d + Tanh +
+//                    0.5x+0.5 (sndcgan.py:37-38,47) and d(loss)/d(image) of the first D layer (G-step, R1).
+//
+// Thread mapping (fwd / wgrad): a pixel's K output channels are spread over K/4 lanes (float4 per lane, so a
+// pixel's channels are written as one contiguous 4*K-byte run); a 256-thread block therefore works on
+// 1024/K pixels at a time and walks a tile of TH rows x W columns whose input halo sits in LDS.
+#include "common.h"
+#include "../../include/contrad_hip.h"
+
+namespace {
+
+constexpr int MAX_TAPS = 9;  // k <= 3
+constexpr int MAX_CIN = 4;
+
+struct RgbArgs {
+  const float* img;  // NCHW
+  const float* wp;   // packed [(tap*Cin + ci)][ldw]
+  const float* bias;
+  float* y;          // NHWC, ld = ldy
+  int N, Cin, H, W, K, ldy, ldw, k, pad, TH;
+  float in_scale, in_shift, slope, gain;
+};
+
+// stage rows [h0-pad, h0+TH+pad) x cols [-pad, W+pad) of image n, all Cin channels, transformed, zero outside
+__device__ __forceinline__ void stage_halo(float* lds, const RgbArgs& a, int n, int h0) {
+  const int HW = a.W + 2 * a.pad, HH = a.TH + 2 * a.pad;
+  for (int e = threadIdx.x; e < a.Cin * HH * HW; e += blockDim.x) {
+    const int ci = e / (HH * HW), r = (e / HW) % HH, c = e % HW;
+    const int h = h0 - a.pad + r, w = c - a.pad;
+    float v = 0.f;
+    if ((unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
+      v = a.img[((size_t)(n * a.Cin + ci) * a.H + h) * a.W + w] * a.in_scale + a.in_shift;
+    lds[e] = v;
+  }
+}
+
+template <int KSZ, int CIN>
+__global__ __launch_bounds__(256) void rgb_conv_fwd_kernel(RgbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int TAPS = KSZ * KSZ;
+  const int tpp = a.K >> 2;              // lanes per pixel
+  const int slots = blockDim.x / tpp;    // pixels in flight
+  const int cg = threadIdx.x % tpp, slot = threadIdx.x / tpp;
+  const int tiles_h = cdiv_dev(a.H, a.TH);
+  const int HW = a.W + 2 * a.pad, HH = a.TH + 2 * a.pad;
+
+  float4 w[TAPS * CIN];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+      w[t * CIN + ci] = *reinterpret_cast<const float4*>(a.wp + (size_t)(t * CIN + ci) * a.ldw + cg * 4);
+  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + cg * 4);
+
+  for (int tile = blockIdx.x; tile < a.N * tiles_h; tile += gridDim.x) {
+    const int n = tile / tiles_h, h0 = (tile % tiles_h) * a.TH;
+    __syncthreads();
+    stage_halo(lds, a, n, h0);
+    __syncthreads();
+    const int rows = min(a.TH, a.H - h0);
+    for (int pix = slot; pix < rows * a.W; pix += slots) {
+      const int r = pix / a.W, c = pix - r * a.W;
+      float4 acc = b4;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const int kh = t / KSZ, kw = t % KSZ;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+          const float xv = lds[(ci * HH + r + kh) * HW + c + kw];
+          const float4 ww = w[t * CIN + ci];
+          acc.x = fmaf(xv, ww.x, acc.x); acc.y = fmaf(xv, ww.y, acc.y);
+          acc.z = fmaf(xv, ww.z, acc.z); acc.w = fmaf(xv, ww.w, acc.w);
+        }
+      }
+      acc.x = (acc.x > 0.f ? acc.x : acc.x * a.slope) * a.gain;
+      acc.y = (acc.y > 0.f ? acc.y : acc.y * a.slope) * a.gain;
+      acc.z = (acc.z > 0.f ? acc.z : acc.z * a.slope) * a.gain;
+      acc.w = (acc.w > 0.f ? acc.w : acc.w * a.slope) * a.gain;
+      *reinterpret_cast<float4*>(a.y + ((size_t)(n * a.H + h0 + r) * a.W + c) * a.ldy + cg * 4) = acc;
+    }
+  }
+}
+
+struct RgbWgradArgs {
+  const float* img;
+  const float* gy;   // NHWC gradient wrt the PRE-activation output, ld = ldy
+  float* partial;    // [gridDim.x][(TAPS*Cin + 1) * K]   (last K entries: bias gradient)
+  int N, Cin, H, W, K, ldy, k, pad, TH;
+  float in_scale, in_shift;
+};
+
+template <int KSZ, int CIN>
+__global__ __launch_bounds__(256) void rgb_conv_wgrad_kernel(RgbWgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int TAPS = KSZ * KSZ;
+  const int tpp = a.K >> 2;
+  const int slots = blockDim.x / tpp;
+  const int cg = threadIdx.x % tpp, slot = threadIdx.x / tpp;
+  const int tiles_h = cdiv_dev(a.H, a.TH);
+  const int HW = a.W + 2 * a.pad, HH = a.TH + 2 * a.pad;
+  RgbArgs h{};  // reuse the halo stager
+  h.img = a.img; h.Cin = a.Cin; h.H = a.H; h.W = a.W; h.pad = a.pad; h.TH = a.TH;
+  h.in_scale = a.in_scale; h.in_shift = a.in_shift;
+
+  float4 acc[TAPS * CIN];
+#pragma unroll
+  for (int i = 0; i < TAPS * CIN; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 accb = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (int tile = blockIdx.x; tile < a.N * tiles_h; tile += gridDim.x) {
+    const int n = tile / tiles_h, h0 = (tile % tiles_h) * a.TH;
+    __syncthreads();
+    stage_halo(lds, h, n, h0);
+    __syncthreads();
+    const int rows = min(a.TH, a.H - h0);
+    for (int pix = slot; pix < rows * a.W; pix += slots) {
+      const int r = pix / a.W, c = pix - r * a.W;
+      const float4 g = *reinterpret_cast<const float4*>(a.gy + ((size_t)(n * a.H + h0 + r) * a.W + c) * a.ldy + cg * 4);
+      accb.x += g.x; accb.y += g.y; accb.z += g.z; accb.w += g.w;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const int kh = t / KSZ, kw = t % KSZ;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+          const float xv = lds[(ci * HH + r + kh) * HW + c + kw];
+          float4& q = acc[t * CIN + ci];
+          q.x = fmaf(xv, g.x, q.x); q.y = fmaf(xv, g.y, q.y);
+          q.z = fmaf(xv, g.z, q.z); q.w = fmaf(xv, g.w, q.w);
+        }
+      }
+    }
+  }
+  // reduce over the pixel slots of the block through LDS (fixed order), then one partial per block
+  __syncthreads();
+  float* out = a.partial + (size_t)blockIdx.x * (TAPS * a.Cin + 1) * a.K;
+  float4* red = reinterpret_cast<float4*>(lds);  // [slots][tpp]
+#pragma unroll
+  for (int q = 0; q <= TAPS * CIN; ++q) {   // fully unrolled: acc[] stays in registers
+    const bool is_bias = (q == TAPS * CIN);
+    const float4 v = is_bias ? accb : acc[q < TAPS * CIN ? q : 0];
+    red[slot * tpp + cg] = v;
+    __syncthreads();
+    if (slot == 0) {
+      float4 s = red[cg];
+      for (int sl = 1; sl < slots; ++sl) {
+        const float4 o = red[sl * tpp + cg];
+        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+      }
+      *reinterpret_cast<float4*>(out + (size_t)q * a.K + cg * 4) = s;
+    }
+    __syncthreads();
+  }
+}
+
+// dwp[row][k] (row < TAPS*Cin, leading dim ldw) and db[k] from the per-block partials, fixed order
+__global__ void rgb_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks, int rows, int K,
+                                        float* __restrict__ dwp, int ldw, float* __restrict__ db) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (rows + 1) * K) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * (rows + 1) * K + e];
+  const int row = e / K, k = e - row * K;
+  if (row < rows) dwp[(size_t)row * ldw + k] = s;
+  else if (db) db[k] = s;
+}
+
+struct RgbDgradArgs {
+  const float* gy;   // NHWC (N,H,W,K), ld = ldy
+  const float* wp;   // packed [(tap*C + c)][ldw]
+  const float* bias; // [C] or NULL
+  float* out;        // NCHW (N,C,H,W)
+  int N, C, H, W, K, ldy, ldw, k, pad;
+  int act;           // 0: none, 1: tanh
+  float out_scale, out_shift;  // out = f(acc + bias) * out_scale + out_shift
+};
+
+// stride-1 transposed conv onto C <= 4 channels: out[n,c,h,w] = sum_{kh,kw,k} gy[n,h+p-kh,w+p-kw,k] wp[(kh,kw,c),k]
+// One thread per output pixel; weights (taps*C*K floats) broadcast from LDS.
+__global__ __launch_bounds__(256) void rgb_conv_dgrad_kernel(RgbDgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [taps][C][K]
+  const int taps = a.k * a.k;
+  for (int e = threadIdx.x; e < taps * a.C * a.K; e += blockDim.x) {
+    const int t = e / (a.C * a.K), c = (e / a.K) % a.C, k = e % a.K;
+    lds[e] = a.wp[(size_t)(t * a.C + c) * a.ldw + k];
+  }
+  __syncthreads();
+  const long long total = (long long)a.N * a.H * a.W;
+  for (long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix < total;
+       pix += (long long)gridDim.x * blockDim.x) {
+    const int w = (int)(pix % a.W);
+    const int h = (int)((pix / a.W) % a.H);
+    const int n = (int)(pix / ((long long)a.W * a.H));
+    float acc[MAX_CIN] = {0.f, 0.f, 0.f, 0.f};
+    for (int kh = 0; kh < a.k; ++kh) {
+      const int ho = h + a.pad - kh;
+      if ((unsigned)ho >= (unsigned)a.H) continue;
+      for (int kw = 0; kw < a.k; ++kw) {
+        const int wo = w + a.pad - kw;
+        if ((unsigned)wo >= (unsigned)a.W) continue;
+        const float* g = a.gy + ((size_t)(n * a.H + ho) * a.W + wo) * a.ldy;
+        const float* wt = lds + (size_t)(kh * a.k + kw) * a.C * a.K;
+        for (int k = 0; k < a.K; k += 4) {
+          const float4 gv = *reinterpret_cast<const float4*>(g + k);
+#pragma unroll
+          for (int c = 0; c < MAX_CIN; ++c) {
+            if (c < a.C) {
+              const float4 wv = *reinterpret_cast<const float4*>(wt + c * a.K + k);
+              acc[c] = fmaf(gv.x, wv.x, acc[c]); acc[c] = fmaf(gv.y, wv.y, acc[c]);
+              acc[c] = fmaf(gv.z, wv.z, acc[c]); acc[c] = fmaf(gv.w, wv.w, acc[c]);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < MAX_CIN; ++c) {
+      if (c < a.C) {
+        float v = acc[c] + (a.bias ? a.bias[c] : 0.f);
+        if (a.act == 1) v = tanhf(v);
+        a.out[((size_t)(n * a.C + c) * a.H + h) * a.W + w] = v * a.out_scale + a.out_shift;
+      }
+    }
+  }
+}
+
+int rgb_common_check(int N, int Cin, int H, int W, int K, int k, int ldy, int ldw) {
+  CONTRAD_ARG(N > 0 && H > 0 && W > 0 && Cin == 3);  /* RGB images (nc = 3 everywhere in the reference) */
+  CONTRAD_ARG(k == 1 || k == 3);
+  CONTRAD_ARG(K >= 4 && (K & 3) == 0 && K <= 1024 && (1024 % K) == 0);
+  CONTRAD_ARG(ldy >= K && (ldy & 3) == 0 && (ldw & 3) == 0 && ldw >= K);
+  return 0;
+}
+
+int pick_th(int W) { int th = 256 / W; return th < 1 ? 1 : (th > 8 ? 8 : th); }
+
+}  // namespace
+
+extern "C" int contrad_rgb_conv_fwd(const float* img, const float* wp, const float* bias, float* y, int N,
+                                    int Cin, int H, int W, int K, int k, int ldy, int ldw, float in_scale,
+                                    float in_shift, float slope, float gain, contrad_stream_t stream) {
+  int rc = rgb_common_check(N, Cin, H, W, K, k, ldy, ldw);
+  if (rc) return rc;
+  CONTRAD_ARG(img && wp && y);
+  RgbArgs a{};
+  a.img = img; a.wp = wp; a.bias = bias; a.y = y;
+  a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.K = K; a.ldy = ldy; a.ldw = ldw; a.k = k; a.pad = k / 2;
+  a.TH = pick_th(W);
+  a.in_scale = in_scale; a.in_shift = in_shift; a.slope = slope; a.gain = gain;
+  const int tiles = N * cdiv(H, a.TH);
+  const int grid = tiles < 4096 ? tiles : 4096;
+  const size_t smem = (size_t)Cin * (a.TH + 2 * a.pad) * (W + 2 * a.pad) * sizeof(float);
+  CONTRAD_ARG(smem <= 64 * 1024);
+  if (k == 3) hipLaunchKernelGGL((rgb_conv_fwd_kernel<3, 3>), dim3(grid), dim3(256), smem, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((rgb_conv_fwd_kernel<1, 3>), dim3(grid), dim3(256), smem, (hipStream_t)stream, a);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+static int rgb_wgrad_grid(int N, int H, int W) {
+  const int tiles = N * cdiv(H, pick_th(W));
+  return tiles < 1024 ? tiles : 1024;
+}
+
+extern "C" long long contrad_rgb_conv_wgrad_workspace_bytes(int N, int Cin, int H, int W, int K, int k) {
+  return (long long)rgb_wgrad_grid(N, H, W) * (k * k * Cin + 1) * K * (long long)sizeof(float);
+}
+
+extern "C" int contrad_rgb_conv_wgrad(const float* img, const float* gy, float* dwp, float* dbias, int N,
+                                      int Cin, int H, int W, int K, int k, int ldy, int ldw, float in_scale,
+                                      float in_shift, float* workspace, long long workspace_bytes,
+                                      contrad_stream_t stream) {
+  int rc = rgb_common_check(N, Cin, H, W, K, k, ldy, ldw);
+  if (rc) return rc;
+  CONTRAD_ARG(img && gy && dwp && workspace);
+  CONTRAD_ARG(workspace_bytes >= contrad_rgb_conv_wgrad_workspace_bytes(N, Cin, H, W, K, k));
+  RgbWgradArgs a{};
+  a.img = img; a.gy = gy; a.partial = workspace;
+  a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.K = K; a.ldy = ldy; a.k = k; a.pad = k / 2; a.TH = pick_th(W);
+  a.in_scale = in_scale; a.in_shift = in_shift;
+  const int grid = rgb_wgrad_grid(N, H, W);
+  size_t smem = (size_t)Cin * (a.TH + 2 * a.pad) * (W + 2 * a.pad) * sizeof(float);
+  const size_t red = 256 * sizeof(float4);
+  if (smem < red) smem = red;
+  CONTRAD_ARG(smem <= 64 * 1024);
+  if (k == 3) hipLaunchKernelGGL((rgb_conv_wgrad_kernel<3, 3>), dim3(grid), dim3(256), smem, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((rgb_conv_wgrad_kernel<1, 3>), dim3(grid), dim3(256), smem, (hipStream_t)stream, a);
+  CONTRAD_CHECK_LAUNCH();
+  const int rows = k * k * Cin;
+  hipLaunchKernelGGL(rgb_wgrad_reduce_kernel, dim3(cdiv((rows + 1) * K, 256)), dim3(256), 0,
+                     (hipStream_t)stream, workspace, grid, rows, K, dwp, ldw, dbias);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int contrad_rgb_conv_dgrad(const float* gy, const float* wp, const float* bias, float* out, int N,
+                                      int C, int H, int W, int K, int k, int ldy, int ldw, int act,
+                                      float out_scale, float out_shift, contrad_stream_t stream) {
+  CONTRAD_ARG(gy && wp && out && N > 0 && H > 0 && W > 0 && C >= 1 && C <= MAX_CIN);
+  CONTRAD_ARG((k == 1 || k == 3) && K >= 4 && (K & 3) == 0 && ldy >= K && (ldy & 3) == 0 && ldw >= K);
+  CONTRAD_ARG(act == 0 || act == 1);
+  RgbDgradArgs a{};
+  a.gy = gy; a.wp = wp; a.bias = bias; a.out = out;
+  a.N = N; a.C = C; a.H = H; a.W = W; a.K = K; a.ldy = ldy; a.ldw = ldw; a.k = k; a.pad = k / 2;
+  a.act = act; a.out_scale = out_scale; a.out_shift = out_shift;
+  const size_t smem = (size_t)k * k * C * K * sizeof(float);
+  CONTRAD_ARG(smem <= 64 * 1024);
+  const long long total = (long long)N * H * W;
+  long long grid = (total + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(rgb_conv_dgrad_kernel, dim3((int)grid), dim3(256), smem, (hipStream_t)stream, a);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}

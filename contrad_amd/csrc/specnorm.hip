@@ -1,0 +1,311 @@
+// Weight preparation for the conv engine, batched over all layers of a network in a handful of launches:
+//
+//   forward : spectral normalisation exactly as torch.nn.utils.spectral_norm's pre-forward hook (applied to
+//             every Conv2d/Linear of D at models/gan/sndcgan.py:111-118): ONE power iteration per call in
+//             training mode      v <- normalize(W^T u),  u <- normalize(W v),  sigma = u^T W v,
+//             u/v updated in place, and the effective weight W/sigma written directly in the packed GEMM
+//             layout Wp[(tap*C + c)][k] the implicit-GEMM kernels consume (OIHW -> "HWIO" transpose through
+//             LDS).  Layers with fixed_scale > 0 skip the iteration and use W * fixed_scale instead
+//             (StyleGAN2's EqualConv2d / EqualLinear runtime scale, stylegan2/layers.py:104,117,141).
+//   backward: given G = dL/dWp (packed), dL/dW_orig = (G - <G, Wp> u v^T) / sigma   (u, v constants in the
+//             graph, as in torch), transposed back to OIHW.
+//
+// Everything is deterministic: cross-block reductions go through per-block partial slots summed in a fixed
+// order by the consumer.  W is [K][IN] row-major with IN = C*T, column index i = c*T + tap.
+#include "common.h"
+#include "../../include/contrad_hip.h"
+
+namespace {
+
+constexpr int SN_THREADS = 256;
+constexpr int MAXP = CONTRAD_SN_MAX_PARTIALS;  // partial slots per layer per reduction
+
+struct BlockMap {
+  int start[CONTRAD_SN_MAX_LAYERS + 1];
+};
+
+__device__ __forceinline__ int find_layer(const BlockMap& m, int n, int b) {
+  int l = 0;
+  while (l + 1 < n && b >= m.start[l + 1]) ++l;
+  return l;
+}
+
+// scratch layout (floats) per layer l at base l*SCR_STRIDE:
+//   [0, MAXP)        partial sums of |W^T u|^2        (phase 1)
+//   [MAXP, 2 MAXP)   partial sums of |W v|^2          (phase 2)
+//   [2 MAXP, 3 MAXP) partial sums of <G, Wp>          (backward)
+//   [3 MAXP, +IN)    vt = W^T u (unnormalised)
+//   then             t  = W v   (K floats)
+__device__ __forceinline__ size_t scr_base(const contrad_sn_batch& b, int l) { return (size_t)b.scratch_off[l]; }
+
+// ---- phase 1: vt[i] = sum_k W[k][i] u[k]; partial |vt|^2 per block ----
+__global__ void sn_phase1_kernel(contrad_sn_batch b, BlockMap map, float* __restrict__ scratch) {
+  __shared__ float red[16];
+  const int l = find_layer(map, b.n, blockIdx.x);
+  const contrad_sn_layer& L = b.layers[l];
+  const int chunk = blockIdx.x - map.start[l];
+  const int IN = L.C * L.T;
+  float* scr = scratch + scr_base(b, l);
+  const int i = chunk * SN_THREADS + threadIdx.x;
+  float acc = 0.f;
+  if (i < IN) {
+    const float* w = L.w + i;
+    for (int k = 0; k < L.K; ++k) acc += w[(size_t)k * IN] * L.u[k];
+    scr[3 * MAXP + i] = acc;
+  }
+  const float ss = block_sum(acc * acc, red);
+  if (threadIdx.x == 0) scr[chunk] = ss;
+}
+
+__device__ __forceinline__ float sum_partials(const float* p, int n) {
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) s += p[i];
+  return s;
+}
+
+// ---- phase 2: t[k] = sum_i W[k][i] vhat[i]; one wave per row; partial |t|^2 per block ----
+__global__ void sn_phase2_kernel(contrad_sn_batch b, BlockMap map, int training, float eps,
+                                 float* __restrict__ scratch) {
+  __shared__ float red[16];
+  const int l = find_layer(map, b.n, blockIdx.x);
+  const contrad_sn_layer& L = b.layers[l];
+  const int chunk = blockIdx.x - map.start[l];
+  const int IN = L.C * L.T;
+  float* scr = scratch + scr_base(b, l);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = chunk * 4 + wave;
+  float inv = 1.f;
+  const float* vsrc;
+  if (training) {
+    const int np1 = cdiv_dev(IN, SN_THREADS);
+    inv = 1.f / fmaxf(sqrtf(sum_partials(scr, np1)), eps);
+    vsrc = scr + 3 * MAXP;
+  } else {
+    vsrc = L.v;
+  }
+  float acc = 0.f;
+  if (k < L.K) {
+    const float* w = L.w + (size_t)k * IN;
+    for (int i = lane; i < IN; i += 64) acc += w[i] * vsrc[i];
+    acc = wave_sum(acc) * inv;
+    if (lane == 0) scr[3 * MAXP + IN + k] = acc;
+  }
+  const float mine = (lane == 0 && k < L.K) ? acc * acc : 0.f;
+  const float ss = block_sum(mine, red);
+  if (threadIdx.x == 0) scr[MAXP + chunk] = ss;
+}
+
+// ---- phase 3: finalise u, v, sigma; write Wp = W / sigma in packed layout (LDS transpose) ----
+// block tile: 32 rows (k) x CB channels (all T taps)
+__global__ void sn_phase3_kernel(contrad_sn_batch b, BlockMap map, int training, float eps,
+                                 float* __restrict__ scratch, float* __restrict__ sigma_out) {
+  __shared__ float tile[32][257];
+  const int l = find_layer(map, b.n, blockIdx.x);
+  const contrad_sn_layer& L = b.layers[l];
+  const int chunk = blockIdx.x - map.start[l];
+  const int IN = L.C * L.T;
+  float* scr = scratch + scr_base(b, l);
+  const int CB = max(1, 256 / L.T);
+  const int cchunks = cdiv_dev(L.C, CB);
+  const int kt = chunk / cchunks, cc = chunk % cchunks;
+  const int k0 = kt * 32, c0 = cc * CB;
+  const int cn = min(CB, L.C - c0);
+  const int width = cn * L.T;  // contiguous floats per row in this tile
+
+  float inv_sigma;
+  if (L.fixed_scale > 0.f) {
+    inv_sigma = L.fixed_scale;
+    if (chunk == 0 && threadIdx.x == 0) sigma_out[l] = 1.f / L.fixed_scale;
+  } else {
+    const float* t = scr + 3 * MAXP + IN;
+    float sigma;
+    if (training) {
+      const int np2 = cdiv_dev(L.K, 4);
+      const float nt2 = sum_partials(scr + MAXP, np2);
+      const float inv_t = 1.f / fmaxf(sqrtf(nt2), eps);
+      sigma = nt2 * inv_t;
+      if (chunk == 0) {
+        const int np1 = cdiv_dev(IN, SN_THREADS);
+        const float inv_v = 1.f / fmaxf(sqrtf(sum_partials(scr, np1)), eps);
+        for (int k = threadIdx.x; k < L.K; k += blockDim.x) {
+          const float uk = t[k] * inv_t;
+          L.u[k] = uk;
+          if (L.u_snap) L.u_snap[k] = uk;
+        }
+        for (int i = threadIdx.x; i < IN; i += blockDim.x) {
+          const float vi = scr[3 * MAXP + i] * inv_v;
+          L.v[i] = vi;
+          if (L.v_snap) L.v_snap[i] = vi;
+        }
+      }
+    } else {
+      // sigma = u . (W v): fixed-order dot by every block (K <= a few thousand)
+      sigma = 0.f;
+      for (int k = 0; k < L.K; ++k) sigma += L.u[k] * t[k];
+      if (chunk == 0) {
+        if (L.u_snap) for (int k = threadIdx.x; k < L.K; k += blockDim.x) L.u_snap[k] = L.u[k];
+        if (L.v_snap) for (int i = threadIdx.x; i < IN; i += blockDim.x) L.v_snap[i] = L.v[i];
+      }
+    }
+    inv_sigma = 1.f / sigma;
+    if (chunk == 0 && threadIdx.x == 0) sigma_out[l] = sigma;
+  }
+
+  // load 32 x width (coalesced along the row), scaled
+  for (int e = threadIdx.x; e < 32 * width; e += blockDim.x) {
+    const int r = e / width, j = e - r * width;
+    const int k = k0 + r;
+    tile[r][j] = (k < L.K) ? L.w[(size_t)k * IN + (size_t)c0 * L.T + j] * inv_sigma : 0.f;
+  }
+  __syncthreads();
+  // store: packed row (tap*C + c), 32 consecutive k
+  const int kk = threadIdx.x & 31;
+  for (int rr = threadIdx.x >> 5; rr < width; rr += (blockDim.x >> 5)) {
+    const int tap = rr / cn, c = rr - tap * cn;  // iterate tap-major so consecutive rr are consecutive rows
+    if (k0 + kk < L.K)
+      L.wp[((size_t)tap * L.C + c0 + c) * L.ldw + k0 + kk] = tile[kk][c * L.T + tap];
+  }
+}
+
+// ---- backward 1: partial <G, Wp> per block (grid-stride over packed rows) ----
+__global__ void sn_bwd_dot_kernel(contrad_sn_batch b, BlockMap map, float* __restrict__ scratch) {
+  __shared__ float red[16];
+  const int l = find_layer(map, b.n, blockIdx.x);
+  const contrad_sn_layer& L = b.layers[l];
+  const int chunk = blockIdx.x - map.start[l];
+  const int nchunks = map.start[l + 1] - map.start[l];
+  float* scr = scratch + scr_base(b, l);
+  float acc = 0.f;
+  if (L.fixed_scale <= 0.f) {
+    const long long total = (long long)L.C * L.T * L.K;
+    for (long long e = (long long)chunk * blockDim.x + threadIdx.x; e < total;
+         e += (long long)nchunks * blockDim.x) {
+      const long long r = e / L.K;
+      const int k = (int)(e - r * L.K);
+      acc += L.gwp[r * L.ldw + k] * L.wp[r * L.ldw + k];
+    }
+  }
+  const float s = block_sum(acc, red);
+  if (threadIdx.x == 0) scr[2 * MAXP + chunk] = s;
+}
+
+// ---- backward 2: gw[k][c*T+tap] = (G[(tap*C+c)][k] - dot * u[k] v[c*T+tap]) / sigma ----
+__global__ void sn_bwd_write_kernel(contrad_sn_batch b, BlockMap map, BlockMap dotmap,
+                                    const float* __restrict__ scratch, const float* __restrict__ sigma) {
+  __shared__ float tile[32][257];
+  const int l = find_layer(map, b.n, blockIdx.x);
+  const contrad_sn_layer& L = b.layers[l];
+  const int chunk = blockIdx.x - map.start[l];
+  const int IN = L.C * L.T;
+  const float* scr = scratch + scr_base(b, l);
+  const int CB = max(1, 256 / L.T);
+  const int cchunks = cdiv_dev(L.C, CB);
+  const int kt = chunk / cchunks, cc = chunk % cchunks;
+  const int k0 = kt * 32, c0 = cc * CB;
+  const int cn = min(CB, L.C - c0);
+  const int width = cn * L.T;
+  float dot = 0.f, inv_sigma;
+  if (L.fixed_scale > 0.f) {
+    inv_sigma = L.fixed_scale;
+  } else {
+    dot = sum_partials(scr + 2 * MAXP, dotmap.start[l + 1] - dotmap.start[l]);
+    inv_sigma = 1.f / sigma[l];
+  }
+  const int kk = threadIdx.x & 31;
+  for (int rr = threadIdx.x >> 5; rr < width; rr += (blockDim.x >> 5)) {
+    const int tap = rr / cn, c = rr - tap * cn;
+    tile[kk][c * L.T + tap] =
+        (k0 + kk < L.K) ? L.gwp[((size_t)tap * L.C + c0 + c) * L.ldw + k0 + kk] : 0.f;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 32 * width; e += blockDim.x) {
+    const int r = e / width, j = e - r * width;
+    const int k = k0 + r;
+    if (k < L.K) {
+      const size_t i = (size_t)c0 * L.T + j;
+      float g = tile[r][j];
+      if (L.fixed_scale <= 0.f) g -= dot * (L.u_snap ? L.u_snap[k] : L.u[k]) * (L.v_snap ? L.v_snap[i] : L.v[i]);
+      L.gw[(size_t)k * IN + i] = g * inv_sigma;
+    }
+  }
+}
+
+int check_batch(const contrad_sn_batch* b) {
+  CONTRAD_ARG(b && b->n > 0 && b->n <= CONTRAD_SN_MAX_LAYERS);
+  for (int l = 0; l < b->n; ++l) {
+    const contrad_sn_layer& L = b->layers[l];
+    CONTRAD_ARG(L.w && L.wp && L.K > 0 && L.C > 0 && L.T > 0 && L.T <= 256 && L.ldw >= L.K);
+    if (L.fixed_scale <= 0.f) {
+      CONTRAD_ARG(L.u && L.v);
+      CONTRAD_ARG(cdiv(L.C * L.T, SN_THREADS) <= MAXP && cdiv(L.K, 4) <= MAXP);
+    }
+  }
+  return 0;
+}
+
+int tiles_of(const contrad_sn_layer& L) {
+  const int CB = (256 / L.T) > 1 ? (256 / L.T) : 1;
+  return cdiv(L.K, 32) * cdiv(L.C, CB);
+}
+
+}  // namespace
+
+extern "C" long long contrad_sn_scratch_floats(int K, int C, int T) {
+  return 3ll * MAXP + (long long)C * T + K + 16;
+}
+
+extern "C" int contrad_sn_weight_prep(const contrad_sn_batch* b, int training, float eps, float* scratch,
+                                      float* sigma_out, contrad_stream_t stream) {
+  int rc = check_batch(b);
+  if (rc) return rc;
+  CONTRAD_ARG(scratch && sigma_out);
+  hipStream_t s = (hipStream_t)stream;
+  BlockMap m1{}, m2{}, m3{};
+  bool any_sn = false;
+  for (int l = 0; l < b->n; ++l) {
+    const contrad_sn_layer& L = b->layers[l];
+    const bool sn = L.fixed_scale <= 0.f;
+    any_sn |= sn;
+    m1.start[l + 1] = m1.start[l] + ((sn && training) ? cdiv(L.C * L.T, SN_THREADS) : 0);
+    m2.start[l + 1] = m2.start[l] + (sn ? cdiv(L.K, 4) : 0);
+    m3.start[l + 1] = m3.start[l] + tiles_of(L);
+  }
+  if (any_sn) {
+    if (training && m1.start[b->n] > 0) {
+      hipLaunchKernelGGL(sn_phase1_kernel, dim3(m1.start[b->n]), dim3(SN_THREADS), 0, s, *b, m1, scratch);
+      CONTRAD_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(sn_phase2_kernel, dim3(m2.start[b->n]), dim3(256), 0, s, *b, m2, training, eps, scratch);
+    CONTRAD_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(sn_phase3_kernel, dim3(m3.start[b->n]), dim3(256), 0, s, *b, m3, training, eps, scratch,
+                     sigma_out);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int contrad_sn_weight_grad(const contrad_sn_batch* b, float* scratch, const float* sigma,
+                                      contrad_stream_t stream) {
+  int rc = check_batch(b);
+  if (rc) return rc;
+  CONTRAD_ARG(scratch && sigma);
+  hipStream_t s = (hipStream_t)stream;
+  BlockMap md{}, mw{};
+  for (int l = 0; l < b->n; ++l) {
+    const contrad_sn_layer& L = b->layers[l];
+    CONTRAD_ARG(L.gwp && L.gw);
+    const long long total = (long long)L.C * L.T * L.K;
+    int nb = (int)((total + 256 * 16 - 1) / (256 * 16));
+    if (nb > MAXP) nb = MAXP;
+    if (nb < 1) nb = 1;
+    md.start[l + 1] = md.start[l] + (L.fixed_scale <= 0.f ? nb : 0);
+    mw.start[l + 1] = mw.start[l] + tiles_of(L);
+  }
+  if (md.start[b->n] > 0) {
+    hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(md.start[b->n]), dim3(256), 0, s, *b, md, scratch);
+    CONTRAD_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(sn_bwd_write_kernel, dim3(mw.start[b->n]), dim3(256), 0, s, *b, mw, md, scratch, sigma);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}

@@ -177,3 +177,219 @@ def contrast_bwd(z, lse, N, mode, temperature, grad_scale=None):
     lib().call('contrad_contrast_bwd', _p(z), _p(lse), R, D, N, mode, 1.0 / temperature, _p(grad_scale), _p(dz),
                _stream())
     return dz
+
+
+# --------------------------------------------------------------------------------------------------
+# weight preparation (spectral norm / fixed scale + packing), batched
+# --------------------------------------------------------------------------------------------------
+from ._lib import SnBatch, SnLayer, AdamBatch, SN_MAX_LAYERS, ADAM_MAX_TENSORS, AUG_NPARAM  # noqa: E402
+
+
+class SnSpec(object):
+    """Static description of one layer for the batched weight prep: weight (K, C, KH, KW) [or (K, C) for a
+    linear], optional spectral-norm buffers, destination view inside a packed buffer."""
+    __slots__ = ('w', 'u', 'v', 'K', 'C', 'T', 'fixed_scale')
+
+    def __init__(self, w, u=None, v=None, fixed_scale=0.0, view_kct=None):
+        self.w, self.u, self.v = w, u, v
+        if view_kct is not None:
+            self.K, self.C, self.T = view_kct
+        elif w.dim() == 4:
+            self.K, self.C, self.T = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+        else:
+            self.K, self.C, self.T = w.shape[0], w.shape[1], 1
+        assert self.K * self.C * self.T == w.numel()
+        self.fixed_scale = float(fixed_scale)
+
+
+def sn_scratch_floats(specs):
+    offs, tot = [], 0
+    for s in specs:
+        offs.append(tot)
+        tot += int(lib().raw('contrad_sn_scratch_floats')(s.K, s.C, s.T))
+        tot = round_up(tot, 4)
+    return offs, tot
+
+
+def _sn_batches(specs, wps, ldws, offs, u_snaps=None, v_snaps=None, gwps=None, gws=None):
+    """Yield (SnBatch, first_layer_index) chunks of at most SN_MAX_LAYERS layers."""
+    for start in range(0, len(specs), SN_MAX_LAYERS):
+        b = SnBatch()
+        chunk = specs[start:start + SN_MAX_LAYERS]
+        b.n = len(chunk)
+        for j, s in enumerate(chunk):
+            i = start + j
+            L = b.layers[j]
+            L.w = s.w.data_ptr()
+            L.u = s.u.data_ptr() if s.u is not None else None
+            L.v = s.v.data_ptr() if s.v is not None else None
+            L.u_snap = u_snaps[i].data_ptr() if (u_snaps is not None and u_snaps[i] is not None) else None
+            L.v_snap = v_snaps[i].data_ptr() if (v_snaps is not None and v_snaps[i] is not None) else None
+            L.wp = wps[i].data_ptr()
+            L.gwp = gwps[i].data_ptr() if gwps is not None else None
+            L.gw = gws[i].data_ptr() if gws is not None else None
+            L.K, L.C, L.T, L.ldw = s.K, s.C, s.T, ldws[i]
+            L.fixed_scale = s.fixed_scale
+            b.scratch_off[j] = offs[i]
+        yield b, start
+
+
+def sn_weight_prep(specs, wps, ldws, training, scratch, offs, sigma, u_snaps=None, v_snaps=None, eps=1e-12):
+    for b, start in _sn_batches(specs, wps, ldws, offs, u_snaps, v_snaps):
+        lib().call('contrad_sn_weight_prep', ctypes.byref(b), int(bool(training)), float(eps), _p(scratch),
+                   ctypes.c_void_p(sigma.data_ptr() + 4 * start), _stream())
+
+
+def sn_weight_grad(specs, wps, ldws, gwps, gws, scratch, offs, sigma, u_snaps=None, v_snaps=None):
+    for b, start in _sn_batches(specs, wps, ldws, offs, u_snaps, v_snaps, gwps, gws):
+        lib().call('contrad_sn_weight_grad', ctypes.byref(b), _p(scratch),
+                   ctypes.c_void_p(sigma.data_ptr() + 4 * start), _stream())
+
+
+# --------------------------------------------------------------------------------------------------
+# RGB-end convolutions
+# --------------------------------------------------------------------------------------------------
+def rgb_conv_fwd(img, wp, bias, K, k, in_scale, in_shift, slope, gain, out=None):
+    """img NCHW (N,3,H,W) -> NHWC (N,H,W,K)."""
+    _chk(img, 'img'); _chk(wp, 'wp'); _chk(bias, 'bias')
+    if not img.is_contiguous():
+        raise RuntimeError('contrad_hip: image batch must be contiguous NCHW')
+    N, Cin, H, W = img.shape
+    if out is None:
+        out = torch.empty((N, H, W, K), device=img.device, dtype=torch.float32)
+    lib().call('contrad_rgb_conv_fwd', _p(img), _p(wp), _p(bias), _p(out), N, Cin, H, W, K, k, _ld(out),
+               wp.stride(0), float(in_scale), float(in_shift), float(slope), float(gain), _stream())
+    return out
+
+
+def rgb_conv_wgrad(img, gy, k, in_scale, in_shift, dwp, dbias=None):
+    _chk(img, 'img'); _chk(gy, 'gy'); _chk(dwp, 'dwp')
+    N, Cin, H, W = img.shape
+    K = gy.shape[3]
+    nbytes = lib().raw('contrad_rgb_conv_wgrad_workspace_bytes')(N, Cin, H, W, K, k)
+    ws = _workspace(nbytes, img.device)
+    lib().call('contrad_rgb_conv_wgrad', _p(img), _p(gy), _p(dwp), _p(dbias), N, Cin, H, W, K, k, _ld(gy),
+               dwp.stride(0), float(in_scale), float(in_shift), _p(ws), ctypes.c_longlong(ws.numel() * 4), _stream())
+    return dwp
+
+
+def rgb_conv_dgrad(gy, wp, bias, C, k, act=0, out_scale=1.0, out_shift=0.0, out=None):
+    """gy NHWC (N,H,W,K) -> NCHW (N,C,H,W), C <= 4."""
+    _chk(gy, 'gy'); _chk(wp, 'wp'); _chk(bias, 'bias')
+    N, H, W, K = gy.shape
+    if out is None:
+        out = torch.empty((N, C, H, W), device=gy.device, dtype=torch.float32)
+    lib().call('contrad_rgb_conv_dgrad', _p(gy), _p(wp), _p(bias), _p(out), N, C, H, W, K, k, _ld(gy),
+               wp.stride(0), int(act), float(out_scale), float(out_shift), _stream())
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# statistics / BatchNorm / losses / Adam
+# --------------------------------------------------------------------------------------------------
+def colstats(x2d, with_sq=False, out=None, accumulate=False):
+    """x2d: (M, K) row-major view (row stride = ld).  Returns (1 or 2, K)."""
+    _chk(x2d, 'x')
+    M, K = x2d.shape
+    ld = _ld(x2d)
+    if out is None:
+        out = torch.empty((2 if with_sq else 1, K), device=x2d.device, dtype=torch.float32)
+    nbytes = lib().raw('contrad_colstats_workspace_bytes')(ctypes.c_longlong(M), K, int(with_sq))
+    ws = _workspace(nbytes, x2d.device)
+    lib().call('contrad_colstats', _p(x2d), ctypes.c_longlong(M), K, ld, int(with_sq), _p(out), int(accumulate),
+               _p(ws), ctypes.c_longlong(ws.numel() * 4), _stream())
+    return out
+
+
+def as_rows(t):
+    """(N,H,W,C) NHWC dense tensor / view -> (N*H*W, C) strided matrix view (no copy)."""
+    N, H, W, C = t.shape
+    return t.as_strided((N * H * W, C), (_ld(t), 1), t.storage_offset())
+
+
+def bn_relu_apply(x2d, y2d, stats, count, gamma, beta, eps=1e-5, perm_hw=1):
+    M, K = x2d.shape
+    lib().call('contrad_bn_relu_apply', _p(x2d), _p(y2d), ctypes.c_longlong(M), K, _ld(x2d), _ld(y2d), _p(stats),
+               float(count), _p(gamma), _p(beta), float(eps), int(perm_hw), _stream())
+    return y2d
+
+
+def bn_running_update(stats, count, conv_bias, momentum, running_mean, running_var):
+    K = running_mean.numel()
+    lib().call('contrad_bn_running_update', _p(stats), float(count), K, _p(conv_bias), float(momentum),
+               _p(running_mean), _p(running_var), _stream())
+
+
+GAN_LOSS_KINDS = {'nonsat': 0, 'wgan': 1, 'hinge': 2, 'lsgan': 3}
+
+
+def gan_d_loss(logits, N, kind):
+    """logits (3N,1) -> (out3 = [loss, mean d_real, mean d_gen], grad (3N,1))."""
+    _chk(logits, 'logits')
+    out = torch.empty(3, device=logits.device, dtype=torch.float32)
+    grad = torch.empty((3 * N, 1), device=logits.device, dtype=torch.float32)
+    lib().call('contrad_gan_d_loss', _p(logits), logits.stride(0), N, GAN_LOSS_KINDS[kind], _p(out), _p(grad), _stream())
+    return out, grad
+
+
+def gan_g_loss(logits, kind):
+    _chk(logits, 'logits')
+    N = logits.shape[0]
+    out = torch.empty(1, device=logits.device, dtype=torch.float32)
+    grad = torch.empty((N, 1), device=logits.device, dtype=torch.float32)
+    lib().call('contrad_gan_g_loss', _p(logits), logits.stride(0), N, GAN_LOSS_KINDS.get(kind, 1), _p(out), _p(grad),
+               _stream())
+    return out, grad
+
+
+def adam_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, beta2, eps=1e-8, grad_scale=1.0):
+    n = len(params)
+    for start in range(0, n, ADAM_MAX_TENSORS):
+        b = AdamBatch()
+        m = min(ADAM_MAX_TENSORS, n - start)
+        b.n = m
+        for j in range(m):
+            p, g = params[start + j], grads[start + j]
+            if not (p.is_contiguous() and g.is_contiguous()):
+                raise RuntimeError('contrad_hip: Adam needs contiguous parameters and gradients')
+            t = b.t[j]
+            t.p, t.g = p.data_ptr(), g.data_ptr()
+            t.m, t.v = exp_avgs[start + j].data_ptr(), exp_avg_sqs[start + j].data_ptr()
+            t.numel = p.numel()
+        lib().call('contrad_adam_step', ctypes.byref(b), int(step), float(lr), float(beta1), float(beta2),
+                   float(eps), float(grad_scale), _stream())
+
+
+def axpby_(y, x, a, b):
+    lib().call('contrad_axpby', _p(y), _p(x), ctypes.c_longlong(y.numel()), float(a), float(b), _stream())
+    return y
+
+
+# --------------------------------------------------------------------------------------------------
+# augmentation
+# --------------------------------------------------------------------------------------------------
+def simclr_augment(x, params, contrast_first, has_contrast, out=None):
+    """x NCHW (B,3,H,W); params (B, AUG_NPARAM) on the same device."""
+    _chk(x, 'x'); _chk(params, 'params')
+    if not x.is_contiguous() or tuple(params.shape) != (x.shape[0], AUG_NPARAM) or not params.is_contiguous():
+        raise RuntimeError('contrad_hip: simclr_augment needs contiguous NCHW input and (B,%d) params' % AUG_NPARAM)
+    B, C, H, W = x.shape
+    if C != 3:
+        raise RuntimeError('contrad_hip: simclr_augment is defined for RGB images')
+    if out is None:
+        out = torch.empty_like(x)
+    nbytes = lib().raw('contrad_simclr_workspace_bytes')(B, H, W)
+    ws = _workspace(nbytes, x.device)
+    lib().call('contrad_simclr_augment', _p(x), _p(out), _p(params), B, H, W, int(contrast_first), int(has_contrast),
+               _p(ws), ctypes.c_longlong(ws.numel() * 4), _stream())
+    return out
+
+
+def gaussian_blur_masked(x, params, kernel1d, radius, out=None):
+    B, C, H, W = x.shape
+    tmp = torch.empty_like(x)
+    if out is None:
+        out = torch.empty_like(x)
+    lib().call('contrad_gaussian_blur_masked', _p(x), _p(tmp), _p(out), _p(params), _p(kernel1d), B, H, W,
+               int(radius), _stream())
+    return out

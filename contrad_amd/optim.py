@@ -1,0 +1,36 @@
+"""Fused multi-tensor Adam on the HIP kernel (one launch per 64 tensors), numerically torch.optim.Adam as the
+reference constructs it (train_gan.py:273-274: lr, betas, eps=1e-8, no weight decay / amsgrad).  The state layout
+(`step`, `exp_avg`, `exp_avg_sq`) matches torch's so ``optim.pt`` checkpoints interchange (train_gan.py:219-223)."""
+import torch
+
+from . import ops
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            beta1, beta2 = group['betas']
+            by_step = {}
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if len(st) == 0:
+                    st['step'] = 0
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st['step'] = int(st['step']) + 1
+                by_step.setdefault(st['step'], []).append(p)
+            for step, ps in by_step.items():
+                ops.adam_step([p.data for p in ps], [p.grad.data for p in ps],
+                              [self.state[p]['exp_avg'] for p in ps], [self.state[p]['exp_avg_sq'] for p in ps],
+                              step, group['lr'], beta1, beta2, group['eps'], grad_scale)
+        return loss

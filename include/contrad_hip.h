@@ -81,6 +81,128 @@ int contrad_l2norm_fwd(const float* u, int ldu, float* z, float* inv_norm, int R
 int contrad_l2norm_bwd(const float* dz, const float* z, const float* inv_norm, float* du, int ldu, int R,
                        int D, int accumulate, contrad_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Weight preparation, batched over the layers of a network: spectral normalisation (one power
+ * iteration per forward in training mode, u/v updated in place -- torch.nn.utils.spectral_norm as
+ * applied at models/gan/sndcgan.py:111-118) or a fixed runtime scale (EqualConv2d/EqualLinear,
+ * models/gan/stylegan2/layers.py:104,117,141), fused with the OIHW -> packed-GEMM-layout transpose.
+ * ---------------------------------------------------------------------------------------------- */
+#define CONTRAD_SN_MAX_LAYERS 24
+#define CONTRAD_SN_MAX_PARTIALS 256
+typedef struct {
+  const float* w;    /* [K][C*T] original weight (OIHW flattened; column = c*T + tap)            */
+  float* u;          /* [K]   left singular vector estimate (in/out)      (NULL if fixed_scale)  */
+  float* v;          /* [C*T] right singular vector estimate (in/out)     (NULL if fixed_scale)  */
+  float* u_snap;     /* [K]   copy of the u used by THIS call (fwd: written; bwd: read); may be NULL  */
+  float* v_snap;     /* [C*T] copy of the v used by THIS call (fwd: written; bwd: read); may be NULL  */
+  float* wp;         /* [T*C][ldw] packed effective weight (out fwd, in bwd)                      */
+  const float* gwp;  /* [T*C][ldw] gradient wrt wp            (backward only)                     */
+  float* gw;         /* [K][C*T]   gradient wrt w (out)       (backward only)                     */
+  int K, C, T, ldw;  /* T = KH*KW                                                                 */
+  float fixed_scale; /* > 0: wp = w * fixed_scale, no spectral norm                               */
+} contrad_sn_layer;
+typedef struct {
+  int n;
+  contrad_sn_layer layers[CONTRAD_SN_MAX_LAYERS];
+  long long scratch_off[CONTRAD_SN_MAX_LAYERS]; /* float offset of layer l's scratch, each at least
+                                                   contrad_sn_scratch_floats(K, C, T) long            */
+} contrad_sn_batch;
+
+long long contrad_sn_scratch_floats(int K, int C, int T);
+/* sigma_out[n]: per-layer sigma (1/fixed_scale for fixed layers), needed by the backward. */
+int contrad_sn_weight_prep(const contrad_sn_batch* b, int training, float eps, float* scratch,
+                           float* sigma_out, contrad_stream_t stream);
+/* gw = (gwp - <gwp, wp> u v^T) / sigma, with the sigma, wp and u/v (u_snap/v_snap when given, else u/v)
+ * of the matching forward. */
+int contrad_sn_weight_grad(const contrad_sn_batch* b, float* scratch, const float* sigma,
+                           contrad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * RGB ends of the networks (one GEMM dimension is 3 -> direct VALU kernels, HBM-bound).
+ * ---------------------------------------------------------------------------------------------- */
+/* First conv of D on the NCHW image with the x*2-1 input rescale fused (D_SNDCGAN.penultimate +
+ * main.0, models/gan/sndcgan.py:91,123; StyleGAN2 FromRGB, stylegan2/discriminator.py:17-19,226):
+ * y[n,h,w,:] = gain*lrelu_slope(conv_kxk(img*in_scale+in_shift) + bias), NHWC out; k in {1,3}, Cin = 3. */
+int contrad_rgb_conv_fwd(const float* img, const float* wp, const float* bias, float* y, int N, int Cin,
+                         int H, int W, int K, int k, int ldy, int ldw, float in_scale, float in_shift,
+                         float slope, float gain, contrad_stream_t stream);
+long long contrad_rgb_conv_wgrad_workspace_bytes(int N, int Cin, int H, int W, int K, int k);
+/* dwp[(tap*Cin+ci)][k] and dbias[k] (may be NULL) from gy = gradient wrt the pre-activation output. */
+int contrad_rgb_conv_wgrad(const float* img, const float* gy, float* dwp, float* dbias, int N, int Cin,
+                           int H, int W, int K, int k, int ldy, int ldw, float in_scale, float in_shift,
+                           float* workspace, long long workspace_bytes, contrad_stream_t stream);
+/* Stride-1 transposed conv onto C <= 4 channels, NHWC in -> NCHW out, out = f(acc+bias)*out_scale+out_shift,
+ * f = identity (act 0) or tanh (act 1): G_SNDCGAN's last ConvTranspose2d+Tanh+0.5x+0.5
+ * (models/gan/sndcgan.py:37-38,47) and d loss / d image of D's first conv. */
+int contrad_rgb_conv_dgrad(const float* gy, const float* wp, const float* bias, float* out, int N, int C,
+                           int H, int W, int K, int k, int ldy, int ldw, int act, float out_scale,
+                           float out_shift, contrad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * HBM-bound helpers: column statistics, BatchNorm (generator forward), GAN logit losses, Adam.
+ * ---------------------------------------------------------------------------------------------- */
+/* out[0][c] = sum_r x[r][c] (and out[1][c] = sum_r x[r][c]^2 if with_sq) over M rows; bias gradients
+ * (autograd of the "+ bias" in nn.Conv2d / nn.Linear) and BatchNorm batch statistics. */
+long long contrad_colstats_workspace_bytes(long long M, int K, int with_sq);
+int contrad_colstats(const float* x, long long M, int K, int ld, int with_sq, float* out, int accumulate,
+                     float* workspace, long long workspace_bytes, contrad_stream_t stream);
+/* nn.BatchNorm2d (train mode) + ReLU of G_SNDCGAN (models/gan/sndcgan.py:25-35,43): stats = {sum, sumsq}
+ * over `count` rows (all ranks for SyncBatchNorm); perm_hw > 1 additionally maps column c*perm_hw+hw to
+ * NHWC (hw, c) (the view(-1, 512, 4, 4) after norm_init, sndcgan.py:44). */
+int contrad_bn_relu_apply(const float* x, float* y, long long M, int K, int ldx, int ldy, const float* stats,
+                          float count, const float* gamma, const float* beta, float eps, int perm_hw,
+                          contrad_stream_t stream);
+int contrad_bn_running_update(const float* stats, float count, int K, const float* conv_bias, float momentum,
+                              float* running_mean, float* running_var, contrad_stream_t stream);
+/* contrad.loss_D_fn's GAN term (training/gan/contrad.py:51-64) on logits[3N] (stride ld): kind 0 nonsat,
+ * 1 wgan, 2 hinge, 3 lsgan.  out3 = {loss, mean d_real, mean d_gen}; grad[3N] = d loss / d logits. */
+int contrad_gan_d_loss(const float* logits, int ld, int N, int kind, float* out3, float* grad,
+                       contrad_stream_t stream);
+/* contrad.loss_G_fn (contrad.py:73-82) on logits[N]: kind 0 nonsat, 3 lsgan, other: -mean. */
+int contrad_gan_g_loss(const float* logits, int ld, int N, int kind, float* out1, float* grad,
+                       contrad_stream_t stream);
+
+/* torch.optim.Adam step (train_gan.py:273-274; no weight decay / amsgrad) fused over up to 64 tensors per
+ * launch; `step` is the 1-based step count of these tensors, grad_scale multiplies every gradient first
+ * (1/world_size after a sum all-reduce). */
+#define CONTRAD_ADAM_MAX_TENSORS 64
+#define CONTRAD_ADAM_CHUNK 16384
+typedef struct {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  long long numel;
+} contrad_adam_tensor;
+typedef struct {
+  int n;
+  contrad_adam_tensor t[CONTRAD_ADAM_MAX_TENSORS];
+  int block_start[CONTRAD_ADAM_MAX_TENSORS + 1]; /* filled by the launcher */
+} contrad_adam_batch;
+int contrad_adam_step(const contrad_adam_batch* b, int step, float lr, float beta1, float beta2, float eps,
+                      float grad_scale, contrad_stream_t stream);
+/* y = a*y + b*x (G EMA `accumulate`, utils.py:130-143) */
+int contrad_axpby(float* y, const float* x, long long n, float a, float b, contrad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SimCLR augmentation, fused (augment/__init__.py:106-122 `simclr()` / `simclr_hq()`):
+ * RandomResizeCropLayer + HorizontalFlipLayer (augment/spatial.py:84-148) as ONE bilinear/reflection
+ * gather, RandomApply(ColorJitterLayer) (augment/color_jitter.py:16-104, augment/utils.py:6-63),
+ * RandomApply(RandomColorGrayLayer) (augment/__init__.py:82-103).  NCHW in, NCHW out, x != y.
+ * params[B][CONTRAD_AUG_NPARAM] = {theta00, theta11, theta02, theta12, flip_sign, jitter_mask,
+ * f_contrast, f_h, f_s, f_v, gray_mask, blur_mask}, sampled on the host in the reference's draw order.
+ * ---------------------------------------------------------------------------------------------- */
+#define CONTRAD_AUG_NPARAM 12
+long long contrad_simclr_workspace_bytes(int B, int H, int W);
+int contrad_simclr_augment(const float* x, float* y, const float* params, int B, int H, int W,
+                           int contrast_first, int has_contrast, float* workspace,
+                           long long workspace_bytes, contrad_stream_t stream);
+/* RandomApply(GaussianBlur) (augment/__init__.py:53-78): separable (2*radius+1)-tap blur with reflect
+ * padding on samples whose blur_mask != 0, copy-through otherwise; tmp is a scratch image batch. */
+int contrad_gaussian_blur_masked(const float* x, float* tmp, float* y, const float* params,
+                                 const float* kernel1d, int B, int H, int W, int radius,
+                                 contrad_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -322,13 +322,24 @@ def spectral_norm_weight(sd, prefix, training=True, eps=1e-12):
     return w / sigma
 
 
-def sndcgan_d_features(sd, x, training=True):
+def _lrelu(y, slope, mask=None):
+    """leaky_relu; with ``mask`` (bool, True where the unit is in its positive region) the linear region is
+    imposed from outside instead of taken from sign(y).  Used by the GPU parity tests to evaluate the CPU
+    gradient on the SAME piecewise-linear region as the kernel under test: leaky_relu's derivative is
+    discontinuous at 0, and a pre-activation of ~1e-8 (pure fp32 summation-order noise) otherwise flips a slope
+    1 <-> 0.1 and pollutes an element-wise gradient comparison with an error that is not a kernel error."""
+    if mask is None:
+        return F.leaky_relu(y, slope)
+    return y * torch.where(mask, torch.ones((), dtype=y.dtype), torch.full((), slope, dtype=y.dtype))
+
+
+def sndcgan_d_features(sd, x, training=True, act_masks=None):
     """D_SNDCGAN.penultimate (sndcgan.py:122-128)."""
     h = x * 2. - 1.
     for i, (ci, co, k, s, p) in enumerate(SNDCGAN_D_CONVS):
         pre = 'main.%d' % (2 * i)
         h = F.conv2d(h, spectral_norm_weight(sd, pre, training), sd[pre + '.bias'], stride=s, padding=p)
-        h = F.leaky_relu(h, 0.1)
+        h = _lrelu(h, 0.1, None if act_masks is None else act_masks[i])
     return h.reshape(h.size(0), -1)
 
 
@@ -336,21 +347,22 @@ def _sn_linear(sd, prefix, x, training):
     return F.linear(x, spectral_norm_weight(sd, prefix, training), sd[prefix + '.bias'])
 
 
-def d_heads(sd, features, sg_linear, training=True):
+def d_heads(sd, features, sg_linear, training=True, hidden_masks=None):
     """BaseDiscriminator.forward heads (base.py:122-133) with TinyDiscriminator (base.py:14-35)."""
     fd = features.detach() if sg_linear else features
-    out = _sn_linear(sd, 'linear.l2', F.leaky_relu(_sn_linear(sd, 'linear.l1', fd, training), 0.1), training)
+    hm = hidden_masks if hidden_masks is not None else (None, None, None)
+    out = _sn_linear(sd, 'linear.l2', _lrelu(_sn_linear(sd, 'linear.l1', fd, training), 0.1, hm[0]), training)
     proj = _sn_linear(sd, 'projection.2',
-                      F.leaky_relu(_sn_linear(sd, 'projection.0', features, training), 0.1), training)
+                      _lrelu(_sn_linear(sd, 'projection.0', features, training), 0.1, hm[1]), training)
     proj2 = _sn_linear(sd, 'projection2.2',
-                       F.leaky_relu(_sn_linear(sd, 'projection2.0', features, training), 0.1), training)
+                       _lrelu(_sn_linear(sd, 'projection2.0', features, training), 0.1, hm[2]), training)
     out = out + (proj.mean() + proj2.mean()) * 0.
     return out, proj, proj2
 
 
-def sndcgan_d_forward(sd, x, sg_linear=False, training=True):
-    feats = sndcgan_d_features(sd, x, training)
-    out, proj, proj2 = d_heads(sd, feats, sg_linear, training)
+def sndcgan_d_forward(sd, x, sg_linear=False, training=True, act_masks=None, hidden_masks=None):
+    feats = sndcgan_d_features(sd, x, training, act_masks)
+    out, proj, proj2 = d_heads(sd, feats, sg_linear, training, hidden_masks)
     return out, proj, proj2, feats
 
 
