@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""Headline benchmark: discriminator-step images/sec (ContraD, SimCLR aug), SNDCGAN on CIFAR-10-shaped synthetic
+data, global batch 512 (BASELINE.json configs[1]; configs[2] = the same global batch over N GPUs).
+
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run)
+
+One "step" = one full D-step of the reference loop (train_gan.py:153-163): no-grad G forward for N fakes ->
+SimCLR-augment 3N images -> D forward -> NT-Xent + SupCon + non-saturating GAN loss -> backward -> [embedding
+all-gather / gradient all-reduce over RCCL] -> Adam on D.  Inputs are resident in HBM before the timed region;
+weights are random-init.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GLOBAL_BATCH = 512
+FLOP_PER_IMAGE = 4.28e9        # algorithmic FLOPs of one SNDCGAN D-step per real image
+PEAK_FP32_MFMA = 157.3         # TFLOP/s, MI355X_MICROARCH.md chip table (v_mfma_f32_32x32x2_f32)
+
+
+def cpu_baseline(n=64, steps=5):
+    """BASELINE.json configs[0] on the host cores: the oracle's (= reference algorithm's) PyTorch-CPU D-step."""
+    from oracle import contrad_oracle as O
+    torch.manual_seed(0); np.random.seed(0)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 32))      # the 32x32 convs stop scaling (and oversubscribe) beyond that
+    torch.set_num_threads(threads)
+    sd = O.det_fill(O.sndcgan_d_param_shapes(), seed=1)
+    gsd = O.det_fill(O.sndcgan_g_param_shapes(), seed=2)
+    params = [k for k in sd if k.endswith('weight_orig') or k.endswith('bias')]
+    for k in params:
+        sd[k].requires_grad_()
+    m = {k: torch.zeros_like(sd[k]) for k in params}
+    v = {k: torch.zeros_like(sd[k]) for k in params}
+    x = torch.rand(n, 3, 32, 32)
+
+    def step(t):
+        with torch.no_grad():
+            fake = O.sndcgan_g_forward(gsd, O.sample_latent_sndcgan(n))
+        p = O.sample_simclr_params(3 * n, 32, 32, O.SIMCLR_CIFAR)
+        aug = O.simclr_apply(torch.cat([x, x, fake]), p)
+        closs, gloss, _, _ = O.contrad_loss_d(lambda z: O.sndcgan_d_forward(sd, z, sg_linear=True)[:3], aug, n)
+        for k in params:
+            sd[k].grad = None
+        (closs + gloss).backward()
+        with torch.no_grad():
+            for k in params:
+                O.adam_step(sd[k], sd[k].grad, m[k], v[k], t, 2e-4, 0.5, 0.999)
+
+    t0 = time.perf_counter()
+    step(1)
+    warm = time.perf_counter() - t0
+    steps = max(1, min(steps, int(20.0 / max(warm, 1e-3))))      # bound the sample to ~20 s of CPU work
+    t0 = time.perf_counter()
+    for t in range(steps):
+        step(t + 2)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": n / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "SNDCGAN ContraD D-step, 32x32, batch %d, %d timed steps after 1 warm-up "
+                      "(oracle = PyTorch-CPU restatement of the reference path, %.3f s/step)" % (n, steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)     # "nccl" is RCCL on ROCm
+
+    from contrad_amd import config, ops
+    from contrad_amd.augment import get_augment
+    from contrad_amd.engine import GradAllReducer, d_step, set_grad
+    from contrad_amd.models.gan import get_architecture
+    from contrad_amd.optim import FusedAdam
+    from contrad_amd.training.gan import setup
+
+    config.clear_config()
+    config.parse_config_files_and_bindings([os.path.join(config.CONFIG_ROOT, 'defaults', 'gan.gin'),
+                                            os.path.join(config.CONFIG_ROOT, 'defaults', 'augment.gin'),
+                                            os.path.join(config.CONFIG_ROOT, 'gan', 'cifar10', 'c10_b512.gin')])
+    opt = config.get_bindings('options')
+    assert opt['batch_size'] == GLOBAL_BATCH and GLOBAL_BATCH % world == 0
+    n_local = GLOBAL_BATCH // world                          # train_gan.py:247
+
+    torch.manual_seed(0 + rank); np.random.seed(0 + rank)
+    G, D = get_architecture('sndcgan', (32, 32, 3))
+    if world > 1:                                            # identical weights on every rank (DDP's broadcast)
+        torch.manual_seed(0)
+        G, D = get_architecture('sndcgan', (32, 32, 3))
+        torch.manual_seed(0 + rank)
+    G, D = G.to(dev).train(), D.to(dev).train()
+    P = argparse.Namespace(mode='contrad', aug='simclr', temp=0.1, lbd_a=1.0, distributed=(world > 1))
+    P = setup(P)
+    P.augment_fn = get_augment(mode=P.aug).to(dev)
+    options = {'loss': opt['loss'], 'batch_size': n_local}
+    opt_D = FusedAdam(D.parameters(), lr=opt['lr'], betas=tuple(opt['beta']))
+    reducer = GradAllReducer(D.parameters()) if world > 1 else None
+    set_grad(G, False); set_grad(D, True)
+    images = torch.rand(n_local, 3, 32, 32, device=dev)      # synthetic CIFAR-shaped batch, resident in HBM
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        d_step(P, G, D, opt_D, options, images, reducer)
+    ops.PROFILE = []                                         # per-launch events of the conv engine (roofline)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        d_loss, aux = d_step(P, G, D, opt_D, options, images, reducer)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms = dt / args.steps * 1e3
+    value = GLOBAL_BATCH * args.steps / dt
+    finite = bool(torch.isfinite(d_loss).item() and torch.isfinite(aux['penalty']).item())
+
+    if rank == 0:
+        # dominant kernel = the conv-engine instance with the largest summed device time in the timed region
+        agg = {}
+        for name, flops, e0, e1 in prof:
+            a = agg.setdefault(name, [0.0, 0.0, 0])
+            a[0] += e0.elapsed_time(e1) * 1e-3
+            a[1] += flops
+            a[2] += 1
+        dom = max(agg.items(), key=lambda kv: kv[1][0])
+        name, (tsum, fsum, cnt) = dom
+        achieved = fsum / tsum / 1e12
+        conv_time = sum(a[0] for a in agg.values())
+        roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": None,
+                    "launches_per_step": cnt / args.steps, "avg_launch_ms": round(tsum / cnt * 1e3, 4),
+                    "algorithmic_gflop_per_launch": round(fsum / cnt / 1e9, 2),
+                    "conv_engine_share_of_step": round(conv_time / dt, 3),
+                    "all_kernels": {k: {"tflops": round(v[1] / v[0] / 1e12, 1), "ms_per_step": round(v[0] / args.steps * 1e3, 3)}
+                                    for k, v in sorted(agg.items())},
+                    "step_level": {"achieved": round(value / world * FLOP_PER_IMAGE / 1e12, 2),
+                                   "frac": round(value / world * FLOP_PER_IMAGE / 1e12 / PEAK_FP32_MFMA, 4),
+                                   "flop_per_image": FLOP_PER_IMAGE}}
+        out = {"metric": "discriminator-step images/sec (ContraD, SimCLR aug)", "value": round(value, 1),
+               "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "SNDCGAN + ContraD D-step, CIFAR-10 32x32, global batch %d, simclr aug, "
+                                      "nonsat loss, Adam(2e-4,(0.5,0.999)), random-init weights" % GLOBAL_BATCH,
+                          "global_batch": GLOBAL_BATCH, "per_gpu_batch": n_local,
+                          "parallelism": "dp%d" % world, "losses_finite": finite},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -61,6 +61,8 @@ def _map_type(t):
         base = t[:-1].replace('const', '').strip()
         if base == 'contrad_conv_desc':
             return ctypes.POINTER(ConvDesc)
+        if base == 'int':
+            return ctypes.POINTER(ctypes.c_int)
         return ctypes.c_void_p
     t = t.replace('const', '').strip()
     return _CTYPES[t]

@@ -162,15 +162,24 @@ __global__ __launch_bounds__(256) void rgb_conv_wgrad_kernel(RgbWgradArgs a) {
 }
 
 // dwp[row][k] (row < TAPS*Cin, leading dim ldw) and db[k] from the per-block partials, fixed order
-__global__ void rgb_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks, int rows, int K,
-                                        float* __restrict__ dwp, int ldw, float* __restrict__ db) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (rows + 1) * K) return;
+__global__ __launch_bounds__(256) void rgb_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks,
+                                                               int rows, int K, float* __restrict__ dwp, int ldw,
+                                                               float* __restrict__ db) {
+  __shared__ float red[4][64];
+  const int ex = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + ex;
+  const int E = (rows + 1) * K;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * (rows + 1) * K + e];
-  const int row = e / K, k = e - row * K;
-  if (row < rows) dwp[(size_t)row * ldw + k] = s;
-  else if (db) db[k] = s;
+  if (e < E)
+    for (int b = py; b < nblocks; b += 4) s += partial[(size_t)b * E + e];
+  red[py][ex] = s;
+  __syncthreads();
+  if (py == 0 && e < E) {
+    s = (red[0][ex] + red[1][ex]) + (red[2][ex] + red[3][ex]);
+    const int row = e / K, k = e - row * K;
+    if (row < rows) dwp[(size_t)row * ldw + k] = s;
+    else if (db) db[k] = s;
+  }
 }
 
 struct RgbDgradArgs {
@@ -184,50 +193,57 @@ struct RgbDgradArgs {
 };
 
 // stride-1 transposed conv onto C <= 4 channels: out[n,c,h,w] = sum_{kh,kw,k} gy[n,h+p-kh,w+p-kw,k] wp[(kh,kw,c),k]
-// One thread per output pixel; weights (taps*C*K floats) broadcast from LDS.
+// K/4 lanes cooperate on one output pixel: each lane owns 4 input channels (one coalesced float4 per tap, so a
+// pixel's K channels are read as one contiguous run), keeps its taps x C x 4 weights in registers, and the C partial
+// sums are combined with xor-shuffles inside the lane group.  256/(K/4) pixels per block pass.
+template <int KSZ>
 __global__ __launch_bounds__(256) void rgb_conv_dgrad_kernel(RgbDgradArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [taps][C][K]
-  const int taps = a.k * a.k;
-  for (int e = threadIdx.x; e < taps * a.C * a.K; e += blockDim.x) {
-    const int t = e / (a.C * a.K), c = (e / a.K) % a.C, k = e % a.K;
-    lds[e] = a.wp[(size_t)(t * a.C + c) * a.ldw + k];
-  }
-  __syncthreads();
-  const long long total = (long long)a.N * a.H * a.W;
-  for (long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix < total;
-       pix += (long long)gridDim.x * blockDim.x) {
-    const int w = (int)(pix % a.W);
-    const int h = (int)((pix / a.W) % a.H);
-    const int n = (int)(pix / ((long long)a.W * a.H));
-    float acc[MAX_CIN] = {0.f, 0.f, 0.f, 0.f};
-    for (int kh = 0; kh < a.k; ++kh) {
-      const int ho = h + a.pad - kh;
-      if ((unsigned)ho >= (unsigned)a.H) continue;
-      for (int kw = 0; kw < a.k; ++kw) {
-        const int wo = w + a.pad - kw;
-        if ((unsigned)wo >= (unsigned)a.W) continue;
-        const float* g = a.gy + ((size_t)(n * a.H + ho) * a.W + wo) * a.ldy;
-        const float* wt = lds + (size_t)(kh * a.k + kw) * a.C * a.K;
-        for (int k = 0; k < a.K; k += 4) {
-          const float4 gv = *reinterpret_cast<const float4*>(g + k);
+  constexpr int TAPS = KSZ * KSZ;
+  const int tpp = a.K >> 2;                 // lanes per pixel (power of two, <= 64)
+  const int slots = blockDim.x / tpp;
+  const int cg = threadIdx.x % tpp, slot = threadIdx.x / tpp;
+  float4 w[TAPS * MAX_CIN];
 #pragma unroll
-          for (int c = 0; c < MAX_CIN; ++c) {
-            if (c < a.C) {
-              const float4 wv = *reinterpret_cast<const float4*>(wt + c * a.K + k);
-              acc[c] = fmaf(gv.x, wv.x, acc[c]); acc[c] = fmaf(gv.y, wv.y, acc[c]);
-              acc[c] = fmaf(gv.z, wv.z, acc[c]); acc[c] = fmaf(gv.w, wv.w, acc[c]);
-            }
-          }
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < MAX_CIN; ++c)
+      w[t * MAX_CIN + c] = (c < a.C)
+                               ? *reinterpret_cast<const float4*>(a.wp + (size_t)(t * a.C + c) * a.ldw + cg * 4)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+  const long long total = (long long)a.N * a.H * a.W;
+  for (long long pix0 = (long long)blockIdx.x * slots; pix0 < total; pix0 += (long long)gridDim.x * slots) {
+    const long long pix = pix0 + slot;
+    const bool live = pix < total;
+    const long long pp = live ? pix : 0;
+    const int wq = (int)(pp % a.W);
+    const int h = (int)((pp / a.W) % a.H);
+    const int n = (int)(pp / ((long long)a.W * a.H));
+    float acc[MAX_CIN] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < KSZ; ++kh) {
+      const int ho = h + a.pad - kh;
+#pragma unroll
+      for (int kw = 0; kw < KSZ; ++kw) {
+        const int wo = wq + a.pad - kw;
+        const bool ok = live && (unsigned)ho < (unsigned)a.H && (unsigned)wo < (unsigned)a.W;
+        const float4 g = *reinterpret_cast<const float4*>(
+            a.gy + (ok ? ((size_t)(n * a.H + ho) * a.W + wo) * a.ldy + cg * 4 : 0));
+        const float m = ok ? 1.f : 0.f;
+#pragma unroll
+        for (int c = 0; c < MAX_CIN; ++c) {
+          const float4 ww = w[(kh * KSZ + kw) * MAX_CIN + c];
+          acc[c] += m * (g.x * ww.x + g.y * ww.y + g.z * ww.z + g.w * ww.w);
         }
       }
     }
 #pragma unroll
-    for (int c = 0; c < MAX_CIN; ++c) {
-      if (c < a.C) {
-        float v = acc[c] + (a.bias ? a.bias[c] : 0.f);
-        if (a.act == 1) v = tanhf(v);
-        a.out[((size_t)(n * a.C + c) * a.H + h) * a.W + w] = v * a.out_scale + a.out_shift;
-      }
+    for (int c = 0; c < MAX_CIN; ++c)
+      for (int o = tpp >> 1; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 64);
+    if (live && cg < a.C) {
+      float v = (cg == 0) ? acc[0] : (cg == 1) ? acc[1] : (cg == 2) ? acc[2] : acc[3];
+      v += a.bias ? a.bias[cg] : 0.f;
+      if (a.act == 1) v = tanhf(v);
+      a.out[((size_t)(n * a.C + cg) * a.H + h) * a.W + wq] = v * a.out_scale + a.out_shift;
     }
   }
 }
@@ -267,7 +283,7 @@ extern "C" int contrad_rgb_conv_fwd(const float* img, const float* wp, const flo
 
 static int rgb_wgrad_grid(int N, int H, int W) {
   const int tiles = N * cdiv(H, pick_th(W));
-  return tiles < 1024 ? tiles : 1024;
+  return tiles < 512 ? tiles : 512;
 }
 
 extern "C" long long contrad_rgb_conv_wgrad_workspace_bytes(int N, int Cin, int H, int W, int K, int k) {
@@ -295,7 +311,7 @@ extern "C" int contrad_rgb_conv_wgrad(const float* img, const float* gy, float* 
   else hipLaunchKernelGGL((rgb_conv_wgrad_kernel<1, 3>), dim3(grid), dim3(256), smem, (hipStream_t)stream, a);
   CONTRAD_CHECK_LAUNCH();
   const int rows = k * k * Cin;
-  hipLaunchKernelGGL(rgb_wgrad_reduce_kernel, dim3(cdiv((rows + 1) * K, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(rgb_wgrad_reduce_kernel, dim3(cdiv((rows + 1) * K, 64)), dim3(256), 0,
                      (hipStream_t)stream, workspace, grid, rows, K, dwp, ldw, dbias);
   CONTRAD_CHECK_LAUNCH();
   return 0;
@@ -305,18 +321,18 @@ extern "C" int contrad_rgb_conv_dgrad(const float* gy, const float* wp, const fl
                                       int C, int H, int W, int K, int k, int ldy, int ldw, int act,
                                       float out_scale, float out_shift, contrad_stream_t stream) {
   CONTRAD_ARG(gy && wp && out && N > 0 && H > 0 && W > 0 && C >= 1 && C <= MAX_CIN);
-  CONTRAD_ARG((k == 1 || k == 3) && K >= 4 && (K & 3) == 0 && ldy >= K && (ldy & 3) == 0 && ldw >= K);
-  CONTRAD_ARG(act == 0 || act == 1);
+  CONTRAD_ARG((k == 1 || k == 3) && K >= 16 && K <= 256 && (K & (K - 1)) == 0 && ldy >= K && (ldy & 3) == 0);
+  CONTRAD_ARG(ldw >= K && (ldw & 3) == 0 && (act == 0 || act == 1));
   RgbDgradArgs a{};
   a.gy = gy; a.wp = wp; a.bias = bias; a.out = out;
   a.N = N; a.C = C; a.H = H; a.W = W; a.K = K; a.ldy = ldy; a.ldw = ldw; a.k = k; a.pad = k / 2;
   a.act = act; a.out_scale = out_scale; a.out_shift = out_shift;
-  const size_t smem = (size_t)k * k * C * K * sizeof(float);
-  CONTRAD_ARG(smem <= 64 * 1024);
   const long long total = (long long)N * H * W;
-  long long grid = (total + 255) / 256;
-  if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(rgb_conv_dgrad_kernel, dim3((int)grid), dim3(256), smem, (hipStream_t)stream, a);
+  const int slots = 256 / (K / 4);
+  long long grid = (total + slots - 1) / slots;
+  if (grid > 4096) grid = 4096;
+  if (k == 3) hipLaunchKernelGGL(rgb_conv_dgrad_kernel<3>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(rgb_conv_dgrad_kernel<1>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a);
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }

@@ -52,14 +52,30 @@ __global__ __launch_bounds__(256) void colstats_partial_kernel(const float* __re
   }
 }
 
-// out[s][c] = sum_b partial[b][s][c]  (optionally accumulated onto out)
-__global__ void colstats_reduce_kernel(const float* __restrict__ partial, int nblocks, int nstat, int K,
-                                       float* __restrict__ out, int accumulate) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nstat * K) return;
-  float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * nstat * K + e];
-  out[e] = accumulate ? out[e] + s : s;
+// out[s][c] = sum_b partial[b][s][c]  (optionally accumulated onto out).  Block = 64 entries x 4 partial lanes:
+// the partial index is split over the 4 waves so no thread walks more than nblocks/4 strided loads.
+__global__ __launch_bounds__(256) void colstats_reduce_kernel(const float* __restrict__ partial, int nblocks,
+                                                              int nstat, int K, float* __restrict__ out,
+                                                              int accumulate) {
+  __shared__ float red[4][64];
+  const int ex = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + ex;
+  const int E = nstat * K;
+  float s0 = 0.f, s1 = 0.f;
+  if (e < E) {
+    int b = py;
+    for (; b + 4 < nblocks; b += 8) {
+      s0 += partial[(size_t)b * E + e];
+      s1 += partial[(size_t)(b + 4) * E + e];
+    }
+    if (b < nblocks) s0 += partial[(size_t)b * E + e];
+  }
+  red[py][ex] = s0 + s1;
+  __syncthreads();
+  if (py == 0 && e < E) {
+    const float s = (red[0][ex] + red[1][ex]) + (red[2][ex] + red[3][ex]);
+    out[e] = accumulate ? out[e] + s : s;
+  }
 }
 
 // ---- BatchNorm (training mode) finalise + apply + ReLU ----
@@ -185,7 +201,7 @@ __global__ void axpby_kernel(float* __restrict__ y, const float* __restrict__ x,
 
 int colstats_plan(long long M, int* rows_per_block, int* nblocks) {
   long long nb = (M + 255) / 256;  // >= 256 rows per block
-  if (nb > 1024) nb = 1024;
+  if (nb > 512) nb = 512;
   if (nb < 1) nb = 1;
   *rows_per_block = (int)((M + nb - 1) / nb);
   *nblocks = (int)((M + *rows_per_block - 1) / *rows_per_block);
@@ -213,7 +229,7 @@ extern "C" int contrad_colstats(const float* x, long long M, int K, int ld, int 
   else hipLaunchKernelGGL(colstats_partial_kernel<false>, grid, dim3(256), 0, s, x, M, K, ld, rpb, workspace);
   CONTRAD_CHECK_LAUNCH();
   const int nstat = with_sq ? 2 : 1;
-  hipLaunchKernelGGL(colstats_reduce_kernel, dim3(cdiv(nstat * K, 256)), dim3(256), 0, s, workspace, nb, nstat, K,
+  hipLaunchKernelGGL(colstats_reduce_kernel, dim3(cdiv(nstat * K, 64)), dim3(256), 0, s, workspace, nb, nstat, K,
                      out, accumulate);
   CONTRAD_CHECK_LAUNCH();
   return 0;

@@ -47,7 +47,13 @@ struct IgemmArgs {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-template <int MODE, int BM, int BN>
+// Loads are BRANCH-FREE: an out-of-range element loads from a clamped (always valid) address and is zeroed by a
+// predicate mask when the tile is written to LDS, one K-tile later.  (A "cond ? load : 0" select makes hipcc
+// branch around every load and wait vmcnt(0) at the merge, which serialises the global-load latency with the MFMA
+// phase -- cdna_hip_programming.md 5, trap (c).)  VEC = every operand row is 16-byte addressable in float4 units
+// (C % 4 == 0, K % 4 == 0, leading dimensions % 4 == 0); the !VEC instantiation covers odd shapes (Cin = 3,
+// Cout = 1) with per-element gathers and is only ever a tiny share of a step.
+template <int MODE, int BM, int BN, bool VEC>
 __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool A_KCONTIG = (MODE != MODE_WGRAD);
@@ -57,6 +63,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
   constexpr int A_SZ = BK * LDA, B_SZ = BK * LDB;
   constexpr int PA = BM / 32, PB = BN / 32;  // float4 prefetch registers per operand
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  constexpr int EPV = VEC ? 1 : 4;           // predicate bits per float4
 
   const contrad_conv_desc& d = p.d;
   const int tid = threadIdx.x;
@@ -70,7 +77,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
   // ---------------- per-mode problem geometry ----------------
   int M = p.M, Ncol = p.Ncol, Kg = p.Kg;
   // DGRAD parity class
-  int ph = 0, pw = 0, Hc = 0, Wc = 0, kh0 = 0, kw0 = 0, nth = 0, ntw = 0, bh = 0, bw = 0;
+  int ph = 0, pw = 0, Hc = 0, Wc = 0, kh0 = 0, kw0 = 0, nth = 0, ntw = 1, bh = 0, bw = 0;
   if constexpr (MODE == MODE_DGRAD) {
     const int s = d.stride;
     ph = blockIdx.y / s;
@@ -86,6 +93,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
     M = d.N * Hc * Wc;
     Ncol = d.C;
     Kg = nth * ntw * d.K;
+    if (ntw == 0) ntw = 1;
     if (m0 >= M) return;  // uniform per block, before any barrier
   }
   // WGRAD split range over positions
@@ -107,9 +115,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
 
   int a_n[PA], a_h[PA], a_w[PA];
   bool a_ok[PA];
-  // WGRAD: fixed (tap, channel) of this thread's 4 A columns, and incremental position decode
-  int wg_kh = 0, wg_kw = 0, wg_c = 0;
-  bool wg_colok = false;
   int wg_dn = 0, wg_dh = 0, wg_dw = 0;
 
   if constexpr (MODE == MODE_FWD) {
@@ -136,13 +141,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
       a_w[i] = wq + bw;      // wo = a_w - tw
     }
   } else {
-    const int icol = m0 + a_c4 * 4;
-    wg_colok = icol < Kg;
-    const int ic = wg_colok ? icol : 0;
-    const int tap = ic / d.C;
-    wg_c = ic - tap * d.C;
-    wg_kh = tap / d.KW;
-    wg_kw = tap - wg_kh * d.KW;
     const int hw = d.Ho * d.Wo;
     wg_dn = BK / hw;
     const int rem = BK - wg_dn * hw;
@@ -160,129 +158,149 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
   }
 
   float4 ra[PA], rb[PB];
+  unsigned amask = 0, bmask = 0;   // predicate bits of the tile currently held in ra / rb
 
-  // ---------------- global -> register tile loads ----------------
+  // element offsets (in floats) with validity, per mode ----------------------------------------------------
+  // FWD   A element (row i, contraction index k): x[n, ho*s-p+kh, wo*s-p+kw, c]
+  auto fwd_a = [&](int i, int k, bool& ok) -> size_t {
+    const int kk = (k < Kg) ? k : 0;
+    const int tap = kk / d.C, c = kk - tap * d.C;
+    const int kh = tap / d.KW, kw = tap - kh * d.KW;
+    const int hi = a_h[i] + kh, wi = a_w[i] + kw;
+    ok = (k < Kg) && a_ok[i] && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
+    return ok ? ((size_t)(a_n[i] * d.H + hi) * d.W + wi) * d.ldx + c : 0;
+  };
+  // DGRAD A element: gy[n, hq+bh-th, wq+bw-tw, co];  B element (k, column c): wp[(tap, c), co]
+  auto dg_decode = [&](int k, int& th, int& tw, int& co, int& tapflat) {
+    const int kk = (k < Kg) ? k : 0;
+    const int ti = kk / d.K;
+    co = kk - ti * d.K;
+    th = ti / ntw;
+    tw = ti - th * ntw;
+    tapflat = (kh0 + d.stride * th) * d.KW + (kw0 + d.stride * tw);
+  };
+  // WGRAD A element (position row i, gemm column ic): x[n, ho*s-p+kh, wo*s-p+kw, c]
+  auto wg_a = [&](int i, int ic, bool pok, bool& ok) -> size_t {
+    const int icc = (ic < Kg) ? ic : 0;
+    const int tap = icc / d.C, c = icc - tap * d.C;
+    const int kh = tap / d.KW, kw = tap - kh * d.KW;
+    const int hi = a_h[i] * d.stride - d.pad + kh, wi = a_w[i] * d.stride - d.pad + kw;
+    ok = pok && (ic < Kg) && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
+    return ok ? ((size_t)(a_n[i] * d.H + hi) * d.W + wi) * d.ldx + c : 0;
+  };
+
+  // ---------------- global -> register tile loads (no branches, no waits) ----------------
   auto load_tile = [&](int t) {
     const int k0 = t * BK;
+    amask = 0;
+    bmask = 0;
     if constexpr (MODE == MODE_FWD) {
-      // A: im2col gather, 4 consecutive channels of one tap
       const int k = k0 + kq * 4;
-      if ((d.C & 3) == 0) {
-        const bool kok = k < Kg;
-        const int kk = kok ? k : 0;
-        const int tap = kk / d.C, c = kk - tap * d.C;
-        const int kh = tap / d.KW, kw = tap - kh * d.KW;
 #pragma unroll
-        for (int i = 0; i < PA; ++i) {
-          const int hi = a_h[i] + kh, wi = a_w[i] + kw;
-          const bool ok = kok && a_ok[i] && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
-          ra[i] = ok ? ld4(p.A + ((size_t)(a_n[i] * d.H + hi) * d.W + wi) * d.ldx + c) : zero4();
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < PA; ++i) {
+      for (int i = 0; i < PA; ++i) {
+        if constexpr (VEC) {
+          bool ok;
+          const size_t off = fwd_a(i, k, ok);
+          ra[i] = ld4(p.A + off);
+          amask |= (unsigned)ok << i;
+        } else {
           float v[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const int kj = k + j;
-            v[j] = 0.f;
-            if (kj < Kg && a_ok[i]) {
-              const int tap = kj / d.C, c = kj - tap * d.C;
-              const int kh = tap / d.KW, kw = tap - kh * d.KW;
-              const int hi = a_h[i] + kh, wi = a_w[i] + kw;
-              if ((unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W)
-                v[j] = p.A[((size_t)(a_n[i] * d.H + hi) * d.W + wi) * d.ldx + c];
-            }
+            bool ok;
+            const size_t off = fwd_a(i, k + j, ok);
+            v[j] = p.A[off];
+            amask |= (unsigned)ok << (4 * i + j);
           }
           ra[i] = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
-      // B: packed weights, row-contiguous
       const int col = n0 + b_c4 * 4;
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
         const int kr = k0 + b_r + B_RPP * i;
-        if (kr < Kg && col + 3 < Ncol) {
-          rb[i] = ld4(p.B + (size_t)kr * d.ldw + col);
+        if constexpr (VEC) {
+          const bool ok = kr < Kg && col < Ncol;
+          rb[i] = ld4(p.B + (ok ? (size_t)kr * d.ldw + col : 0));
+          bmask |= (unsigned)ok << i;
         } else {
-          float v[4] = {0.f, 0.f, 0.f, 0.f};
-          if (kr < Kg) {
+          float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (col + j < Ncol) v[j] = p.B[(size_t)kr * d.ldw + col + j];
+          for (int j = 0; j < 4; ++j) {
+            const bool ok = kr < Kg && col + j < Ncol;
+            v[j] = p.B[ok ? (size_t)kr * d.ldw + col + j : 0];
+            bmask |= (unsigned)ok << (4 * i + j);
           }
           rb[i] = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
     } else if constexpr (MODE == MODE_DGRAD) {
       const int k = k0 + kq * 4;
-      if ((d.K & 3) == 0) {
+      if constexpr (VEC) {
+        int th, tw, co, tapflat;
+        dg_decode(k, th, tw, co, tapflat);
         const bool kok = k < Kg;
-        const int kk = kok ? k : 0;
-        const int ti = kk / d.K, co = kk - ti * d.K;
-        const int th = ti / ntw, tw = ti - th * ntw;
-        const int tapflat = (kh0 + d.stride * th) * d.KW + (kw0 + d.stride * tw);
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
           const int ho = a_h[i] - th, wo = a_w[i] - tw;
           const bool ok = kok && a_ok[i] && (unsigned)ho < (unsigned)d.Ho && (unsigned)wo < (unsigned)d.Wo;
-          ra[i] = ok ? ld4(p.A + ((size_t)(a_n[i] * d.Ho + ho) * d.Wo + wo) * d.ldy + co) : zero4();
+          ra[i] = ld4(p.A + (ok ? ((size_t)(a_n[i] * d.Ho + ho) * d.Wo + wo) * d.ldy + co : 0));
+          amask |= (unsigned)ok << i;
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
           const int c = n0 + krow + 32 * i;
-          rb[i] = (kok && c < Ncol) ? ld4(p.B + ((size_t)tapflat * d.C + c) * d.ldw + co) : zero4();
+          const bool ok = kok && c < Ncol;
+          rb[i] = ld4(p.B + (ok ? ((size_t)tapflat * d.C + c) * d.ldw + co : 0));
+          bmask |= (unsigned)ok << i;
         }
       } else {
-#pragma unroll
-        for (int i = 0; i < PA; ++i) ra[i] = zero4();
-#pragma unroll
-        for (int i = 0; i < PB; ++i) rb[i] = zero4();
+        float va[PA][4], vb[PB][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int kj = k + j;
-          if (kj < Kg) {
-            const int ti = kj / d.K, co = kj - ti * d.K;
-            const int th = ti / ntw, tw = ti - th * ntw;
-            const int tapflat = (kh0 + d.stride * th) * d.KW + (kw0 + d.stride * tw);
+          int th, tw, co, tapflat;
+          dg_decode(k + j, th, tw, co, tapflat);
+          const bool kok = (k + j) < Kg;
 #pragma unroll
-            for (int i = 0; i < PA; ++i) {
-              const int ho = a_h[i] - th, wo = a_w[i] - tw;
-              if (a_ok[i] && (unsigned)ho < (unsigned)d.Ho && (unsigned)wo < (unsigned)d.Wo)
-                (&ra[i].x)[j] = p.A[((size_t)(a_n[i] * d.Ho + ho) * d.Wo + wo) * d.ldy + co];
-            }
+          for (int i = 0; i < PA; ++i) {
+            const int ho = a_h[i] - th, wo = a_w[i] - tw;
+            const bool ok = kok && a_ok[i] && (unsigned)ho < (unsigned)d.Ho && (unsigned)wo < (unsigned)d.Wo;
+            va[i][j] = p.A[ok ? ((size_t)(a_n[i] * d.Ho + ho) * d.Wo + wo) * d.ldy + co : 0];
+            amask |= (unsigned)ok << (4 * i + j);
+          }
 #pragma unroll
-            for (int i = 0; i < PB; ++i) {
-              const int c = n0 + krow + 32 * i;
-              if (c < Ncol) (&rb[i].x)[j] = p.B[((size_t)tapflat * d.C + c) * d.ldw + co];
-            }
+          for (int i = 0; i < PB; ++i) {
+            const int c = n0 + krow + 32 * i;
+            const bool ok = kok && c < Ncol;
+            vb[i][j] = p.B[ok ? ((size_t)tapflat * d.C + c) * d.ldw + co : 0];
+            bmask |= (unsigned)ok << (4 * i + j);
           }
         }
+#pragma unroll
+        for (int i = 0; i < PA; ++i) ra[i] = make_float4(va[i][0], va[i][1], va[i][2], va[i][3]);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) rb[i] = make_float4(vb[i][0], vb[i][1], vb[i][2], vb[i][3]);
       }
     } else {  // WGRAD
       const int pbase = p_begin + k0;
+      const int icol = m0 + a_c4 * 4;
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
         const int pp = pbase + a_r + A_RPP * i;
         const bool pok = pp < p_end;
-        if ((d.C & 3) == 0) {
-          const int hi = a_h[i] * d.stride - d.pad + wg_kh, wi = a_w[i] * d.stride - d.pad + wg_kw;
-          const bool ok = pok && wg_colok && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
-          ra[i] = ok ? ld4(p.A + ((size_t)(a_n[i] * d.H + hi) * d.W + wi) * d.ldx + wg_c) : zero4();
+        if constexpr (VEC) {
+          bool ok;
+          const size_t off = wg_a(i, icol, pok, ok);
+          ra[i] = ld4(p.A + off);
+          amask |= (unsigned)ok << i;
         } else {
-          float v[4] = {0.f, 0.f, 0.f, 0.f};
-          if (pok) {
+          float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int ic = m0 + a_c4 * 4 + j;
-              if (ic < Kg) {
-                const int tap = ic / d.C, c = ic - tap * d.C;
-                const int kh = tap / d.KW, kw = tap - kh * d.KW;
-                const int hi = a_h[i] * d.stride - d.pad + kh, wi = a_w[i] * d.stride - d.pad + kw;
-                if ((unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W)
-                  v[j] = p.A[((size_t)(a_n[i] * d.H + hi) * d.W + wi) * d.ldx + c];
-              }
-            }
+          for (int j = 0; j < 4; ++j) {
+            bool ok;
+            const size_t off = wg_a(i, icol + j, pok, ok);
+            v[j] = p.A[off];
+            amask |= (unsigned)ok << (4 * i + j);
           }
           ra[i] = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -297,14 +315,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
         const int pp = pbase + b_r + B_RPP * i;
-        if (pp < p_end && col + 3 < Ncol && (d.ldy & 3) == 0) {
-          rb[i] = ld4(p.B + (size_t)pp * d.ldy + col);
+        if constexpr (VEC) {
+          const bool ok = pp < p_end && col < Ncol;
+          rb[i] = ld4(p.B + (ok ? (size_t)pp * d.ldy + col : 0));
+          bmask |= (unsigned)ok << i;
         } else {
-          float v[4] = {0.f, 0.f, 0.f, 0.f};
-          if (pp < p_end) {
+          float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (col + j < Ncol) v[j] = p.B[(size_t)pp * d.ldy + col + j];
+          for (int j = 0; j < 4; ++j) {
+            const bool ok = pp < p_end && col + j < Ncol;
+            v[j] = p.B[ok ? (size_t)pp * d.ldy + col + j : 0];
+            bmask |= (unsigned)ok << (4 * i + j);
           }
           rb[i] = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -312,37 +333,47 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
     }
   };
 
-  // ---------------- register -> LDS ----------------
+  auto masked = [&](float4 v, unsigned mask, int i) -> float4 {
+    if constexpr (VEC) {
+      if (!((mask >> i) & 1u)) v = zero4();
+    } else {
+      if (!((mask >> (4 * i + 0)) & 1u)) v.x = 0.f;
+      if (!((mask >> (4 * i + 1)) & 1u)) v.y = 0.f;
+      if (!((mask >> (4 * i + 2)) & 1u)) v.z = 0.f;
+      if (!((mask >> (4 * i + 3)) & 1u)) v.w = 0.f;
+    }
+    return v;
+  };
+
+  // ---------------- register -> LDS (predicates applied here) ----------------
   auto store_tile = [&](int buf) {
     float* As = smem + buf * (A_SZ + B_SZ);
     float* Bs = As + A_SZ;
-    if constexpr (A_KCONTIG) {
 #pragma unroll
-      for (int i = 0; i < PA; ++i) {
+    for (int i = 0; i < PA; ++i) {
+      const float4 v = masked(ra[i], amask, i);
+      if constexpr (A_KCONTIG) {
         const int row = krow + 32 * i;
-        As[(kq * 4 + 0) * LDA + row] = ra[i].x;
-        As[(kq * 4 + 1) * LDA + row] = ra[i].y;
-        As[(kq * 4 + 2) * LDA + row] = ra[i].z;
-        As[(kq * 4 + 3) * LDA + row] = ra[i].w;
+        As[(kq * 4 + 0) * LDA + row] = v.x;
+        As[(kq * 4 + 1) * LDA + row] = v.y;
+        As[(kq * 4 + 2) * LDA + row] = v.z;
+        As[(kq * 4 + 3) * LDA + row] = v.w;
+      } else {
+        *reinterpret_cast<float4*>(As + (a_r + A_RPP * i) * LDA + a_c4 * 4) = v;
       }
-    } else {
-#pragma unroll
-      for (int i = 0; i < PA; ++i)
-        *reinterpret_cast<float4*>(As + (a_r + A_RPP * i) * LDA + a_c4 * 4) = ra[i];
     }
-    if constexpr (B_KCONTIG) {
 #pragma unroll
-      for (int i = 0; i < PB; ++i) {
+    for (int i = 0; i < PB; ++i) {
+      const float4 v = masked(rb[i], bmask, i);
+      if constexpr (B_KCONTIG) {
         const int row = krow + 32 * i;
-        Bs[(kq * 4 + 0) * LDB + row] = rb[i].x;
-        Bs[(kq * 4 + 1) * LDB + row] = rb[i].y;
-        Bs[(kq * 4 + 2) * LDB + row] = rb[i].z;
-        Bs[(kq * 4 + 3) * LDB + row] = rb[i].w;
+        Bs[(kq * 4 + 0) * LDB + row] = v.x;
+        Bs[(kq * 4 + 1) * LDB + row] = v.y;
+        Bs[(kq * 4 + 2) * LDB + row] = v.z;
+        Bs[(kq * 4 + 3) * LDB + row] = v.w;
+      } else {
+        *reinterpret_cast<float4*>(Bs + (b_r + B_RPP * i) * LDB + b_c4 * 4) = v;
       }
-    } else {
-#pragma unroll
-      for (int i = 0; i < PB; ++i)
-        *reinterpret_cast<float4*>(Bs + (b_r + B_RPP * i) * LDB + b_c4 * 4) = rb[i];
     }
   };
 
@@ -364,22 +395,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
 
   for (int t = 0; t < T; ++t) {
     const int cur = t & 1;
-    if (t + 1 < T) load_tile(t + 1);
-    const float* As = smem + cur * (A_SZ + B_SZ);
-    const float* Bs = As + A_SZ;
+    if (t + 1 < T) load_tile(t + 1);   // in flight during the MFMA phase below
+    const float* As = smem + cur * (A_SZ + B_SZ) + wm * WM + l31;
+    const float* Bs = smem + cur * (A_SZ + B_SZ) + A_SZ + wn * WN + l31;
+    // software-pipelined operand fetch: fragments of k-step ks+1 are read while the MFMAs of ks execute
+    float av[2][TM], bv[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) av[0][i] = As[lhi * LDA + i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[0][j] = Bs[lhi * LDB + j * 32];
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
-      const int k = ks * 2 + lhi;
-      float av[TM], bv[TN];
+      const int cb = ks & 1, nb = cb ^ 1;
+      if (ks + 1 < BK / 2) {
+        const int k = (ks + 1) * 2 + lhi;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = As[k * LDA + wm * WM + i * 32 + l31];
+        for (int i = 0; i < TM; ++i) av[nb][i] = As[k * LDA + i * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = Bs[k * LDB + wn * WN + j * 32 + l31];
+        for (int j = 0; j < TN; ++j) bv[nb][j] = Bs[k * LDB + j * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the next fragments' ds_reads ahead of this step's MFMAs
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][i], bv[cb][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (t + 1 < T) store_tile(cur ^ 1);
     __syncthreads();
@@ -466,23 +507,33 @@ constexpr size_t smem_bytes(int mode) {
   return main_loop > epi ? main_loop : epi;
 }
 
-template <int MODE, int BM, int BN>
+template <int MODE, int BM, int BN, bool VEC>
 int launch(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
   static bool attr_set = false;  // benign race: idempotent
   const size_t smem = smem_bytes<BM, BN>(MODE);
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<MODE, BM, BN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<MODE, BM, BN, VEC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN>), grid, dim3(NTHREADS), smem, stream, a);
+  hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, VEC>), grid, dim3(NTHREADS), smem, stream, a);
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }
 
+// float4-addressable operands?  (the !VEC kernels are instantiated for the 64x64 tile only)
+bool vec_ok(const contrad_conv_desc* d, int mode) {
+  const bool c4 = (d->C & 3) == 0 && (d->ldx & 3) == 0;
+  const bool k4 = (d->K & 3) == 0 && (d->ldy & 3) == 0;
+  if (mode == MODE_FWD) return c4 && (d->K & 3) == 0;   // A: x rows; B: packed weight rows (ldw % 4 checked)
+  if (mode == MODE_DGRAD) return k4;                    // A: gy rows; B: packed weight rows along cout
+  return c4 && k4;                                      // WGRAD: x rows and gy rows
+}
+
 // Tile choice: biggest tile that still yields enough blocks to fill 256 CUs x 2 blocks.
-void pick_tile(long long M, int Ncol, int* bm, int* bn) {
+void pick_tile(long long M, int Ncol, bool vec, int* bm, int* bn) {
+  if (!vec) { *bm = 64; *bn = 64; return; }
   *bn = (Ncol > 64) ? 128 : 64;
   const long long tn = (Ncol + *bn - 1) / *bn;
   *bm = 128;
@@ -491,11 +542,12 @@ void pick_tile(long long M, int Ncol, int* bm, int* bn) {
 }
 
 template <int MODE>
-int dispatch(const IgemmArgs& a, int bm, int bn, dim3 grid, hipStream_t s) {
-  if (bm == 128 && bn == 128) return launch<MODE, 128, 128>(a, grid, s);
-  if (bm == 128 && bn == 64) return launch<MODE, 128, 64>(a, grid, s);
-  if (bm == 64 && bn == 128) return launch<MODE, 64, 128>(a, grid, s);
-  return launch<MODE, 64, 64>(a, grid, s);
+int dispatch(const IgemmArgs& a, int bm, int bn, bool vec, dim3 grid, hipStream_t s) {
+  if (!vec) return launch<MODE, 64, 64, false>(a, grid, s);
+  if (bm == 128 && bn == 128) return launch<MODE, 128, 128, true>(a, grid, s);
+  if (bm == 128 && bn == 64) return launch<MODE, 128, 64, true>(a, grid, s);
+  if (bm == 64 && bn == 128) return launch<MODE, 64, 128, true>(a, grid, s);
+  return launch<MODE, 64, 64, true>(a, grid, s);
 }
 
 int check_desc(const contrad_conv_desc* d) {
@@ -517,10 +569,13 @@ int wgrad_plan(const contrad_conv_desc* d, int* bm, int* bn, int* tiles_m, int* 
   const long long P = (long long)d->N * d->Ho * d->Wo;
   *bn = (d->K > 64) ? 128 : 64;
   *bm = (Kg > 64) ? 128 : 64;
+  if (!vec_ok(d, MODE_WGRAD)) { *bm = 64; *bn = 64; }
   *tiles_m = cdiv(Kg, *bm);
   *tiles_n = cdiv(d->K, *bn);
   const long long ptiles = cdivll(P, BK);
-  long long want = cdivll(1024, (long long)(*tiles_m) * (*tiles_n));  // ~4 blocks per CU in total
+  // 2 blocks are resident per CU (LDS): aim at <= 1024 blocks = two full rounds of the 256 CUs, never a ragged
+  // third one (9 x 114 = 1026 blocks cost +30 % on the 3x3 layers before this was a floor)
+  long long want = 1024 / ((long long)(*tiles_m) * (*tiles_n));
   if (want < 1) want = 1;
   long long pps = cdivll(ptiles, want);
   if (pps < 4) pps = 4;  // at least 128 positions per split
@@ -546,9 +601,10 @@ extern "C" int contrad_conv2d_fwd(const contrad_conv_desc* d, const float* x, co
   CONTRAD_ARG(M < (1ll << 31));
   a.M = (int)M; a.Ncol = d->K; a.Kg = d->KH * d->KW * d->C;
   int bm, bn;
-  pick_tile(M, d->K, &bm, &bn);
+  const bool vec = vec_ok(d, MODE_FWD);
+  pick_tile(M, d->K, vec, &bm, &bn);
   a.tiles_m = cdiv(a.M, bm); a.tiles_n = cdiv(a.Ncol, bn);
-  return dispatch<MODE_FWD>(a, bm, bn, dim3(a.tiles_m * a.tiles_n), (hipStream_t)stream);
+  return dispatch<MODE_FWD>(a, bm, bn, vec, dim3(a.tiles_m * a.tiles_n), (hipStream_t)stream);
 }
 
 extern "C" int contrad_conv2d_dgrad(const contrad_conv_desc* d, const float* gy, const float* wp,
@@ -565,9 +621,25 @@ extern "C" int contrad_conv2d_dgrad(const contrad_conv_desc* d, const float* gy,
   const long long Mc = (long long)d->N * cdiv(d->H, s) * cdiv(d->W, s);  // largest class
   CONTRAD_ARG(Mc < (1ll << 31));
   int bm, bn;
-  pick_tile(Mc, d->C, &bm, &bn);
+  const bool vec = vec_ok(d, MODE_DGRAD);
+  pick_tile(Mc, d->C, vec, &bm, &bn);
   a.tiles_m = cdiv((int)Mc, bm); a.tiles_n = cdiv(d->C, bn);
-  return dispatch<MODE_DGRAD>(a, bm, bn, dim3(a.tiles_m * a.tiles_n, s * s), (hipStream_t)stream);
+  return dispatch<MODE_DGRAD>(a, bm, bn, vec, dim3(a.tiles_m * a.tiles_n, s * s), (hipStream_t)stream);
+}
+
+extern "C" int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm, int* bn) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  CONTRAD_ARG(bm && bn && mode >= 0 && mode <= 2);
+  if (mode == MODE_FWD) {
+    pick_tile((long long)d->N * d->Ho * d->Wo, d->K, vec_ok(d, MODE_FWD), bm, bn);
+  } else if (mode == MODE_DGRAD) {
+    pick_tile((long long)d->N * cdiv(d->H, d->stride) * cdiv(d->W, d->stride), d->C, vec_ok(d, MODE_DGRAD), bm, bn);
+  } else {
+    int tm, tn, sp, pps;
+    wgrad_plan(d, bm, bn, &tm, &tn, &sp, &pps);
+  }
+  return 0;
 }
 
 extern "C" long long contrad_conv2d_wgrad_workspace_bytes(const contrad_conv_desc* d) {
@@ -592,7 +664,8 @@ extern "C" int contrad_conv2d_wgrad(const contrad_conv_desc* d, const float* x, 
   const long long P = (long long)d->N * d->Ho * d->Wo;
   CONTRAD_ARG(P < (1ll << 31) - 4096);
   a.P = (int)P; a.ptiles_per_split = pps;
-  rc = dispatch<MODE_WGRAD>(a, bm, bn, dim3(a.tiles_m * a.tiles_n, splits), (hipStream_t)stream);
+  rc = dispatch<MODE_WGRAD>(a, bm, bn, vec_ok(d, MODE_WGRAD), dim3(a.tiles_m * a.tiles_n, splits),
+                            (hipStream_t)stream);
   if (rc) return rc;
   const long long total = (long long)a.M * a.Ncol;
   int blocks = (int)((total + 255) / 256);

@@ -1,0 +1,80 @@
+"""The discriminator step of the reference training loop (train_gan.py:153-163) as a reusable function, plus the
+data-parallel gradient exchange that replaces DistributedDataParallel's reducer (train_gan.py:311-313).
+
+Data parallelism: one process per GPU; each rank owns N_local real images, draws its own fakes and
+augmentation parameters; ONE packed RCCL all-gather of embeddings inside the loss (training/gan/contrad.py), then a
+SUM all-reduce of the parameter gradients whose 1/world_size is folded into the fused Adam kernel's grad_scale.
+The discriminator's backward hands autograd views of two flat buffers (all weight gradients, all bias gradients),
+so the exchange is two large collectives over xGMI instead of DDP's 25 MB buckets.
+"""
+import torch
+import torch.distributed as dist
+
+
+def _dist_on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class GradAllReducer(object):
+    """Sum-all-reduce ``p.grad`` for all params, coalescing gradients that are views of one storage into a single
+    collective over the covering span (the HIP discriminator returns exactly two such storages)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params]
+
+    def spans(self):
+        groups = {}
+        for p in self.params:
+            g = p.grad
+            if g is None:
+                continue
+            if not g.is_contiguous():
+                raise RuntimeError('GradAllReducer needs contiguous gradients')
+            key = g.untyped_storage().data_ptr()
+            lo = g.storage_offset()
+            hi = lo + g.numel()
+            if key in groups:
+                t, a, b = groups[key]
+                groups[key] = (t, min(a, lo), max(b, hi))
+            else:
+                groups[key] = (g, lo, hi)
+        out = []
+        for g, lo, hi in groups.values():
+            out.append(g.as_strided((hi - lo,), (1,), lo))
+        return out
+
+    def __call__(self):
+        if not _dist_on():
+            return 1
+        for flat in self.spans():
+            dist.all_reduce(flat)          # SUM; the mean's 1/W goes into Adam's grad_scale
+        return dist.get_world_size()
+
+
+def sample_generator(G, num_samples, enable_grad=True):
+    """_sample_generator of train_gan.py:96-100."""
+    latent = G.sample_latent(num_samples)
+    with torch.set_grad_enabled(enable_grad):
+        return G(latent)
+
+
+def set_grad(model, flag=True):
+    """utils.set_grad (utils.py:125-127)."""
+    for p in model.parameters():
+        p.requires_grad = flag
+
+
+def d_step(P, G, D, opt_D, options, images, reducer=None):
+    """One discriminator step, exactly train_gan.py:153-163 (minus the four logging .item() syncs): fakes under
+    no_grad -> loss_D_fn -> zero_grad -> backward -> [gradient all-reduce] -> Adam.  Returns (d_loss, aux)."""
+    gen_images = sample_generator(G, images.size(0), enable_grad=False)
+    d_loss, aux = P.train_fn["D"](P, D, options, images, gen_images)
+    loss = d_loss + aux['penalty']
+    opt_D.zero_grad()
+    loss.backward()
+    world = reducer() if reducer is not None else 1
+    if world > 1:
+        opt_D.step(grad_scale=1.0 / world)
+    else:
+        opt_D.step()
+    return d_loss, aux

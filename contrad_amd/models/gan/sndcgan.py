@@ -106,7 +106,9 @@ class _DFunction(torch.autograd.Function):
             x = ops.conv2d_fwd(x, wps[i], biases[i], co, k, k, s, p, _SLOPE, 1.0)
             acts.append(x)
         bias_cat = torch.cat([biases[7], biases[8], biases[9]])
-        hidden = ops.conv2d_fwd(x, merged, bias_cat, 3 * dh, plan.hb, plan.wb, 1, 0, _SLOPE, 1.0)  # (B,1,1,3dh)
+        # first head layers: Linear over the flattened features == 1x1 conv on the (B,1,1,hb*wb*512) NHWC view (the
+        # packed rows (tap*512 + c) are exactly the NHWC-flat feature index)
+        hidden = ops.conv2d_fwd(x.view(B, 1, 1, plan.feat), merged, bias_cat, 3 * dh, 1, 1, 1, 0, _SLOPE, 1.0)
         logits = ops.conv2d_fwd(hidden[..., 0:dh], wps[10], biases[10], 1, 1, 1, 1, 0).view(B, 1)
         proj = ops.conv2d_fwd(hidden[..., dh:2 * dh], wps[11], biases[11], dp, 1, 1, 1, 0).view(B, dp)
         proj2 = ops.conv2d_fwd(hidden[..., 2 * dh:3 * dh], wps[12], biases[12], dp, 1, 1, 1, 0).view(B, dp)
@@ -173,7 +175,7 @@ class _DFunction(torch.autograd.Function):
                 ops.colstats(ops.as_rows(g), out=gbias[li].view(1, -1))
         # ---- heads, first (merged) layer ----
         if need_params:
-            ops.conv2d_wgrad(a6, g_hidden, plan.hb, plan.wb, 1, 0, out=gmerged)
+            ops.conv2d_wgrad(a6.view(B, 1, 1, plan.feat), g_hidden, 1, 1, 1, 0, out=gmerged)
             gb_hidden = ops.colstats(ops.as_rows(g_hidden))
             for j in range(3):
                 gbias[7 + j].copy_(gb_hidden[0, j * dh:(j + 1) * dh])
@@ -181,8 +183,9 @@ class _DFunction(torch.autograd.Function):
         if ctx.trunk_grad:
             lo = dh if ctx.sg_linear else 0
             fused = g_feats is None or g_feats.numel() == 0
-            g = ops.conv2d_dgrad(g_hidden[..., lo:], ctx.merged[:, lo:], tuple(a6.shape), plan.hb, plan.wb, 1, 0,
-                                 act_ref=a6 if fused else None, slope=_SLOPE, gain=1.0)
+            g = ops.conv2d_dgrad(g_hidden[..., lo:], ctx.merged[:, lo:], (B, 1, 1, plan.feat), 1, 1, 1, 0,
+                                 act_ref=a6.view(B, 1, 1, plan.feat) if fused else None, slope=_SLOPE,
+                                 gain=1.0).view(a6.shape)
             if not fused:   # gradient arriving through aux['penultimate'] (not on the hot path)
                 g = g + g_feats.reshape(B, 512, plan.hb, plan.wb).permute(0, 2, 3, 1)
                 g = (g * torch.where(a6 > 0, 1.0, _SLOPE)).contiguous()

@@ -51,6 +51,29 @@ def out_size(h, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1
 
 
+# Optional per-launch profiler (bench.py): when set to a list, every conv-engine launch is bracketed by events on
+# the launch stream and appended as (kernel_name, algorithmic_flops, start_event, end_event).
+PROFILE = None
+_MODE_NAMES = ('FWD', 'DGRAD', 'WGRAD')
+
+
+def _conv_call(mode, d, name, *args):
+    if PROFILE is None:
+        lib().call(name, *args)
+        return
+    bm, bn = ctypes.c_int(0), ctypes.c_int(0)
+    lib().call('contrad_conv2d_tile', ctypes.byref(d), mode, ctypes.byref(bm), ctypes.byref(bn))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st = torch.cuda.current_stream()
+    e0.record(st)
+    lib().call(name, *args)
+    e1.record(st)
+    flops = 2.0 * d.N * d.Ho * d.Wo * d.K * d.C * d.KH * d.KW
+    if mode == 1 and d.stride > 1:
+        pass  # algorithmic dgrad flops == forward flops (only contributing taps are multiplied)
+    PROFILE.append(('igemm_kernel<%s,%d,%d>' % (_MODE_NAMES[mode], bm.value, bn.value), flops, e0, e1))
+
+
 def make_desc(N, H, W, C, K, KH, KW, stride, pad, ldx, ldy, ldw):
     return ConvDesc(N, H, W, C, ldx, out_size(H, KH, stride, pad), out_size(W, KW, stride, pad), K, ldy,
                     KH, KW, stride, pad, ldw)
@@ -82,7 +105,7 @@ def conv2d_fwd(x, wp, bias, K, KH, KW, stride, pad, slope=1.0, gain=1.0, out=Non
         out = torch.empty((N, Ho, Wo, K), device=x.device, dtype=torch.float32)
     _chk(out, 'out')
     d = make_desc(N, H, W, C, K, KH, KW, stride, pad, _ld(x), _ld(out), wp.stride(0))
-    lib().call('contrad_conv2d_fwd', ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(out),
+    _conv_call(0, d, 'contrad_conv2d_fwd', ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(out),
                float(slope), float(gain), _stream())
     return out
 
@@ -100,7 +123,7 @@ def conv2d_dgrad(gy, wp, x_shape, KH, KW, stride, pad, act_ref=None, slope=1.0, 
     d = make_desc(N, H, W, C, K, KH, KW, stride, pad, _ld(out), _ld(gy), wp.stride(0))
     if (d.Ho, d.Wo) != (gy.shape[1], gy.shape[2]):
         raise RuntimeError('contrad_hip: gy spatial size does not match the conv geometry')
-    lib().call('contrad_conv2d_dgrad', ctypes.byref(d), _p(gy), _p(wp), _p(out), _p(act_ref),
+    _conv_call(1, d, 'contrad_conv2d_dgrad', ctypes.byref(d), _p(gy), _p(wp), _p(out), _p(act_ref),
                float(slope), float(gain), _stream())
     return out
 
@@ -132,7 +155,7 @@ def conv2d_wgrad(x, gy, KH, KW, stride, pad, ldw=None, out=None):
     if nbytes < 0:
         raise RuntimeError('contrad_hip: bad conv descriptor (%d)' % nbytes)
     ws = _workspace(nbytes, x.device)
-    lib().call('contrad_conv2d_wgrad', ctypes.byref(d), _p(x), _p(gy), _p(out), _p(ws),
+    _conv_call(2, d, 'contrad_conv2d_wgrad', ctypes.byref(d), _p(x), _p(gy), _p(out), _p(ws),
                ctypes.c_longlong(ws.numel() * 4), _stream())
     return out
 
