@@ -1,0 +1,64 @@
+"""World-size-2 gloo tests (CPU) of the data-parallel host logic: rank-ordered packed all-gather + regrouping of
+the embedding rows, GatherLayer's local-slice backward, the coalescing gradient all-reducer.  The contrastive
+kernel itself cannot run on CPU; the oracle's loss stands in for it here as the checker of the ORDERING only."""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import contrad_oracle as O
+
+
+def _worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from contrad_amd.third_party.gather_layer import GatherLayer, all_gather_rows
+    from contrad_amd.training.gan.contrad import _regroup
+    from contrad_amd.engine import GradAllReducer
+    n, D = 3, 8
+    g = torch.Generator().manual_seed(100)
+    full1 = torch.nn.functional.normalize(torch.randn(world, 2 * n, D, generator=g), dim=2)   # [rank][v1;v2]
+    full2 = torch.nn.functional.normalize(torch.randn(world, 3 * n, D, generator=g), dim=2)
+    z1, z2 = full1[rank], full2[rank]
+    packed = torch.cat([z1, z2], 0)
+    gathered = all_gather_rows(packed)
+    z1g = _regroup(gathered[:, :2 * n], 2, n)
+    z2g = _regroup(gathered[:, 2 * n:], 3, n)
+    # reference ordering: cat over ranks of each block (criterion.py:30-32, contrad.py:9-12)
+    exp1 = torch.cat([torch.cat([full1[r, :n] for r in range(world)]), torch.cat([full1[r, n:] for r in range(world)])])
+    exp2 = torch.cat([torch.cat([full2[r, i * n:(i + 1) * n] for r in range(world)]) for i in range(3)])
+    ok = torch.equal(z1g, exp1) and torch.equal(z2g, exp2)
+    # global loss == single-process loss on the concatenated batch
+    N = n * world
+    l = O.nt_xent(z1g[:N], z1g[N:], 0.1) + O.supcon_fake(z2g[:N], z2g[N:2 * N], z2g[2 * N:], 0.1)
+    l_ref = O.nt_xent(exp1[:N], exp1[N:], 0.1) + O.supcon_fake(exp2[:N], exp2[N:2 * N], exp2[2 * N:], 0.1)
+    ok = ok and abs(l.item() - l_ref.item()) < 1e-6
+    # GatherLayer: forward order, backward = own slice
+    x = z1[:n].clone().requires_grad_()
+    outs = GatherLayer.apply(x)
+    cat = torch.cat(outs, 0)
+    w = torch.arange(cat.numel(), dtype=torch.float32).view_as(cat)
+    (cat * w).sum().backward()
+    ok = ok and torch.equal(cat.detach(), torch.cat([full1[r, :n] for r in range(world)]))
+    ok = ok and torch.equal(x.grad, w[rank * n:(rank + 1) * n])
+    # gradient all-reducer: grads that are views of one flat buffer -> one collective over the span
+    flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
+    p1, p2 = torch.nn.Parameter(torch.zeros(2, 2)), torch.nn.Parameter(torch.zeros(4))
+    p1.grad, p2.grad = flat[0:4].view(2, 2), flat[6:10]
+    red = GradAllReducer([p1, p2])
+    spans = red.spans()
+    ok = ok and len(spans) == 1 and spans[0].numel() == 10
+    wsize = red()
+    ok = ok and wsize == world and torch.equal(p2.grad, torch.arange(6, 10, dtype=torch.float32) * 3)
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, 29511, ret), nprocs=world, join=True)
+    assert all(ret.get(r, False) for r in range(world)), dict(ret)
