@@ -1,0 +1,361 @@
+"""Op-level autograd nodes over the HIP library that are differentiable to ANY order: the backward of every node
+is built only from other nodes of this file, exactly the scheme the reference uses for its native upfirdn2d op
+(models/gan/stylegan2/op/upfirdn2d.py:19-142) -- needed because the R1 penalty (train_stylegan2.py:106-113)
+differentiates ``||dD/dx||^2``, i.e. runs a backward through the backward.
+
+The convolution family is closed under differentiation (each op is bilinear in its two tensor arguments):
+
+    Conv2dFn(x, wp)      -> y        d/dx: ConvDgradFn(gy, wp)     d/dwp: ConvWgradFn(x, gy)
+    ConvDgradFn(gy, wp)  -> dx       d/dgy: Conv2dFn(h, wp)        d/dwp: ConvWgradFn(h, gy)
+    ConvWgradFn(x, gy)   -> dwp      d/dx: ConvDgradFn(gy, h)      d/dgy: Conv2dFn(x, h)
+
+and so is the RGB family (RgbConvFn / RgbDgradFn / RgbWgradFn).  Activations are NHWC; ``wp`` is the packed GEMM
+weight produced by PackWeightsFn (whose backward is UnpackWeightsFn and vice versa).
+The SNDCGAN discriminator does NOT use these (it is one fused node, models/gan/sndcgan.py); the StyleGAN2
+discriminator does.
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+
+def _cont(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# convolution family.  geom = (K, KH, KW, stride, pad)
+# ----------------------------------------------------------------------------------------------------------
+class Conv2dFn(Function):
+    @staticmethod
+    def forward(ctx, x, wp, geom):
+        K, KH, KW, s, p = geom
+        x = _cont(x)
+        ctx.save_for_backward(x, wp)
+        ctx.geom = geom
+        return ops.conv2d_fwd(x, wp, None, K, KH, KW, s, p)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wp = ctx.saved_tensors
+        gx = ConvDgradFn.apply(gy, wp, tuple(x.shape), ctx.geom) if ctx.needs_input_grad[0] else None
+        gw = ConvWgradFn.apply(x, gy, ctx.geom, tuple(wp.shape)) if ctx.needs_input_grad[1] else None
+        return gx, gw, None
+
+
+class ConvDgradFn(Function):
+    @staticmethod
+    def forward(ctx, gy, wp, x_shape, geom):
+        K, KH, KW, s, p = geom
+        gy = _cont(gy)
+        ctx.save_for_backward(gy, wp)
+        ctx.geom, ctx.x_shape = geom, x_shape
+        return ops.conv2d_dgrad(gy, wp, x_shape, KH, KW, s, p)
+
+    @staticmethod
+    def backward(ctx, h):
+        gy, wp = ctx.saved_tensors
+        g_gy = Conv2dFn.apply(h, wp, ctx.geom) if ctx.needs_input_grad[0] else None
+        g_wp = ConvWgradFn.apply(h, gy, ctx.geom, tuple(wp.shape)) if ctx.needs_input_grad[1] else None
+        return g_gy, g_wp, None, None
+
+
+class ConvWgradFn(Function):
+    @staticmethod
+    def forward(ctx, x, gy, geom, wp_shape):
+        K, KH, KW, s, p = geom
+        x, gy = _cont(x), _cont(gy)
+        ctx.save_for_backward(x, gy)
+        ctx.geom = geom
+        out = torch.zeros(wp_shape, device=x.device, dtype=torch.float32)   # padding columns (ldw > K) stay 0
+        return ops.conv2d_wgrad(x, gy, KH, KW, s, p, out=out)
+
+    @staticmethod
+    def backward(ctx, h):
+        x, gy = ctx.saved_tensors
+        h = _cont(h)
+        g_x = ConvDgradFn.apply(gy, h, tuple(x.shape), ctx.geom) if ctx.needs_input_grad[0] else None
+        g_gy = Conv2dFn.apply(x, h, ctx.geom) if ctx.needs_input_grad[1] else None
+        return g_x, g_gy, None, None
+
+
+class ActBwdFn(Function):
+    """g_pre = g_post * lrelu'(.) * gain, with the linear region read from the activation OUTPUT ``y``
+    (FusedLeakyReLUFunctionBackward, op/fused_act.py:20-55: linear in g, its own backward is the same op)."""
+
+    @staticmethod
+    def forward(ctx, g, y, slope, gain):
+        ctx.save_for_backward(y)
+        ctx.cfg = (slope, gain)
+        return ops.fused_bias_act(_cont(g), None, y, 3, 1, slope, gain)
+
+    @staticmethod
+    def backward(ctx, h):
+        y, = ctx.saved_tensors
+        slope, gain = ctx.cfg
+        return ActBwdFn.apply(h, y, slope, gain), None, None, None
+
+
+class ColSumFn(Function):
+    """Bias gradient: sum over all leading dims of an (..., K) tensor."""
+
+    @staticmethod
+    def forward(ctx, g):
+        g = _cont(g)
+        ctx.shape = tuple(g.shape)
+        return ops.colstats(g.view(-1, g.shape[-1]))[0]
+
+    @staticmethod
+    def backward(ctx, h):
+        return h.view((1,) * (len(ctx.shape) - 1) + (-1,)).expand(ctx.shape)
+
+
+class ConvBiasActFn(Function):
+    """y = gain * lrelu_slope(conv(x, wp) + bias): conv + FusedLeakyReLU (stylegan2/layers.py:174-198,
+    op/fused_act.py:74-92) / nn.Linear + LeakyReLU in ONE kernel (bias + activation in the GEMM epilogue)."""
+
+    @staticmethod
+    def forward(ctx, x, wp, bias, geom, slope, gain):
+        K, KH, KW, s, p = geom
+        x = _cont(x)
+        y = ops.conv2d_fwd(x, wp, bias, K, KH, KW, s, p, slope, gain)
+        ctx.save_for_backward(x, wp, y)
+        ctx.cfg = (geom, slope, gain)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wp, y = ctx.saved_tensors
+        geom, slope, gain = ctx.cfg
+        g_pre = gy if (slope == 1.0 and gain == 1.0) else ActBwdFn.apply(gy, y, slope, gain)
+        gx = ConvDgradFn.apply(g_pre, wp, tuple(x.shape), geom) if ctx.needs_input_grad[0] else None
+        gw = ConvWgradFn.apply(x, g_pre, geom, tuple(wp.shape)) if ctx.needs_input_grad[1] else None
+        gb = ColSumFn.apply(g_pre) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------------------
+# RGB family (image NCHW (N,3,H,W) <-> activation NHWC (N,H,W,K)); rgb = (k, in_scale, in_shift)
+# ----------------------------------------------------------------------------------------------------------
+class RgbConvFn(Function):
+    @staticmethod
+    def forward(ctx, img, wp, K, rgb):
+        k, a, b = rgb
+        img = _cont(img)
+        ctx.save_for_backward(img, wp)
+        ctx.cfg = (K, rgb)
+        return ops.rgb_conv_fwd(img, wp, None, K, k, a, b, 1.0, 1.0)
+
+    @staticmethod
+    def backward(ctx, gy):
+        img, wp = ctx.saved_tensors
+        K, (k, a, b) = ctx.cfg
+        g_img = RgbDgradFn.apply(gy, wp, img.shape[1], (k, a)) if ctx.needs_input_grad[0] else None
+        g_wp = RgbWgradFn.apply(img, gy, (k, a, b), tuple(wp.shape)) if ctx.needs_input_grad[1] else None
+        return g_img, g_wp, None, None
+
+
+class RgbDgradFn(Function):
+    """d_img[n,c,h,w] = scale * sum_{taps,k} g[n,h+p-kh,w+p-kw,k] wp[(tap,c),k]."""
+
+    @staticmethod
+    def forward(ctx, g, wp, C, ks):
+        k, scale = ks
+        g = _cont(g)
+        ctx.save_for_backward(g, wp)
+        ctx.cfg = (C, ks)
+        return ops.rgb_conv_dgrad(g, wp, None, C, k, act=0, out_scale=scale)
+
+    @staticmethod
+    def backward(ctx, h):
+        g, wp = ctx.saved_tensors
+        C, (k, scale) = ctx.cfg
+        K = g.shape[3]
+        g_g = RgbConvFn.apply(h, wp, K, (k, scale, 0.0)) if ctx.needs_input_grad[0] else None
+        g_wp = RgbWgradFn.apply(h, g, (k, scale, 0.0), tuple(wp.shape)) if ctx.needs_input_grad[1] else None
+        return g_g, g_wp, None, None
+
+
+class RgbWgradFn(Function):
+    @staticmethod
+    def forward(ctx, img, g, rgb, wp_shape):
+        k, a, b = rgb
+        img, g = _cont(img), _cont(g)
+        ctx.save_for_backward(img, g)
+        ctx.cfg = rgb
+        out = torch.zeros(wp_shape, device=img.device, dtype=torch.float32)
+        return ops.rgb_conv_wgrad(img, g, k, a, b, out)
+
+    @staticmethod
+    def backward(ctx, h):
+        img, g = ctx.saved_tensors
+        k, a, b = ctx.cfg
+        h = _cont(h)
+        g_img = RgbDgradFn.apply(g, h, img.shape[1], (k, a)) if ctx.needs_input_grad[0] else None
+        g_g = RgbConvFn.apply(img, h, g.shape[3], (k, a, b)) if ctx.needs_input_grad[1] else None
+        return g_img, g_g, None, None
+
+
+class RgbConvBiasActFn(Function):
+    """FromRGB / first conv with the input rescale, bias and activation fused (one read of the image)."""
+
+    @staticmethod
+    def forward(ctx, img, wp, bias, K, rgb, slope, gain):
+        k, a, b = rgb
+        img = _cont(img)
+        y = ops.rgb_conv_fwd(img, wp, bias, K, k, a, b, slope, gain)
+        ctx.save_for_backward(img, wp, y)
+        ctx.cfg = (K, rgb, slope, gain)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        img, wp, y = ctx.saved_tensors
+        K, (k, a, b), slope, gain = ctx.cfg
+        g_pre = ActBwdFn.apply(gy, y, slope, gain)
+        g_img = RgbDgradFn.apply(g_pre, wp, img.shape[1], (k, a)) if ctx.needs_input_grad[0] else None
+        g_wp = RgbWgradFn.apply(img, g_pre, (k, a, b), tuple(wp.shape)) if ctx.needs_input_grad[1] else None
+        g_b = ColSumFn.apply(g_pre) if ctx.needs_input_grad[2] else None
+        return g_img, g_wp, g_b, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------------------
+# upfirdn2d (Blur / Upsample / Downsample), NHWC
+# ----------------------------------------------------------------------------------------------------------
+class UpFirDn2dFn(Function):
+    """UpFirDn2d (op/upfirdn2d.py:88-142) with pad = (x0, x1, y0, y1)."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, up, down, pad):
+        x = _cont(x)
+        kh, kw = kernel.shape
+        B, H, W, C = x.shape
+        out = ops.upfirdn2d(x, kernel, up, down, pad)
+        oh, ow = out.shape[1], out.shape[2]
+        px0, px1, py0, py1 = pad
+        g_pad = (kw - px0 - 1, W * up - ow * down + px0 - up + 1,
+                 kh - py0 - 1, H * up - oh * down + py0 - up + 1)
+        ctx.save_for_backward(kernel)
+        ctx.cfg = (up, down, pad, g_pad, (H, W), (oh, ow))
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        kernel, = ctx.saved_tensors
+        up, down, pad, g_pad, in_hw, out_hw = ctx.cfg
+        return UpFirDn2dBackwardFn.apply(gy, kernel, up, down, pad, g_pad, in_hw), None, None, None, None
+
+
+class UpFirDn2dBackwardFn(Function):
+    """UpFirDn2dBackward (op/upfirdn2d.py:19-85): upfirdn with the flipped kernel and up/down swapped; its own
+    backward is the forward op again."""
+
+    @staticmethod
+    def forward(ctx, gy, kernel, up, down, pad, g_pad, in_hw):
+        gk = torch.flip(kernel, [0, 1]).contiguous()
+        gx = ops.upfirdn2d(_cont(gy), gk, down, up, g_pad)
+        assert (gx.shape[1], gx.shape[2]) == tuple(in_hw), (gx.shape, in_hw)
+        ctx.save_for_backward(kernel)
+        ctx.cfg = (up, down, pad)
+        return gx
+
+    @staticmethod
+    def backward(ctx, h):
+        kernel, = ctx.saved_tensors
+        up, down, pad = ctx.cfg
+        return UpFirDn2dFn.apply(h, kernel, up, down, pad), None, None, None, None, None, None
+
+
+class LinCombFn(Function):
+    """y = a*x + b*z  (ResBlock merge, discriminator.py:72-74)."""
+
+    @staticmethod
+    def forward(ctx, x, z, a, b):
+        ctx.cfg = (a, b)
+        return ops.lincomb(_cont(x), _cont(z), a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.cfg
+        return g * a, g * b, None, None
+
+
+# ----------------------------------------------------------------------------------------------------------
+# weight packing (fixed runtime scale): OIHW parameters -> packed GEMM layout, batched over layers
+# ----------------------------------------------------------------------------------------------------------
+class PackMeta(object):
+    """entries: list of (K, C, T, scale, group, col_off); groups: list of (rows, cols)."""
+
+    def __init__(self, entries, groups):
+        self.entries, self.groups = entries, groups
+
+
+def _specs_from(meta, ws):
+    return [ops.SnSpec(w, fixed_scale=e[3], view_kct=(e[0], e[1], e[2])) for e, w in zip(meta.entries, ws)]
+
+
+class PackWeightsFn(Function):
+    """(w_0 .. w_{n-1}) -> one packed tensor per group; wp = w * scale in layout [(tap*C + c)][K] at the group's
+    column offset (EqualConv2d / EqualLinear runtime scale folded in, stylegan2/layers.py:104,117,141)."""
+
+    @staticmethod
+    def forward(ctx, meta, *ws):
+        dev = ws[0].device
+        ws = [_cont(w) for w in ws]
+        outs = [torch.zeros(r, c, device=dev, dtype=torch.float32) for (r, c) in meta.groups]
+        specs = _specs_from(meta, ws)
+        wps = [outs[e[4]][:, e[5]:e[5] + e[0]] for e in meta.entries]
+        ldws = [meta.groups[e[4]][1] for e in meta.entries]
+        offs, n = ops.sn_scratch_floats(specs)
+        scratch = torch.empty(n, device=dev, dtype=torch.float32)
+        sigma = torch.empty(len(specs), device=dev, dtype=torch.float32)
+        ops.sn_weight_prep(specs, wps, ldws, False, scratch, offs, sigma)
+        ctx.meta = meta
+        ctx.shapes = [tuple(w.shape) for w in ws]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        meta = ctx.meta
+        gouts = [g if g is not None else None for g in gouts]
+        gws = UnpackWeightsFn.apply(meta, ctx.shapes, *gouts)
+        return (None,) + tuple(gws)
+
+
+class UnpackWeightsFn(Function):
+    """Packed gradients (one per group) -> OIHW gradients * scale.  Inverse-layout twin of PackWeightsFn."""
+
+    @staticmethod
+    def forward(ctx, meta, shapes, *gouts):
+        dev = next(g for g in gouts if g is not None).device
+        gouts = [(_cont(g) if g is not None else torch.zeros(meta.groups[i], device=dev)) for i, g in enumerate(gouts)]
+        gws = [torch.empty(s, device=dev, dtype=torch.float32) for s in shapes]
+        specs = _specs_from(meta, gws)           # .w is only a non-null placeholder on the fixed-scale path
+        gwps = [gouts[e[4]][:, e[5]:e[5] + e[0]] for e in meta.entries]
+        ldws = [meta.groups[e[4]][1] for e in meta.entries]
+        offs, n = ops.sn_scratch_floats(specs)
+        scratch = torch.empty(n, device=dev, dtype=torch.float32)
+        sigma = torch.tensor([1.0 / e[3] for e in meta.entries], device=dev, dtype=torch.float32)
+        ops.sn_weight_grad(specs, gwps, ldws, gwps, gws, scratch, offs, sigma)
+        ctx.meta, ctx.shapes = meta, shapes
+        return tuple(gws)
+
+    @staticmethod
+    def backward(ctx, *hs):
+        dev = next(h for h in hs if h is not None).device
+        hs = [h if h is not None else torch.zeros(s, device=dev) for h, s in zip(hs, ctx.shapes)]
+        outs = PackWeightsFn.apply(ctx.meta, *hs)
+        return (None, None) + tuple(outs)
+
+
+def make_blur_kernel(k=(1, 3, 3, 1)):
+    """make_kernel (stylegan2/layers.py:24-32)."""
+    k = torch.tensor(k, dtype=torch.float32)
+    k = k[None, :] * k[:, None]
+    return k / k.sum()
+
+
+SQRT2 = math.sqrt(2.0)

@@ -1,0 +1,160 @@
+// HIP counterparts of the reference's two native CUDA ops (models/gan/stylegan2/op/):
+//
+//   contrad_upfirdn2d      <-> upfirdn2d_op.upfirdn2d   (op/upfirdn2d.cpp:12-23, op/upfirdn2d_kernel.cu:49-369)
+//   contrad_fused_bias_act <-> fused.fused_bias_act     (op/fused_bias_act.cpp:11-21, op/fused_bias_act_kernel.cu:18-98)
+//
+// Same tensor contract as the reference: input [major, in_h, in_w, minor], FIR kernel [kh, kw], zero-insertion
+// upsampling by (up_x, up_y), padding (may be negative), correlation with the FLIPPED kernel, decimation by
+// (down_x, down_y).  The reference reshapes NCHW to (major = B*C, minor = 1); this build keeps activations NHWC
+// and calls it with (major = B, minor = C), which makes the innermost dimension contiguous and float4-wide --
+// the op is HBM-bound (a 4x4 FIR: 32 FLOP per 8 B), so the design goal is one coalesced read (taps served from
+// L1/L2) and one coalesced write, not the reference's shared-memory tiling per (B*C) plane.
+#include "common.h"
+#include "../../include/contrad_hip.h"
+
+namespace {
+
+struct UpfirdnArgs {
+  const float* in;
+  const float* kernel;
+  float* out;
+  int major, in_h, in_w, minor;
+  int kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0;
+  int out_h, out_w;
+};
+
+constexpr int MAX_FIR = 8;
+
+template <int VW>  // vector width over `minor`: 4 (float4) or 1
+__global__ __launch_bounds__(256) void upfirdn2d_kernel(UpfirdnArgs a) {
+  __shared__ float fir[MAX_FIR * MAX_FIR];  // flipped
+  for (int e = threadIdx.x; e < a.kh * a.kw; e += blockDim.x) {
+    const int ky = e / a.kw, kx = e - ky * a.kw;
+    fir[e] = a.kernel[(a.kh - 1 - ky) * a.kw + (a.kw - 1 - kx)];
+  }
+  __syncthreads();
+  const int mv = a.minor / VW;
+  const long long total = (long long)a.major * a.out_h * a.out_w * mv;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % mv) * VW;
+    long long t = e / mv;
+    const int ox = (int)(t % a.out_w);
+    t /= a.out_w;
+    const int oy = (int)(t % a.out_h);
+    const int m = (int)(t / a.out_h);
+    float acc[VW];
+#pragma unroll
+    for (int v = 0; v < VW; ++v) acc[v] = 0.f;
+    for (int ky = 0; ky < a.kh; ++ky) {
+      const int py = oy * a.down_y + ky - a.pad_y0;     // coordinate in the zero-inserted image
+      if (py < 0 || py % a.up_y != 0) continue;
+      const int iy = py / a.up_y;
+      if (iy >= a.in_h) continue;
+      for (int kx = 0; kx < a.kw; ++kx) {
+        const int px = ox * a.down_x + kx - a.pad_x0;
+        if (px < 0 || px % a.up_x != 0) continue;
+        const int ix = px / a.up_x;
+        if (ix >= a.in_w) continue;
+        const float w = fir[ky * a.kw + kx];
+        const float* src = a.in + (((size_t)m * a.in_h + iy) * a.in_w + ix) * a.minor + c;
+        if (VW == 4) {
+          const float4 x = *reinterpret_cast<const float4*>(src);
+          acc[0] = fmaf(w, x.x, acc[0]); acc[1 % VW] = fmaf(w, x.y, acc[1 % VW]);
+          acc[2 % VW] = fmaf(w, x.z, acc[2 % VW]); acc[3 % VW] = fmaf(w, x.w, acc[3 % VW]);
+        } else {
+          acc[0] = fmaf(w, src[0], acc[0]);
+        }
+      }
+    }
+    float* dst = a.out + (((size_t)m * a.out_h + oy) * a.out_w + ox) * a.minor + c;
+    if (VW == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1 % VW], acc[2 % VW], acc[3 % VW]);
+    else dst[0] = acc[0];
+  }
+}
+
+// y = act(x + b[(i / step_b) % size_b]) * scale  (grad 0) | x * act'(ref) * scale (grad 1) | 0 (grad 2)
+// act 1: linear, act 3: leaky relu with slope alpha  -- the reference's act*10+grad switch
+__global__ void fused_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ b,
+                                      const float* __restrict__ ref, float* __restrict__ y, long long n, int step_b,
+                                      int size_b, int act, int grad, float alpha, float scale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float v = x[i];
+    if (b) v += b[(i / step_b) % size_b];
+    const float r = ref ? ref[i] : 0.f;
+    float o;
+    if (act == 1) {
+      o = (grad == 2) ? 0.f : v * scale;
+    } else {
+      if (grad == 0) o = (v > 0.f ? v : v * alpha) * scale;
+      else if (grad == 1) o = (r > 0.f ? v : v * alpha) * scale;
+      else o = 0.f;
+    }
+    y[i] = o;
+  }
+}
+
+// y = a * x + b * z (elementwise; residual merge (out + skip) / sqrt(2), discriminator.py:72-74)
+__global__ void lincomb_kernel(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ y,
+                               long long n, float a, float bc) {
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 u = reinterpret_cast<const float4*>(x)[i], v = reinterpret_cast<const float4*>(z)[i];
+    reinterpret_cast<float4*>(y)[i] = make_float4(a * u.x + bc * v.x, a * u.y + bc * v.y, a * u.z + bc * v.z,
+                                                  a * u.w + bc * v.w);
+  }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    y[i] = a * x[i] + bc * z[i];
+}
+
+}  // namespace
+
+extern "C" int contrad_upfirdn2d(const float* input, const float* kernel, float* out, int major, int in_h,
+                                 int in_w, int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                                 int pad_x0, int pad_x1, int pad_y0, int pad_y1, contrad_stream_t stream) {
+  CONTRAD_ARG(input && kernel && out && major > 0 && in_h > 0 && in_w > 0 && minor > 0);
+  CONTRAD_ARG(kh > 0 && kw > 0 && kh <= MAX_FIR && kw <= MAX_FIR);
+  CONTRAD_ARG(up_x > 0 && up_y > 0 && down_x > 0 && down_y > 0);
+  UpfirdnArgs a{};
+  a.in = input; a.kernel = kernel; a.out = out;
+  a.major = major; a.in_h = in_h; a.in_w = in_w; a.minor = minor;
+  a.kh = kh; a.kw = kw; a.up_x = up_x; a.up_y = up_y; a.down_x = down_x; a.down_y = down_y;
+  a.pad_x0 = pad_x0; a.pad_y0 = pad_y0;
+  a.out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) / down_y + 1;   // op/upfirdn2d_kernel.cu:227-228
+  a.out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
+  CONTRAD_ARG(a.out_h > 0 && a.out_w > 0);
+  const bool vec = (minor & 3) == 0;
+  const long long total = (long long)major * a.out_h * a.out_w * (vec ? minor / 4 : minor);
+  long long grid = (total + 255) / 256;
+  if (grid > 16384) grid = 16384;
+  if (vec) hipLaunchKernelGGL(upfirdn2d_kernel<4>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(upfirdn2d_kernel<1>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int contrad_fused_bias_act(const float* x, const float* bias, const float* ref, float* y, long long n,
+                                      int step_b, int size_b, int act, int grad, float alpha, float scale,
+                                      contrad_stream_t stream) {
+  CONTRAD_ARG(x && y && n > 0 && (act == 1 || act == 3) && grad >= 0 && grad <= 2);
+  CONTRAD_ARG(!bias || (step_b > 0 && size_b > 0));
+  CONTRAD_ARG(grad != 1 || act == 1 || ref);
+  long long grid = (n + 255) / 256;
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(fused_bias_act_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, x, bias, ref, y, n,
+                     step_b, size_b, act, grad, alpha, scale);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int contrad_lincomb(const float* x, const float* z, float* y, long long n, float a, float b,
+                               contrad_stream_t stream) {
+  CONTRAD_ARG(x && z && y && n > 0);
+  long long grid = (n / 4 + 255) / 256 + 1;
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(lincomb_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, x, z, y, n, a, b);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}

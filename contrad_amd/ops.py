@@ -416,3 +416,42 @@ def gaussian_blur_masked(x, params, kernel1d, radius, out=None):
     lib().call('contrad_gaussian_blur_masked', _p(x), _p(tmp), _p(out), _p(params), _p(kernel1d), B, H, W,
                int(radius), _stream())
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# the reference's native StyleGAN2 ops
+# --------------------------------------------------------------------------------------------------
+def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0, 0, 0)):
+    """x NHWC (B,H,W,C) contiguous, kernel (kh,kw); pad = (x0, x1, y0, y1).  Returns NHWC."""
+    _chk(x, 'x'); _chk(kernel, 'kernel')
+    if not x.is_contiguous() or not kernel.is_contiguous():
+        raise RuntimeError('contrad_hip: upfirdn2d needs contiguous tensors')
+    B, H, W, C = x.shape
+    kh, kw = kernel.shape
+    px0, px1, py0, py1 = pad
+    oh = (H * up + py0 + py1 - kh) // down + 1
+    ow = (W * up + px0 + px1 - kw) // down + 1
+    out = torch.empty((B, oh, ow, C), device=x.device, dtype=torch.float32)
+    lib().call('contrad_upfirdn2d', _p(x), _p(kernel), _p(out), B, H, W, C, kh, kw, up, up, down, down,
+               px0, px1, py0, py1, _stream())
+    return out
+
+
+def fused_bias_act(x, bias, ref, act, grad, alpha, scale, channels_last_size=None):
+    """Elementwise on a contiguous tensor whose LAST dim is the channel (NHWC / (M,K))."""
+    _chk(x, 'x'); _chk(bias, 'bias'); _chk(ref, 'ref')
+    if not x.is_contiguous() or (ref is not None and not ref.is_contiguous()):
+        raise RuntimeError('contrad_hip: fused_bias_act needs contiguous tensors')
+    y = torch.empty_like(x)
+    C = x.shape[-1]
+    lib().call('contrad_fused_bias_act', _p(x), _p(bias), _p(ref), _p(y), ctypes.c_longlong(x.numel()), 1, C,
+               int(act), int(grad), float(alpha), float(scale), _stream())
+    return y
+
+
+def lincomb(x, z, a, b):
+    if not (x.is_contiguous() and z.is_contiguous()) or x.shape != z.shape:
+        raise RuntimeError('contrad_hip: lincomb needs equal-shape contiguous tensors')
+    y = torch.empty_like(x)
+    lib().call('contrad_lincomb', _p(x), _p(z), _p(y), ctypes.c_longlong(x.numel()), float(a), float(b), _stream())
+    return y

@@ -206,6 +206,27 @@ int contrad_gaussian_blur_masked(const float* x, float* tmp, float* y, const flo
                                  const float* kernel1d, int B, int H, int W, int radius,
                                  contrad_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * The reference's two native ops (models/gan/stylegan2/op/), same tensor contracts.
+ * ---------------------------------------------------------------------------------------------- */
+/* upfirdn2d_op.upfirdn2d (op/upfirdn2d.cpp:12-23): input [major,in_h,in_w,minor] -> out [major,out_h,out_w,minor],
+ * out_h = (in_h*up_y + pad_y0 + pad_y1 - kh)/down_y + 1 (likewise w); zero-insertion upsampling, padding (may be
+ * negative), correlation with the flipped FIR kernel [kh,kw], decimation.  The NHWC build passes major = B,
+ * minor = C.  Blur / Upsample / Downsample of stylegan2/layers.py:34-92 and their backward / double backward
+ * (op/upfirdn2d.py:19-142) are all instances of this one call. */
+int contrad_upfirdn2d(const float* input, const float* kernel, float* out, int major, int in_h, int in_w,
+                      int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
+                      int pad_x1, int pad_y0, int pad_y1, contrad_stream_t stream);
+/* fused.fused_bias_act (op/fused_bias_act.cpp:11-21): act 1 linear / 3 leaky-relu(alpha); grad 0: y = act(x +
+ * bias[(i/step_b) % size_b]) * scale; grad 1: y = x * act'(ref) * scale; grad 2: y = 0.  bias / ref may be NULL
+ * where unused.  (FusedLeakyReLU and its first / second backward, op/fused_act.py:20-71.) */
+int contrad_fused_bias_act(const float* x, const float* bias, const float* ref, float* y, long long n,
+                           int step_b, int size_b, int act, int grad, float alpha, float scale,
+                           contrad_stream_t stream);
+/* y = a*x + b*z  (ResBlock merge (out + skip)/sqrt(2), stylegan2/discriminator.py:72-74) */
+int contrad_lincomb(const float* x, const float* z, float* y, long long n, float a, float b,
+                    contrad_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,167 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle for the StyleGAN2 part of the ContraD hot path
+(SURVEY.md 8a rows D4, D5, R1, G0): plain PyTorch-CPU restatement of models/gan/stylegan2/{layers,
+discriminator,generator}.py and op/{upfirdn2d,fused_act}.py, functional over a state dict with the reference's
+key names.  Pinned by tests/golden/make_golden.py against the imported reference (CPU path: upfirdn2d_native,
+pure-torch fused_leaky_relu); see oracle/contrad_oracle.py for the conventions.  Never imported by the product.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .contrad_oracle import _lrelu
+
+
+def make_kernel(k=(1, 3, 3, 1)):
+    """stylegan2/layers.py:24-32."""
+    k = torch.tensor(k, dtype=torch.float32)
+    if k.ndim == 1:
+        k = k[None, :] * k[:, None]
+    return k / k.sum()
+
+
+def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
+    """upfirdn2d_native (op/upfirdn2d.py:159-200) on NCHW: zero-insert, pad (may be negative), correlate with the
+    flipped kernel, decimate.  pad = (pad0, pad1) applied to both axes like the reference wrapper (:144-156)."""
+    B, C, H, W = x.shape
+    kh, kw = kernel.shape
+    p0, p1 = pad
+    out = x.reshape(B * C, H, 1, W, 1)
+    out = F.pad(out, [0, up - 1, 0, 0, 0, up - 1])
+    out = out.reshape(B * C, 1, H * up, W * up)
+    out = F.pad(out, [max(p0, 0), max(p1, 0), max(p0, 0), max(p1, 0)])
+    out = out[:, :, max(-p0, 0): out.shape[2] - max(-p1, 0), max(-p0, 0): out.shape[3] - max(-p1, 0)]
+    out = F.conv2d(out, torch.flip(kernel, [0, 1]).view(1, 1, kh, kw))
+    out = out[:, :, ::down, ::down]
+    return out.reshape(B, C, out.shape[2], out.shape[3])
+
+
+def fused_leaky_relu(x, bias, slope=0.2, scale=2 ** 0.5, mask=None):
+    """op/fused_act.py:86-94 (the live pure-torch branch)."""
+    rest = [1] * (x.ndim - 2)
+    return _lrelu(x + bias.view(1, -1, *rest), slope, mask) * scale
+
+
+def equal_conv(x, w, stride=1, padding=0):
+    """EqualConv2d.forward (layers.py:114-123): weight * 1/sqrt(fan_in) at run time, no bias here."""
+    scale = 1 / math.sqrt(w.shape[1] * w.shape[2] * w.shape[3])
+    return F.conv2d(x, w * scale, None, stride=stride, padding=padding)
+
+
+def minibatch_stddev(x, group=4):
+    """_minibatch_stddev_layer (discriminator.py:22-33)."""
+    B, C, H, W = x.shape
+    g = min(B, group)
+    s = x.view(g, -1, 1, C, H, W)
+    s = torch.sqrt(s.var(0, unbiased=False) + 1e-8)
+    s = s.mean([2, 3, 4], keepdim=True).mean(2)
+    s = s.repeat(g, 1, H, W)
+    return torch.cat([x, s], 1)
+
+
+def d_channels(size, small32, channel_multiplier=2):
+    if small32:
+        return {4: 512, 8: 512, 16: 256, 32: 128}
+    return {4: 512, 8: 512, 16: 512, 32: 512, 64: int(256 * channel_multiplier), 128: int(128 * channel_multiplier),
+            256: int(64 * channel_multiplier), 512: int(32 * channel_multiplier), 1024: int(16 * channel_multiplier)}
+
+
+def d_param_shapes(size, small32, channel_multiplier=2, d_hidden=512, d_project=128):
+    """State-dict names/shapes of ResidualDiscriminatorP (discriminator.py:191-235, base.py:79-101)."""
+    ch = d_channels(size, small32, channel_multiplier)
+    feat = ch[4] * 16
+    s = {}
+    for pre, (o, i) in (('linear.l1', (d_hidden, feat)), ('linear.l2', (1, d_hidden)),
+                        ('projection.0', (d_hidden, feat)), ('projection.2', (d_project, d_hidden)),
+                        ('projection2.0', (d_hidden, feat)), ('projection2.2', (d_project, d_hidden))):
+        s[pre + '.weight'] = (o, i)
+        s[pre + '.bias'] = (o,)
+    s['layers.0.0.weight'] = (ch[size], 3, 1, 1)
+    s['layers.0.1.bias'] = (ch[size],)
+    cin = ch[size]
+    k = 1
+    for i in range(int(math.log2(size)), 2, -1):
+        cout = ch[2 ** (i - 1)]
+        p = 'layers.%d.' % k
+        s[p + 'conv1.0.weight'] = (cin, cin, 3, 3)
+        s[p + 'conv1.1.bias'] = (cin,)
+        s[p + 'conv2.0.kernel'] = (4, 4)
+        s[p + 'conv2.1.weight'] = (cout, cin, 3, 3)
+        s[p + 'conv2.2.bias'] = (cout,)
+        s[p + 'skip.0.kernel'] = (4, 4)
+        s[p + 'skip.1.weight'] = (cout, cin, 1, 1)
+        cin = cout
+        k += 1
+    s['last_conv.0.weight'] = (ch[4], cin + 1, 3, 3)
+    s['last_conv.1.bias'] = (ch[4],)
+    return s
+
+
+def det_fill_d(shapes, seed=2024):
+    """Deterministic fill: weights N(0,1) (EqualConv init), head weights N(0, 0.02), biases N(0, 0.1), blur kernels
+    exact."""
+    sd = {}
+    for i, (name, shape) in enumerate(shapes.items()):
+        g = torch.Generator().manual_seed(seed + i)
+        if name.endswith('kernel'):
+            sd[name] = make_kernel()
+            continue
+        t = torch.randn(*shape, generator=g)
+        if name.endswith('bias'):
+            t = t * 0.1
+        elif name.startswith(('linear', 'projection')):
+            t = t * 0.02
+        sd[name] = t
+    return sd
+
+
+def d_features(sd, x, size, masks=None):
+    """ResidualDiscriminatorP.penultimate (discriminator.py:225-235) with ResBlock (:60-76) and ConvLayer
+    (layers.py:174-198).  ``masks``: optional list of leaky-relu linear-region masks in execution order."""
+    mi = [0]
+
+    def act(y, bias):
+        m = None
+        if masks is not None:
+            m = masks[mi[0]]
+            mi[0] += 1
+        return fused_leaky_relu(y, bias, mask=m)
+
+    h = x * 2. - 1.
+    h = act(equal_conv(h, sd['layers.0.0.weight']), sd['layers.0.1.bias'])
+    k = 1
+    for _ in range(int(math.log2(size)), 2, -1):
+        p = 'layers.%d.' % k
+        o = act(equal_conv(h, sd[p + 'conv1.0.weight'], padding=1), sd[p + 'conv1.1.bias'])
+        o = upfirdn2d(o, sd[p + 'conv2.0.kernel'], pad=(2, 2))
+        o = act(equal_conv(o, sd[p + 'conv2.1.weight'], stride=2), sd[p + 'conv2.2.bias'])
+        s = upfirdn2d(h, sd[p + 'skip.0.kernel'], pad=(1, 1))
+        s = equal_conv(s, sd[p + 'skip.1.weight'], stride=2)
+        h = (o + s) / math.sqrt(2)
+        k += 1
+    h = minibatch_stddev(h)
+    h = act(equal_conv(h, sd['last_conv.0.weight'], padding=1), sd['last_conv.1.bias'])
+    return h.reshape(h.size(0), -1)
+
+
+def d_forward(sd, x, size, sg_linear=False, masks=None, head_masks=None):
+    """BaseDiscriminator.forward (base.py:107-150) with plain nn.Linear heads (no spectral norm in StyleGAN2)."""
+    f = d_features(sd, x, size, masks)
+    fd = f.detach() if sg_linear else f
+    hm = head_masks if head_masks is not None else (None, None, None)
+
+    def lin(pre, t):
+        return F.linear(t, sd[pre + '.weight'], sd[pre + '.bias'])
+
+    out = lin('linear.l2', _lrelu(lin('linear.l1', fd), 0.1, hm[0]))
+    proj = lin('projection.2', _lrelu(lin('projection.0', f), 0.1, hm[1]))
+    proj2 = lin('projection2.2', _lrelu(lin('projection2.0', f), 0.1, hm[2]))
+    return out, proj, proj2, f
+
+
+def r1_penalty(d_out_fn, images_aug):
+    """r1_loss (train_stylegan2.py:106-113) on already-augmented images; d_out_fn(x) -> logits (default flags)."""
+    xa = images_aug.detach().requires_grad_()
+    d_real = d_out_fn(xa)
+    grad_real, = torch.autograd.grad(outputs=d_real.sum(), inputs=xa, create_graph=True, retain_graph=True)
+    return grad_real.pow(2).reshape(grad_real.shape[0], -1).sum(1).mean()

@@ -322,8 +322,98 @@ def gen_adam():
         save('adam_' + tag, p0=p, grads=torch.stack(grads), traj=torch.stack(traj), lr=lr, b1=b1, b2=b2)
 
 
+# ------------------------------------------------------------------------------------------------
+def gen_stylegan2():
+    from oracle import stylegan2_oracle as S
+    from models.gan import get_architecture
+    from models.gan.stylegan2.op import upfirdn2d as ref_upfirdn2d
+    from models.gan.stylegan2.op import fused_leaky_relu as ref_flr
+    from training.gan import contrad as ref_contrad
+    from argparse import Namespace
+    out = {}
+
+    # ---- upfirdn2d in the modes the hot path uses + a negative pad ----
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 5, 9, 11, generator=g)
+    k = S.make_kernel()
+    for tag, (up, down, pad, kk) in {'blur22': (1, 1, (2, 2), k), 'blur11': (1, 1, (1, 1), k),
+                                      'up2': (2, 1, (2, 1), k * 4), 'down2': (1, 2, (1, 1), k),
+                                      'neg': (1, 1, (-1, 2), k), 'k2': (2, 1, (1, 0), k[:2, :2].contiguous() * 4)}.items():
+        ref = ref_upfirdn2d(x, kk, up=up, down=down, pad=pad)
+        check(S.upfirdn2d(x, kk, up, down, pad), ref, 1e-6, 'upfirdn2d ' + tag)
+        out['ufd_%s_out' % tag] = ref
+        out['ufd_%s_cfg' % tag] = torch.tensor([up, down, pad[0], pad[1]])
+        out['ufd_%s_k' % tag] = kk
+    out['ufd_x'] = x
+    b = torch.randn(5, generator=g)
+    check(S.fused_leaky_relu(x, b), ref_flr(x, b), 1e-7, 'fused_leaky_relu')
+    out['flr_b'] = b
+    out['flr_out'] = ref_flr(x, b)
+
+    # ---- ResidualDiscriminatorP small32: state dict, ContraD D loss, R1 with double backward ----
+    G, D = None, None
+    from models.gan.stylegan2.discriminator import ResidualDiscriminatorP
+    D = ResidualDiscriminatorP(size=32, small32=True, mlp_linear=True, d_hidden=512)
+    D.train()
+    shapes = S.d_param_shapes(32, True)
+    ref_shapes = {kk: tuple(v.shape) for kk, v in D.state_dict().items()}
+    assert ref_shapes == shapes, (set(ref_shapes) ^ set(shapes))
+    sd = S.det_fill_d(shapes, seed=2024)
+    D.load_state_dict({kk: v.clone() for kk, v in sd.items()})
+    N = 4
+    g = torch.Generator().manual_seed(17)
+    x = torch.rand(N, 3, 32, 32, generator=g)
+    fake = torch.rand(N, 3, 32, 32, generator=g)
+    aug = torch.rand(3 * N, 3, 32, 32, generator=g)       # stands for augment(cat[x,x,fake]) (explicit input)
+    aug_r1 = torch.rand(N, 3, 32, 32, generator=g)        # stands for augment(x) inside r1_loss
+
+    P = Namespace(augment_fn=lambda t: aug if t.size(0) == 3 * N else aug_r1, temp=0.1, lbd_a=1.0, distributed=False)
+    D.zero_grad()
+    d_loss, aux = ref_contrad.loss_D_fn(P, D, {'loss': 'nonsat'}, x, fake)
+    # r1_loss of train_stylegan2.py:106-113 (the training scripts are not importable: imageio/torchvision)
+    xa = aug_r1.detach().clone().requires_grad_()
+    d_real = D(xa)
+    grad_real, = torch.autograd.grad(outputs=d_real.sum(), inputs=xa, create_graph=True, retain_graph=True)
+    r1 = grad_real.pow(2).reshape(N, -1).sum(1).mean()
+    lbd_r1, d_reg_every = 0.1, 1                           # c10_style64 + --no_lazy (README.md:112-118)
+    loss = d_loss + aux['penalty'] + (0.5 * lbd_r1) * r1 * d_reg_every
+    loss.backward()
+    ref_grads = {kk: v.grad.clone() for kk, v in D.named_parameters()}
+
+    osd = {kk: v.clone() for kk, v in sd.items()}
+    for kk in osd:
+        if not kk.endswith('kernel'):
+            osd[kk].requires_grad_()
+    o_all, o_p, o_p2, o_f = S.d_forward(osd, aug, 32, sg_linear=True)
+    closs, gloss, dr, dg = O.contrad_loss_d(lambda t: (o_all, o_p, o_p2), aug, N)
+    or1 = S.r1_penalty(lambda t: S.d_forward(osd, t, 32)[0], aug_r1)
+    (closs + gloss + 0.05 * or1).backward()
+    check(closs, d_loss, 1e-6, 'sg2 contrad loss')
+    check(gloss, aux['penalty'], 1e-6, 'sg2 gan loss')
+    check(or1, r1, 1e-6, 'sg2 r1')
+    gerr = 0.0
+    for kk, gref in ref_grads.items():
+        gerr = max(gerr, check(osd[kk].grad, gref, 2e-5, 'sg2 grad ' + kk))
+    print('  stylegan2 D: max grad err vs reference %.2e, r1 = %.4f' % (gerr, r1.item()))
+    with torch.no_grad():
+        logit, auxo = D(aug, sg_linear=True, projection=True, projection2=True, penultimate=True)
+        d_r1 = D(aug_r1)
+    out.update({'x': x, 'fake': fake, 'aug': aug, 'aug_r1': aug_r1, 'N': N, 'logit': logit,
+                'projection': auxo['projection'], 'projection2': auxo['projection2'],
+                'penultimate_head': auxo['penultimate'][:, :64], 'penultimate_sum': auxo['penultimate'].sum(1),
+                'contrad_loss': d_loss, 'gan_loss': aux['penalty'], 'r1': r1, 'd_r1_logits': d_r1,
+                'grad_real_head': grad_real.detach().reshape(N, -1)[:, :256], 'grad_real_norm': grad_real.detach().norm()})
+    for kk, gref in ref_grads.items():
+        out['gradnorm/' + kk] = gref.norm()
+        if gref.numel() <= 4096:
+            out['grad/' + kk] = gref
+        else:
+            out['gradhead/' + kk] = gref.reshape(-1)[:512]
+    save('stylegan2_d', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['losses', 'augment', 'sndcgan', 'adam']
+    which = sys.argv[1:] or ['losses', 'augment', 'sndcgan', 'adam', 'stylegan2']
     for w in which:
         globals()['gen_' + w]()
     print('golden vectors OK')

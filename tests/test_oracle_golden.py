@@ -143,3 +143,28 @@ def test_adam_trajectory(golden):
             O.adam_step(p, gr, m, v, t, float(g['lr']), float(g['b1']), float(g['b2']))
             assert close(p, g['traj'][t - 1])
     assert O.warmup_lr(0, 3000, 2e-4) == 2e-4 / 3000 and O.warmup_lr(5000, 3000, 2e-4) == 2e-4
+
+
+def test_stylegan2_oracle_against_golden(golden):
+    from oracle import stylegan2_oracle as S
+    g = golden('stylegan2_d')
+    x = T(g['ufd_x'])
+    for tag in ('blur22', 'blur11', 'up2', 'down2', 'neg', 'k2'):
+        up, down, p0, p1 = [int(v) for v in g['ufd_%s_cfg' % tag]]
+        assert close(S.upfirdn2d(x, T(g['ufd_%s_k' % tag]), up, down, (p0, p1)), g['ufd_%s_out' % tag])
+    assert close(S.fused_leaky_relu(x, T(g['flr_b'])), g['flr_out'], 1e-7)
+    N = int(g['N'])
+    sd = S.det_fill_d(S.d_param_shapes(32, True), seed=2024)
+    for k in sd:
+        if not k.endswith('kernel'):
+            sd[k].requires_grad_()
+    aug = T(g['aug'])
+    o_all, o_p, o_p2, f = S.d_forward(sd, aug, 32, sg_linear=True)
+    assert close(o_all, g['logit']) and close(o_p, g['projection']) and close(f.sum(1), g['penultimate_sum'], 1e-5)
+    closs, gloss, _, _ = O.contrad_loss_d(lambda t: (o_all, o_p, o_p2), aug, N)
+    r1 = S.r1_penalty(lambda t: S.d_forward(sd, t, 32)[0], T(g['aug_r1']))
+    (closs + gloss + 0.05 * r1).backward()
+    assert close(closs, g['contrad_loss']) and close(gloss, g['gan_loss']) and close(r1, g['r1'])
+    for k in g.files:
+        if k.startswith('gradnorm/'):
+            assert close(sd[k[len('gradnorm/'):]].grad.norm(), g[k], 2e-5), k

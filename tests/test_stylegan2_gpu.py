@@ -1,0 +1,166 @@
+"""GPU parity of the StyleGAN2 rows (D4, D5, R1): the two native ops' HIP counterparts and the residual
+discriminator incl. the R1 double backward, against the reference-generated goldens and the oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from contrad_amd import ops
+from contrad_amd.models.gan.stylegan2.discriminator import ResidualDiscriminatorP
+from contrad_amd.training.gan import contrad as hip_contrad
+from oracle import contrad_oracle as O
+from oracle import stylegan2_oracle as S
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+FLIP_TOL = 3e-2      # leaky-relu sign flips vs the raw reference goldens: see tests/test_sndcgan_gpu.py
+DEV = 'cuda'
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def l2(a, b):
+    a, b = torch.as_tensor(a).double().cpu().reshape(-1), torch.as_tensor(b).double().cpu().reshape(-1)
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize('tag', ['blur22', 'blur11', 'up2', 'down2', 'neg', 'k2'])
+def test_upfirdn2d_against_reference(golden, tag):
+    g = golden('stylegan2_d')
+    x = torch.from_numpy(g['ufd_x'])
+    up, down, p0, p1 = [int(v) for v in g['ufd_%s_cfg' % tag]]
+    k = torch.from_numpy(g['ufd_%s_k' % tag]).contiguous()
+    out = ops.upfirdn2d(x.permute(0, 2, 3, 1).contiguous().to(DEV), k.to(DEV), up, down, (p0, p1, p0, p1))
+    assert rel(out.permute(0, 3, 1, 2), g['ufd_%s_out' % tag]) < 1e-5
+
+
+def test_upfirdn2d_adjoint_and_double_backward():
+    """<blur(x), g> == <x, blur_backward(g)> and the backward of the backward is the forward (op/upfirdn2d.py:19-85)."""
+    from contrad_amd import autograd_ops as A
+    g = torch.Generator(device='cuda').manual_seed(0)
+    x = torch.randn(3, 9, 9, 8, device=DEV, generator=g, requires_grad=True)
+    k = A.make_blur_kernel().to(DEV)
+    for pad in ((2, 2, 2, 2), (1, 1, 1, 1)):
+        y = A.UpFirDn2dFn.apply(x, k, 1, 1, pad)
+        gy = torch.randn(y.shape, device=DEV, generator=g, requires_grad=True)
+        gx, = torch.autograd.grad(y, x, gy, create_graph=True)
+        assert abs((y * gy).sum().item() - (x * gx).sum().item()) < 1e-3 * abs((y * gy).sum().item())
+        h = torch.randn(gx.shape, device=DEV, generator=g)
+        ggy, = torch.autograd.grad(gx, gy, h)
+        assert rel(ggy, A.UpFirDn2dFn.apply(h, k, 1, 1, pad).detach()) < 1e-5
+
+
+def test_fused_bias_act(golden):
+    g = golden('stylegan2_d')
+    x = torch.from_numpy(g['ufd_x']).permute(0, 2, 3, 1).contiguous().to(DEV)
+    b = torch.from_numpy(g['flr_b']).to(DEV)
+    y = ops.fused_bias_act(x, b, None, 3, 0, 0.2, math.sqrt(2))
+    assert rel(y.permute(0, 3, 1, 2), g['flr_out']) < 1e-6
+    gy = torch.randn_like(y)
+    gx = ops.fused_bias_act(gy, None, y, 3, 1, 0.2, math.sqrt(2))
+    ref = gy * torch.where(y > 0, math.sqrt(2), 0.2 * math.sqrt(2))
+    assert rel(gx, ref) < 1e-6
+
+
+def build_d():
+    D = ResidualDiscriminatorP(32, small32=True, mlp_linear=True, d_hidden=512)
+    D.load_state_dict(S.det_fill_d(S.d_param_shapes(32, True), seed=2024))
+    return D.to(DEV).train()
+
+
+def test_state_dict_contract():
+    D = ResidualDiscriminatorP(32, small32=True)
+    assert {k: tuple(v.shape) for k, v in D.state_dict().items()} == S.d_param_shapes(32, True)
+    D = ResidualDiscriminatorP(512, channel_multiplier=1.0)
+    assert {k: tuple(v.shape) for k, v in D.state_dict().items()} == S.d_param_shapes(512, False, 1.0)
+
+
+class _P(object):
+    def __init__(self, aug, aug_r1, N):
+        self.augment_fn = lambda t: aug if t.size(0) == 3 * N else aug_r1
+        self.temp, self.lbd_a, self.distributed = 0.1, 1.0, False
+
+
+def hip_step(D, g, N):
+    aug = torch.from_numpy(g['aug']).to(DEV)
+    aug_r1 = torch.from_numpy(g['aug_r1']).to(DEV)
+    P = _P(aug, aug_r1, N)
+    d_loss, a = hip_contrad.loss_D_fn(P, D, {'loss': 'nonsat'}, torch.from_numpy(g['x']).to(DEV),
+                                      torch.from_numpy(g['fake']).to(DEV))
+    xa = aug_r1.detach().clone().requires_grad_()
+    d_real = D(xa)
+    grad_real, = torch.autograd.grad(outputs=d_real.sum(), inputs=xa, create_graph=True, retain_graph=True)
+    r1 = grad_real.pow(2).reshape(N, -1).sum(1).mean()
+    loss = d_loss + a['penalty'] + (0.5 * 0.1) * r1 * 1
+    D.zero_grad()
+    loss.backward()
+    return d_loss, a, r1, grad_real, d_real
+
+
+def test_discriminator_forward_and_r1_step_against_reference(golden):
+    g = golden('stylegan2_d')
+    N = int(g['N'])
+    D = build_d()
+    aug = torch.from_numpy(g['aug']).to(DEV)
+    with torch.no_grad():
+        logit, aux = D(aug, sg_linear=True, projection=True, projection2=True, penultimate=True)
+    assert rel(logit, g['logit']) < TOL
+    assert rel(aux['projection'], g['projection']) < TOL and rel(aux['projection2'], g['projection2']) < TOL
+    assert rel(aux['penultimate'][:, :64], g['penultimate_head']) < TOL
+    assert rel(aux['penultimate'].sum(1), g['penultimate_sum']) < TOL
+
+    d_loss, a, r1, grad_real, d_real = hip_step(D, g, N)
+    assert abs(d_loss.item() - float(g['contrad_loss'])) < TOL * abs(float(g['contrad_loss']))
+    assert abs(a['penalty'].item() - float(g['gan_loss'])) < TOL * abs(float(g['gan_loss']))
+    assert rel(d_real, g['d_r1_logits']) < TOL
+    assert abs(r1.item() - float(g['r1'])) < 5e-3 * float(g['r1'])
+    assert abs(grad_real.norm().item() - float(g['grad_real_norm'])) < 5e-3 * float(g['grad_real_norm'])
+    grads = {k: p.grad for k, p in D.named_parameters()}
+    for k in g.files:
+        if k.startswith('gradnorm/'):
+            name = k[len('gradnorm/'):]
+            e = abs(grads[name].norm().item() - float(g[k])) / max(float(g[k]), 1e-30)
+            assert e < 5e-3, (name, e)
+        elif k.startswith('grad/'):
+            assert l2(grads[k[5:]], g[k]) < FLIP_TOL, k
+
+
+def test_r1_step_on_the_same_linear_region(golden):
+    """Strict element-wise check of first AND second order gradients: oracle evaluated with the leaky-relu
+    sign patterns recorded from the two HIP forwards (D-step batch and R1 batch)."""
+    g = golden('stylegan2_d')
+    N = int(g['N'])
+    D = build_d()
+    D._record_activations = True
+    d_loss, a, r1, grad_real, d_real = hip_step(D, g, N)
+    (rec_a, hl_a, hpq_a), (rec_b, hl_b, hpq_b) = D._recorded[0], D._recorded[1]
+
+    def masks_of(rec):
+        return [(t > 0).permute(0, 3, 1, 2).cpu() for t in rec]
+
+    def head_masks(hl, hpq):
+        hl, hpq = hl.reshape(hl.shape[0], -1).cpu(), hpq.reshape(hpq.shape[0], -1).cpu()
+        return (hl > 0, hpq[:, :512] > 0, hpq[:, 512:] > 0)
+
+    osd = S.det_fill_d(S.d_param_shapes(32, True), seed=2024)
+    for k in osd:
+        if not k.endswith('kernel'):
+            osd[k].requires_grad_()
+    aug, aug_r1 = torch.from_numpy(g['aug']), torch.from_numpy(g['aug_r1'])
+    o_all, o_p, o_p2, _ = S.d_forward(osd, aug, 32, sg_linear=True, masks=masks_of(rec_a),
+                                      head_masks=head_masks(hl_a, hpq_a))
+    closs, gloss, _, _ = O.contrad_loss_d(lambda t: (o_all, o_p, o_p2), aug, N)
+    or1 = S.r1_penalty(lambda t: S.d_forward(osd, t, 32, masks=masks_of(rec_b),
+                                             head_masks=head_masks(hl_b, hpq_b))[0], aug_r1)
+    (closs + gloss + 0.05 * or1).backward()
+    assert abs(d_loss.item() - closs.item()) < TOL * abs(closs.item())
+    assert abs(a['penalty'].item() - gloss.item()) < TOL * abs(gloss.item())
+    assert abs(r1.item() - or1.item()) < TOL * or1.item()
+    for k, prm in D.named_parameters():
+        ref = osd[k].grad
+        e = (prm.grad.cpu() - ref).abs().max().item() / ref.abs().max().clamp_min(1e-30).item()
+        assert e < TOL, (k, e)
