@@ -187,6 +187,8 @@ struct RgbDgradArgs {
   const float* wp;   // packed [(tap*C + c)][ldw]
   const float* bias; // [C] or NULL
   float* out;        // NCHW (N,C,H,W)
+  const float* mod;      // optional [N][K] per-sample modulation of the input channels (ToRGB)
+  const float* residual; // optional NCHW (N,C,H,W) added before the activation (ToRGB skip)
   int N, C, H, W, K, ldy, ldw, k, pad;
   int act;           // 0: none, 1: tanh
   float out_scale, out_shift;  // out = f(acc + bias) * out_scale + out_shift
@@ -196,20 +198,22 @@ struct RgbDgradArgs {
 // K/4 lanes cooperate on one output pixel: each lane owns 4 input channels (one coalesced float4 per tap, so a
 // pixel's K channels are read as one contiguous run), keeps its taps x C x 4 weights in registers, and the C partial
 // sums are combined with xor-shuffles inside the lane group.  256/(K/4) pixels per block pass.
-template <int KSZ>
+template <int KSZ, int CH>   // CH: channel chunks of 4 per lane (K = 4 * CH * lanes-per-pixel)
 __global__ __launch_bounds__(256) void rgb_conv_dgrad_kernel(RgbDgradArgs a) {
   constexpr int TAPS = KSZ * KSZ;
-  const int tpp = a.K >> 2;                 // lanes per pixel (power of two, <= 64)
+  const int tpp = a.K / (4 * CH);           // lanes per pixel (power of two, <= 64)
   const int slots = blockDim.x / tpp;
   const int cg = threadIdx.x % tpp, slot = threadIdx.x / tpp;
-  float4 w[TAPS * MAX_CIN];
+  float4 w[CH][TAPS * MAX_CIN];
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
+  for (int q = 0; q < CH; ++q)
 #pragma unroll
-    for (int c = 0; c < MAX_CIN; ++c)
-      w[t * MAX_CIN + c] = (c < a.C)
-                               ? *reinterpret_cast<const float4*>(a.wp + (size_t)(t * a.C + c) * a.ldw + cg * 4)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int c = 0; c < MAX_CIN; ++c)
+        w[q][t * MAX_CIN + c] =
+            (c < a.C) ? *reinterpret_cast<const float4*>(a.wp + (size_t)(t * a.C + c) * a.ldw + (q * tpp + cg) * 4)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
   const long long total = (long long)a.N * a.H * a.W;
   for (long long pix0 = (long long)blockIdx.x * slots; pix0 < total; pix0 += (long long)gridDim.x * slots) {
     const long long pix = pix0 + slot;
@@ -219,6 +223,11 @@ __global__ __launch_bounds__(256) void rgb_conv_dgrad_kernel(RgbDgradArgs a) {
     const int h = (int)((pp / a.W) % a.H);
     const int n = (int)(pp / ((long long)a.W * a.H));
     float acc[MAX_CIN] = {0.f, 0.f, 0.f, 0.f};
+    float4 md[CH];
+#pragma unroll
+    for (int q = 0; q < CH; ++q)
+      md[q] = a.mod ? *reinterpret_cast<const float4*>(a.mod + (size_t)n * a.K + (q * tpp + cg) * 4)
+                    : make_float4(1.f, 1.f, 1.f, 1.f);
 #pragma unroll
     for (int kh = 0; kh < KSZ; ++kh) {
       const int ho = h + a.pad - kh;
@@ -226,13 +235,16 @@ __global__ __launch_bounds__(256) void rgb_conv_dgrad_kernel(RgbDgradArgs a) {
       for (int kw = 0; kw < KSZ; ++kw) {
         const int wo = wq + a.pad - kw;
         const bool ok = live && (unsigned)ho < (unsigned)a.H && (unsigned)wo < (unsigned)a.W;
-        const float4 g = *reinterpret_cast<const float4*>(
-            a.gy + (ok ? ((size_t)(n * a.H + ho) * a.W + wo) * a.ldy + cg * 4 : 0));
         const float m = ok ? 1.f : 0.f;
 #pragma unroll
-        for (int c = 0; c < MAX_CIN; ++c) {
-          const float4 ww = w[(kh * KSZ + kw) * MAX_CIN + c];
-          acc[c] += m * (g.x * ww.x + g.y * ww.y + g.z * ww.z + g.w * ww.w);
+        for (int q = 0; q < CH; ++q) {
+          const float4 g = *reinterpret_cast<const float4*>(
+              a.gy + (ok ? ((size_t)(n * a.H + ho) * a.W + wo) * a.ldy + (q * tpp + cg) * 4 : 0));
+#pragma unroll
+          for (int c = 0; c < MAX_CIN; ++c) {
+            const float4 ww = w[q][(kh * KSZ + kw) * MAX_CIN + c];
+            acc[c] += m * (g.x * md[q].x * ww.x + g.y * md[q].y * ww.y + g.z * md[q].z * ww.z + g.w * md[q].w * ww.w);
+          }
         }
       }
     }
@@ -242,8 +254,10 @@ __global__ __launch_bounds__(256) void rgb_conv_dgrad_kernel(RgbDgradArgs a) {
     if (live && cg < a.C) {
       float v = (cg == 0) ? acc[0] : (cg == 1) ? acc[1] : (cg == 2) ? acc[2] : acc[3];
       v += a.bias ? a.bias[cg] : 0.f;
+      const size_t o = ((size_t)(n * a.C + cg) * a.H + h) * a.W + wq;
+      if (a.residual) v += a.residual[o];
       if (a.act == 1) v = tanhf(v);
-      a.out[((size_t)(n * a.C + cg) * a.H + h) * a.W + wq] = v * a.out_scale + a.out_shift;
+      a.out[o] = v * a.out_scale + a.out_shift;
     }
   }
 }
@@ -317,22 +331,26 @@ extern "C" int contrad_rgb_conv_wgrad(const float* img, const float* gy, float* 
   return 0;
 }
 
-extern "C" int contrad_rgb_conv_dgrad(const float* gy, const float* wp, const float* bias, float* out, int N,
-                                      int C, int H, int W, int K, int k, int ldy, int ldw, int act,
-                                      float out_scale, float out_shift, contrad_stream_t stream) {
+extern "C" int contrad_rgb_conv_dgrad(const float* gy, const float* wp, const float* bias, const float* mod,
+                                      const float* residual, float* out, int N, int C, int H, int W, int K,
+                                      int k, int ldy, int ldw, int act, float out_scale, float out_shift,
+                                      contrad_stream_t stream) {
   CONTRAD_ARG(gy && wp && out && N > 0 && H > 0 && W > 0 && C >= 1 && C <= MAX_CIN);
-  CONTRAD_ARG((k == 1 || k == 3) && K >= 16 && K <= 256 && (K & (K - 1)) == 0 && ldy >= K && (ldy & 3) == 0);
+  CONTRAD_ARG((k == 1 || k == 3) && K >= 16 && K <= 512 && (K & (K - 1)) == 0 && ldy >= K && (ldy & 3) == 0);
+  CONTRAD_ARG(K <= 256 || k == 1);
   CONTRAD_ARG(ldw >= K && (ldw & 3) == 0 && (act == 0 || act == 1));
   RgbDgradArgs a{};
-  a.gy = gy; a.wp = wp; a.bias = bias; a.out = out;
+  a.gy = gy; a.wp = wp; a.bias = bias; a.out = out; a.mod = mod; a.residual = residual;
   a.N = N; a.C = C; a.H = H; a.W = W; a.K = K; a.ldy = ldy; a.ldw = ldw; a.k = k; a.pad = k / 2;
   a.act = act; a.out_scale = out_scale; a.out_shift = out_shift;
   const long long total = (long long)N * H * W;
-  const int slots = 256 / (K / 4);
+  const int ch = (K > 256) ? 2 : 1;
+  const int slots = 256 / (K / (4 * ch));
   long long grid = (total + slots - 1) / slots;
   if (grid > 4096) grid = 4096;
-  if (k == 3) hipLaunchKernelGGL(rgb_conv_dgrad_kernel<3>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(rgb_conv_dgrad_kernel<1>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a);
+  if (k == 3) hipLaunchKernelGGL((rgb_conv_dgrad_kernel<3, 1>), dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a);
+  else if (ch == 1) hipLaunchKernelGGL((rgb_conv_dgrad_kernel<1, 1>), dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((rgb_conv_dgrad_kernel<1, 2>), dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a);
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }

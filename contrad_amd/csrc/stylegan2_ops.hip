@@ -109,7 +109,89 @@ __global__ void lincomb_kernel(const float* __restrict__ x, const float* __restr
     y[i] = a * x[i] + bc * z[i];
 }
 
+// PixelNorm: one wave per row
+__global__ void pixelnorm_kernel(const float* __restrict__ x, float* __restrict__ y, int M, int K) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  float ss = 0.f;
+  for (int c = lane; c < K; c += 64) { const float v = x[(size_t)row * K + c]; ss += v * v; }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss / (float)K + 1e-8f);
+  for (int c = lane; c < K; c += 64) y[(size_t)row * K + c] = x[(size_t)row * K + c] * r;
+}
+
+__global__ void nhwc_scale_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ y,
+                                  int N, long long HW, int C) {
+  const int c4n = C >> 2;
+  const long long total = (long long)N * HW * c4n;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % c4n);
+    const int n = (int)(e / (HW * c4n));
+    const float4 v = reinterpret_cast<const float4*>(x)[e];
+    const float4 m = *reinterpret_cast<const float4*>(s + (size_t)n * C + c4 * 4);
+    reinterpret_cast<float4*>(y)[e] = make_float4(v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w);
+  }
+}
+
+__global__ void modconv_epilogue_kernel(const float* __restrict__ x, const float* __restrict__ demod,
+                                        const float* __restrict__ noise, const float* __restrict__ noise_w,
+                                        const float* __restrict__ bias, float* __restrict__ y, int N, long long HW,
+                                        int K) {
+  const int k4n = K >> 2;
+  const long long total = (long long)N * HW * k4n;
+  const float nw = (noise && noise_w) ? noise_w[0] : 0.f;
+  const float g = 1.4142135623730951f;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int k4 = (int)(e % k4n);
+    const long long pix = e / k4n;           // n*HW + hw
+    const int n = (int)(pix / HW);
+    float4 v = reinterpret_cast<const float4*>(x)[e];
+    if (demod) {
+      const float4 d = *reinterpret_cast<const float4*>(demod + (size_t)n * K + k4 * 4);
+      v.x *= d.x; v.y *= d.y; v.z *= d.z; v.w *= d.w;
+    }
+    const float nz = noise ? nw * noise[pix] : 0.f;
+    const float4 b = *reinterpret_cast<const float4*>(bias + k4 * 4);
+    v.x += nz + b.x; v.y += nz + b.y; v.z += nz + b.z; v.w += nz + b.w;
+    v.x = (v.x > 0.f ? v.x : 0.2f * v.x) * g; v.y = (v.y > 0.f ? v.y : 0.2f * v.y) * g;
+    v.z = (v.z > 0.f ? v.z : 0.2f * v.z) * g; v.w = (v.w > 0.f ? v.w : 0.2f * v.w) * g;
+    reinterpret_cast<float4*>(y)[e] = v;
+  }
+}
+
 }  // namespace
+
+extern "C" int contrad_pixelnorm(const float* x, float* y, int M, int K, contrad_stream_t stream) {
+  CONTRAD_ARG(x && y && M > 0 && K > 0);
+  hipLaunchKernelGGL(pixelnorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, y, M, K);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int contrad_nhwc_scale(const float* x, const float* s, float* y, int N, long long HW, int C,
+                                  contrad_stream_t stream) {
+  CONTRAD_ARG(x && s && y && N > 0 && HW > 0 && C > 0 && (C & 3) == 0);
+  long long grid = ((long long)N * HW * (C / 4) + 255) / 256;
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(nhwc_scale_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, x, s, y, N, HW, C);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int contrad_modconv_epilogue(const float* x, const float* demod, const float* noise,
+                                        const float* noise_w, const float* bias, float* y, int N, long long HW,
+                                        int K, contrad_stream_t stream) {
+  CONTRAD_ARG(x && bias && y && N > 0 && HW > 0 && K > 0 && (K & 3) == 0);
+  long long grid = ((long long)N * HW * (K / 4) + 255) / 256;
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(modconv_epilogue_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, x, demod, noise,
+                     noise_w, bias, y, N, HW, K);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int contrad_upfirdn2d(const float* input, const float* kernel, float* out, int major, int in_h,
                                  int in_w, int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y,

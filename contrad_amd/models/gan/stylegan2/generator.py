@@ -1,9 +1,284 @@
-"""StyleGAN2 generator (models/gan/stylegan2/generator.py:146-291) -- placeholder until the forward lands."""
+"""StyleGAN2 generator forward on the HIP library -- counterpart of models/gan/stylegan2/generator.py:146-291.
+
+Used under no_grad inside the discriminator step (the fake batch).  Same state-dict names as the reference.
+Design (NHWC feature maps):
+  * mapping network: PixelNorm kernel + 8 EqualLinear(lr_mul 0.01)+fused-lrelu as GEMMs with bias/activation in the
+    epilogue;
+  * ModulatedConv2d is evaluated in its equivalent "modulate the input, demodulate the output" form, so the conv uses
+    the SHARED scaled weight on the MFMA engine instead of the reference's grouped conv over B*Cout per-sample filters
+    (generator.py:52-82):   y_b = demod_b * conv(x_b * s_b, scale*W),  demod_b[k] = rsqrt(sum_c s_b[c]^2 Wsq[c,k] + 1e-8);
+  * upsampling layers: transposed conv stride 2 (= the conv engine's dgrad kernel) followed by the 4x4 blur (upfirdn2d);
+  * demodulation + noise injection + bias + leaky-relu*sqrt2 fused in one elementwise pass;
+  * ToRGB: 1x1 modulated conv onto 3 channels + bias + upsampled skip in one kernel (rgb_conv_dgrad with per-sample
+    channel modulation and a residual input); Upsample of the RGB skip = upfirdn2d(up=2).
+Packed weights / Wsq tables are cached and rebuilt only when a parameter's version counter changes (G is frozen during
+the D-step).
+"""
+import math
+
+import torch
 import torch.nn as nn
+
+from .... import ops
+from .... import autograd_ops as A
+
+
+class _EqualLinearParams(nn.Module):
+    """EqualLinear (stylegan2/layers.py:132-154)."""
+
+    def __init__(self, in_dim, out_dim, bias_init=0, lr_mul=1):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+        self.bias = nn.Parameter(torch.zeros(out_dim))
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul, self.bias_init = lr_mul, bias_init
+
+
+class _Blur(nn.Module):
+    def __init__(self, pad, upsample_factor=1):
+        super().__init__()
+        k = A.make_blur_kernel((1, 3, 3, 1))
+        if upsample_factor > 1:
+            k = k * (upsample_factor ** 2)
+        self.register_buffer('kernel', k)
+        self.pad = pad
+
+
+class _ModConv(nn.Module):
+    """ModulatedConv2d's tensors (generator.py:17-50)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False):
+        super().__init__()
+        self.in_channel, self.out_channel, self.kernel_size = in_channel, out_channel, kernel_size
+        self.upsample, self.demodulate = upsample, demodulate
+        if upsample:
+            p = (4 - 2) - (kernel_size - 1)
+            self.blur = _Blur(((p + 1) // 2 + 2 - 1, p // 2 + 1), upsample_factor=2)
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.modulation = _EqualLinearParams(style_dim, in_channel, bias_init=1)
+
+
+class _Noise(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1))
+
+
+class _ActBias(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(c))
+
+
+class _StyleLayer(nn.Module):
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False):
+        super().__init__()
+        self.conv = _ModConv(in_channel, out_channel, kernel_size, style_dim, upsample=upsample)
+        self.noise = _Noise()
+        self.activate = _ActBias(out_channel)
+
+
+class _Upsample(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.register_buffer('kernel', A.make_blur_kernel((1, 3, 3, 1)) * 4)
+        self.pad = (2, 1)
+
+
+class _ToRGB(nn.Module):
+    def __init__(self, in_channel, style_dim, upsample=True):
+        super().__init__()
+        if upsample:
+            self.upsample = _Upsample()
+        self.conv = _ModConv(in_channel, 3, 1, style_dim, demodulate=False)
+        self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
+
+
+class _Const(nn.Module):
+    def __init__(self, channel, size=4):
+        super().__init__()
+        self.const = nn.Parameter(torch.randn(1, channel, size, size))
+
+
+class _PixelNorm(nn.Module):
+    pass
 
 
 class Generator(nn.Module):
     def __init__(self, size, style_dim=512, n_mlp=8, channel_multiplier=2, blur_kernel=(1, 3, 3, 1), lr_mlp=0.01,
                  small32=False):
         super().__init__()
-        raise NotImplementedError('StyleGAN2 generator forward: scope row G0 (StyleGAN2), not built yet')
+        if tuple(blur_kernel) != (1, 3, 3, 1):
+            raise NotImplementedError('blur kernel [1,3,3,1]')
+        self.size, self.style_dim = size, style_dim
+        layers = [_PixelNorm()]
+        for _ in range(n_mlp):
+            layers.append(_EqualLinearParams(style_dim, style_dim, lr_mul=lr_mlp))
+        self.style = nn.Sequential(*layers)
+        if small32:
+            self.channels = {4: 512, 8: 512, 16: 256, 32: 128}
+        else:
+            self.channels = {4: 512, 8: 512, 16: 512, 32: 512, 64: int(256 * channel_multiplier),
+                             128: int(128 * channel_multiplier), 256: int(64 * channel_multiplier),
+                             512: int(32 * channel_multiplier), 1024: int(16 * channel_multiplier)}
+        self.input = _Const(self.channels[4])
+        self.conv1 = _StyleLayer(self.channels[4], self.channels[4], 3, style_dim)
+        self.to_rgb1 = _ToRGB(self.channels[4], style_dim, upsample=False)
+        self.log_size = int(math.log(size, 2))
+        self.num_layers = (self.log_size - 2) * 2 + 1
+        self.layers = nn.ModuleList()
+        self.to_rgbs = nn.ModuleList()
+        self.noises = nn.Module()
+        in_channel = self.channels[4]
+        for i in range(3, self.log_size + 1):
+            out_channel = self.channels[2 ** i]
+            self.layers.append(_StyleLayer(in_channel, out_channel, 3, style_dim, upsample=True))
+            self.layers.append(_StyleLayer(out_channel, out_channel, 3, style_dim))
+            self.to_rgbs.append(_ToRGB(out_channel, style_dim))
+            in_channel = out_channel
+        self.n_latent = self.log_size * 2 - 2
+        self._cache_key, self._cache = None, None
+
+    @property
+    def device(self):
+        return self.input.const.device
+
+    def sample_latent(self, num_samples):
+        return torch.randn(num_samples, self.style_dim, device=self.device)
+
+    # ---- cached weight preparation -----------------------------------------------------------------------
+    def _modconvs(self):
+        out = [self.conv1.conv, self.to_rgb1.conv]
+        for l in self.layers:
+            out.append(l.conv)
+        for t in self.to_rgbs:
+            out.append(t.conv)
+        return out
+
+    def _prepared(self):
+        params = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if key == self._cache_key:
+            return self._cache
+        dev = self.device
+        ws, entries, groups = [], [], []
+
+        def add(w, K, C, T, scale):
+            groups.append((T * C, ops.round_up(K, 4)))
+            ws.append(w)
+            entries.append((K, C, T, scale, len(groups) - 1, 0))
+            return len(groups) - 1
+
+        c = {'style': [], 'mod': {}, 'conv': {}, 'wsq': {}}
+        with torch.no_grad():
+            for m in list(self.style)[1:]:
+                c['style'].append((add(m.weight, m.weight.shape[0], m.weight.shape[1], 1, m.scale),
+                                   (m.bias * m.lr_mul).contiguous()))
+            for mc in self._modconvs():
+                mod = mc.modulation
+                c['mod'][mc] = (add(mod.weight, mod.weight.shape[0], mod.weight.shape[1], 1, mod.scale),
+                                (mod.bias * mod.lr_mul + mod.bias_init).contiguous())
+                w = mc.weight[0]                                  # (Cout, Cin, k, k)
+                k = mc.kernel_size
+                if mc.upsample or mc.out_channel == 3:            # transposed conv / ToRGB == dgrad of the
+                    #                                               (K = Cin, C = Cout) conv: pack rows (tap, cout), cols cin
+                    c['conv'][mc] = add(w.transpose(0, 1).contiguous(), mc.in_channel, mc.out_channel, k * k, mc.scale)
+                else:
+                    c['conv'][mc] = add(w.contiguous(), mc.out_channel, mc.in_channel, k * k, mc.scale)
+                if mc.demodulate:                                 # Wsq[c][k] = scale^2 * sum_taps W[k,c,:,:]^2
+                    c['wsq'][mc] = ((w * mc.scale).pow(2).sum((2, 3)).t().contiguous())
+            packed = A.PackWeightsFn.apply(A.PackMeta(entries, groups), *ws)
+        c['packed'] = packed
+        self._cache_key, self._cache = key, c
+        return c
+
+    # ---- pieces ----------------------------------------------------------------------------------------------
+    def _mapping(self, z, c):
+        x = ops.pixelnorm(z.contiguous().float())
+        B = x.shape[0]
+        for gi, bias in c['style']:
+            x = ops.conv2d_fwd(x.view(B, 1, 1, -1), c['packed'][gi], bias, self.style_dim, 1, 1, 1, 0, 0.2,
+                               math.sqrt(2.0)).view(B, -1)
+        return x
+
+    def _style(self, mc, w_lat, c):
+        gi, bias = c['mod'][mc]
+        B = w_lat.shape[0]
+        return ops.conv2d_fwd(w_lat.contiguous().view(B, 1, 1, -1), c['packed'][gi], bias, mc.in_channel, 1, 1, 1,
+                              0).view(B, mc.in_channel)
+
+    def _styled_conv(self, layer, x, w_lat, noise, c):
+        mc = layer.conv
+        B, H, W, _ = x.shape
+        s = self._style(mc, w_lat, c)
+        demod = None
+        if mc.demodulate:
+            wsq = c['wsq'][mc]
+            d = ops.conv2d_fwd((s * s).view(B, 1, 1, -1), wsq, None, mc.out_channel, 1, 1, 1, 0).view(B, -1)
+            demod = torch.rsqrt(d + 1e-8)
+        xm = ops.nhwc_scale(x, s)
+        wp = c['packed'][c['conv'][mc]]
+        if mc.upsample:
+            y = ops.conv2d_dgrad(xm, wp, (B, 2 * H + 1, 2 * W + 1, mc.out_channel), 3, 3, 2, 0)
+            p0, p1 = mc.blur.pad
+            y = ops.upfirdn2d(y, mc.blur.kernel, 1, 1, (p0, p1, p0, p1))
+        else:
+            y = ops.conv2d_fwd(xm, wp, None, mc.out_channel, 3, 3, 1, 1)
+        if noise is None:
+            noise = torch.empty(B, 1, y.shape[1], y.shape[2], device=y.device).normal_()   # generator.py:91-92
+        noise = noise.expand(B, 1, y.shape[1], y.shape[2]).contiguous()
+        return ops.modconv_epilogue_(y, demod, noise, layer.noise.weight, layer.activate.bias)
+
+    def _to_rgb(self, trgb, x, w_lat, skip, c, final=False):
+        mc = trgb.conv
+        s = self._style(mc, w_lat, c)
+        res = None
+        if skip is not None:
+            B, C, H, W = skip.shape
+            p0, p1 = trgb.upsample.pad
+            res = ops.upfirdn2d(skip.reshape(B * C, H, W, 1), trgb.upsample.kernel, 2, 1, (p0, p1, p0, p1))
+            res = res.view(B, C, 2 * H, 2 * W)
+        return ops.rgb_conv_dgrad(x, c['packed'][c['conv'][mc]], trgb.bias.view(-1), 3, 1, act=0,
+                                  out_scale=0.5 if final else 1.0, out_shift=0.5 if final else 0.0,
+                                  mod=s, residual=res)
+
+    def forward(self, input, return_latents=False, style_mix=0.9, input_is_latent=False, noise=None, _mix=None):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError('generator backward (G-step) is scope row N1/N2 -- call under no_grad')
+        if not input.is_cuda:
+            raise RuntimeError('contrad_amd StyleGAN2 generator runs on the MI355X HIP path only (no CPU fallback)')
+        c = self._prepared()
+        latent = self._mapping(input, c) if not input_is_latent else input
+        if noise is None:
+            noise = [None] * self.num_layers
+        latents = latent.unsqueeze(1).repeat(1, self.n_latent, 1) if latent.ndim < 3 else latent
+        if self.training and style_mix > 0:
+            B = input.size(0)
+            if _mix is None:                                   # generator.py:252-266 (masks from the CPU generator)
+                latent_mix = self._mapping(self.sample_latent(B), c)
+                nomix_mask = torch.rand(B) >= style_mix
+                mix_layer = torch.randint(self.n_latent, (B,))
+                mix_layer = mix_layer.masked_fill(nomix_mask, self.n_latent)
+            else:
+                latent_mix, mix_layer = self._mapping(_mix[0], c), _mix[1]
+            layer_idx = torch.arange(self.n_latent)[None]
+            mask = (layer_idx < mix_layer.unsqueeze(1)).float().unsqueeze(-1).to(latents.device)
+            latents = latents * mask + latent_mix.unsqueeze(1) * (1 - mask)
+        B = latents.shape[0]
+        x = self.input.const.permute(0, 2, 3, 1).expand(B, -1, -1, -1).contiguous()        # NHWC const input
+        x = self._styled_conv(self.conv1, x, latents[:, 0], noise[0], c)
+        last = len(self.to_rgbs) == 0
+        skip = self._to_rgb(self.to_rgb1, x, latents[:, 1], None, c, final=last)
+        idx = 1
+        for j in range(len(self.to_rgbs)):
+            x = self._styled_conv(self.layers[2 * j], x, latents[:, idx], noise[1 + 2 * j], c)
+            x = self._styled_conv(self.layers[2 * j + 1], x, latents[:, idx + 1], noise[2 + 2 * j], c)
+            skip = self._to_rgb(self.to_rgbs[j], x, latents[:, idx + 2], skip, c, final=(j == len(self.to_rgbs) - 1))
+            idx += 2
+        image = skip                                                                        # 0.5*x+0.5 fused above
+        if not self.training:
+            image = image.clamp(0, 1)
+        if return_latents:
+            return image, latents
+        return image

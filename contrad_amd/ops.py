@@ -296,14 +296,18 @@ def rgb_conv_wgrad(img, gy, k, in_scale, in_shift, dwp, dbias=None):
     return dwp
 
 
-def rgb_conv_dgrad(gy, wp, bias, C, k, act=0, out_scale=1.0, out_shift=0.0, out=None):
-    """gy NHWC (N,H,W,K) -> NCHW (N,C,H,W), C <= 4."""
-    _chk(gy, 'gy'); _chk(wp, 'wp'); _chk(bias, 'bias')
+def rgb_conv_dgrad(gy, wp, bias, C, k, act=0, out_scale=1.0, out_shift=0.0, out=None, mod=None, residual=None):
+    """gy NHWC (N,H,W,K) -> NCHW (N,C,H,W), C <= 4; optional per-sample channel modulation (N,K) and NCHW residual."""
+    _chk(gy, 'gy'); _chk(wp, 'wp'); _chk(bias, 'bias'); _chk(mod, 'mod'); _chk(residual, 'residual')
     N, H, W, K = gy.shape
     if out is None:
         out = torch.empty((N, C, H, W), device=gy.device, dtype=torch.float32)
-    lib().call('contrad_rgb_conv_dgrad', _p(gy), _p(wp), _p(bias), _p(out), N, C, H, W, K, k, _ld(gy),
-               wp.stride(0), int(act), float(out_scale), float(out_shift), _stream())
+    if mod is not None and (tuple(mod.shape) != (N, K) or not mod.is_contiguous()):
+        raise RuntimeError('contrad_hip: mod must be a contiguous (N, K) tensor')
+    if residual is not None and (tuple(residual.shape) != (N, C, H, W) or not residual.is_contiguous()):
+        raise RuntimeError('contrad_hip: residual must be a contiguous (N, C, H, W) tensor')
+    lib().call('contrad_rgb_conv_dgrad', _p(gy), _p(wp), _p(bias), _p(mod), _p(residual), _p(out), N, C, H, W, K, k,
+               _ld(gy), wp.stride(0), int(act), float(out_scale), float(out_shift), _stream())
     return out
 
 
@@ -455,3 +459,28 @@ def lincomb(x, z, a, b):
     y = torch.empty_like(x)
     lib().call('contrad_lincomb', _p(x), _p(z), _p(y), ctypes.c_longlong(x.numel()), float(a), float(b), _stream())
     return y
+
+
+def pixelnorm(x):
+    _chk(x, 'x')
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    lib().call('contrad_pixelnorm', _p(x), _p(y), x.shape[0], x.shape[1], _stream())
+    return y
+
+
+def nhwc_scale(x, s):
+    """x (N,H,W,C) contiguous, s (N,C) -> x * s[:, None, None, :]."""
+    _chk(x, 'x'); _chk(s, 's')
+    N, H, W, C = x.shape
+    y = torch.empty_like(x)
+    lib().call('contrad_nhwc_scale', _p(x), _p(s.contiguous()), _p(y), N, ctypes.c_longlong(H * W), C, _stream())
+    return y
+
+
+def modconv_epilogue_(x, demod, noise, noise_w, bias):
+    """In place on x (N,H,W,K): sqrt2 * lrelu_0.2(x * demod + noise_w * noise + bias)."""
+    N, H, W, K = x.shape
+    lib().call('contrad_modconv_epilogue', _p(x), _p(demod), _p(noise), _p(noise_w), _p(bias), _p(x), N,
+               ctypes.c_longlong(H * W), K, _stream())
+    return x

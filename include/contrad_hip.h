@@ -134,12 +134,15 @@ long long contrad_rgb_conv_wgrad_workspace_bytes(int N, int Cin, int H, int W, i
 int contrad_rgb_conv_wgrad(const float* img, const float* gy, float* dwp, float* dbias, int N, int Cin,
                            int H, int W, int K, int k, int ldy, int ldw, float in_scale, float in_shift,
                            float* workspace, long long workspace_bytes, contrad_stream_t stream);
-/* Stride-1 transposed conv onto C <= 4 channels, NHWC in -> NCHW out, out = f(acc+bias)*out_scale+out_shift,
- * f = identity (act 0) or tanh (act 1): G_SNDCGAN's last ConvTranspose2d+Tanh+0.5x+0.5
- * (models/gan/sndcgan.py:37-38,47) and d loss / d image of D's first conv. */
-int contrad_rgb_conv_dgrad(const float* gy, const float* wp, const float* bias, float* out, int N, int C,
-                           int H, int W, int K, int k, int ldy, int ldw, int act, float out_scale,
-                           float out_shift, contrad_stream_t stream);
+/* Stride-1 transposed conv onto C <= 4 channels, NHWC in -> NCHW out,
+ * out = f(acc + bias + residual) * out_scale + out_shift, f = identity (act 0) or tanh (act 1); `mod` (may be
+ * NULL) is a per-sample [N][K] modulation of the input channels, `residual` (may be NULL) an NCHW tensor:
+ * G_SNDCGAN's last ConvTranspose2d+Tanh+0.5x+0.5 (models/gan/sndcgan.py:37-38,47), d loss / d image of D's first
+ * conv, and StyleGAN2's ToRGB = 1x1 modulated conv + bias + upsampled skip (stylegan2/generator.py:122-143). */
+int contrad_rgb_conv_dgrad(const float* gy, const float* wp, const float* bias, const float* mod,
+                           const float* residual, float* out, int N, int C, int H, int W, int K, int k,
+                           int ldy, int ldw, int act, float out_scale, float out_shift,
+                           contrad_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * HBM-bound helpers: column statistics, BatchNorm (generator forward), GAN logit losses, Adam.
@@ -226,6 +229,21 @@ int contrad_fused_bias_act(const float* x, const float* bias, const float* ref, 
 /* y = a*x + b*z  (ResBlock merge (out + skip)/sqrt(2), stylegan2/discriminator.py:72-74) */
 int contrad_lincomb(const float* x, const float* z, float* y, long long n, float a, float b,
                     contrad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * StyleGAN2 generator forward helpers (models/gan/stylegan2/generator.py).
+ * ---------------------------------------------------------------------------------------------- */
+/* PixelNorm (stylegan2/layers.py:14-19): y = x * rsqrt(mean_c(x^2) + 1e-8) over rows of [M][K]. */
+int contrad_pixelnorm(const float* x, float* y, int M, int K, contrad_stream_t stream);
+/* y[n,h,w,c] = x[n,h,w,c] * s[n,c]: weight modulation moved onto the input channels of the shared-weight conv
+ * (ModulatedConv2d, generator.py:52-60: (scale * W * style) applied to x == conv(x * style, scale * W)). */
+int contrad_nhwc_scale(const float* x, const float* s, float* y, int N, long long HW, int C,
+                       contrad_stream_t stream);
+/* y = sqrt2 * lrelu_0.2( x * demod[n,k] + noise_w[0] * noise[n,h,w] + bias[k] ), in place allowed:
+ * demodulation (generator.py:62-64) + NoiseInjection (:85-94) + FusedLeakyReLU (:113-118) in one pass.
+ * demod / noise may be NULL. */
+int contrad_modconv_epilogue(const float* x, const float* demod, const float* noise, const float* noise_w,
+                             const float* bias, float* y, int N, long long HW, int K, contrad_stream_t stream);
 
 #ifdef __cplusplus
 }

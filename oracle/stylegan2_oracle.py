@@ -165,3 +165,156 @@ def r1_penalty(d_out_fn, images_aug):
     d_real = d_out_fn(xa)
     grad_real, = torch.autograd.grad(outputs=d_real.sum(), inputs=xa, create_graph=True, retain_graph=True)
     return grad_real.pow(2).reshape(grad_real.shape[0], -1).sum(1).mean()
+
+
+# ----------------------------------------------------------------------------------------------
+# Generator (models/gan/stylegan2/generator.py) -- forward only, functional over the state dict
+# ----------------------------------------------------------------------------------------------
+def g_channels(size, small32, channel_multiplier=2):
+    return d_channels(size, small32, channel_multiplier)
+
+
+def equal_linear(x, w, b, lr_mul=1.0, bias_init=0.0, activation=False):
+    """EqualLinear.forward (layers.py:146-153)."""
+    scale = (1 / math.sqrt(w.shape[1])) * lr_mul
+    bias = b * lr_mul + bias_init
+    if activation:
+        return fused_leaky_relu(F.linear(x, w * scale), bias)
+    return F.linear(x, w * scale, bias=bias)
+
+
+def mapping(sd, z, n_mlp=8, lr_mlp=0.01):
+    """PixelNorm + n_mlp x EqualLinear(fused_lrelu) (generator.py:154-160)."""
+    x = z * torch.rsqrt(torch.mean(z ** 2, dim=1, keepdim=True) + 1e-8)
+    for i in range(1, n_mlp + 1):
+        x = equal_linear(x, sd['style.%d.weight' % i], sd['style.%d.bias' % i], lr_mul=lr_mlp, activation=True)
+    return x
+
+
+def modulated_conv(sd, pre, x, style, demodulate=True, upsample=False):
+    """ModulatedConv2d.forward (generator.py:52-82), grouped-conv form as written."""
+    B, cin, H, W = x.shape
+    w = sd[pre + '.weight']
+    _, cout, _, k, _ = w.shape
+    s = equal_linear(style, sd[pre + '.modulation.weight'], sd[pre + '.modulation.bias'], bias_init=1.0)
+    scale = 1 / math.sqrt(cin * k * k)
+    weight = scale * w * s.view(B, 1, cin, 1, 1)
+    if demodulate:
+        demod = torch.rsqrt(weight.pow(2).sum([2, 3, 4]) + 1e-8)
+        weight = weight * demod.view(B, cout, 1, 1, 1)
+    xin = x.reshape(1, B * cin, H, W)
+    if upsample:
+        wt = weight.transpose(1, 2).reshape(B * cin, cout, k, k)
+        out = F.conv_transpose2d(xin, wt, padding=0, stride=2, groups=B)
+        out = out.view(B, cout, out.shape[2], out.shape[3])
+        out = upfirdn2d(out, sd[pre + '.blur.kernel'], pad=(1, 1))
+    else:
+        out = F.conv2d(xin, weight.view(B * cout, cin, k, k), padding=k // 2, groups=B)
+        out = out.view(B, cout, out.shape[2], out.shape[3])
+    return out
+
+
+def styled_layer(sd, pre, x, style, noise, upsample=False):
+    """StyleLayer.forward (generator.py:120-124)."""
+    out = modulated_conv(sd, pre + '.conv', x, style, upsample=upsample)
+    out = out + sd[pre + '.noise.weight'] * noise
+    return fused_leaky_relu(out, sd[pre + '.activate.bias'])
+
+
+def to_rgb(sd, pre, x, style, skip=None):
+    """ToRGB.forward (generator.py:136-144)."""
+    out = modulated_conv(sd, pre + '.conv', x, style, demodulate=False) + sd[pre + '.bias']
+    if skip is not None:
+        out = out + upfirdn2d(skip, sd[pre + '.upsample.kernel'], up=2, pad=(2, 1))
+    return out
+
+
+def g_forward(sd, z, size, noise, mix=None):
+    """Generator.forward in train mode (generator.py:236-291).  noise: list of (B or 1,1,H,W) tensors;
+    mix = (z_mix, mix_layer) reproduces the style-mixing branch (:252-266) with explicit randomness."""
+    log_size = int(math.log2(size))
+    n_latent = log_size * 2 - 2
+    latent = mapping(sd, z)
+    latents = latent.unsqueeze(1).repeat(1, n_latent, 1)
+    if mix is not None:
+        latent_mix = mapping(sd, mix[0]).unsqueeze(1)
+        mask = (torch.arange(n_latent)[None] < mix[1].unsqueeze(1)).float().unsqueeze(-1)
+        latents = latents * mask + latent_mix * (1 - mask)
+    B = z.shape[0]
+    out = sd['input.const'].repeat(B, 1, 1, 1)
+    out = styled_layer(sd, 'conv1', out, latents[:, 0], noise[0])
+    skip = to_rgb(sd, 'to_rgb1', out, latents[:, 1])
+    idx = 1
+    for j in range(log_size - 2):
+        out = styled_layer(sd, 'layers.%d' % (2 * j), out, latents[:, idx], noise[1 + 2 * j], upsample=True)
+        out = styled_layer(sd, 'layers.%d' % (2 * j + 1), out, latents[:, idx + 1], noise[2 + 2 * j])
+        skip = to_rgb(sd, 'to_rgbs.%d' % j, out, latents[:, idx + 2], skip)
+        idx += 2
+    return 0.5 * skip + 0.5
+
+
+def det_fill_g(ref_state, seed=777):
+    """Deterministic fill keyed on the reference generator's state-dict order (names + shapes passed in)."""
+    sd = {}
+    for i, (name, shape) in enumerate(ref_state.items()):
+        g = torch.Generator().manual_seed(seed + i)
+        if name.endswith('kernel'):
+            continue
+        t = torch.randn(*shape, generator=g)
+        if name.endswith('noise.weight'):
+            t = t * 0.1
+        elif name.endswith('bias'):
+            t = t * 0.1
+        elif name.startswith('style.'):
+            t = t * 100.0 if name.endswith('weight') else t       # EqualLinear(lr_mul=0.01): randn / lr_mul
+        sd[name] = t
+    return sd
+
+
+def g_param_shapes(size, small32, channel_multiplier=2, style_dim=512, n_mlp=8):
+    """State-dict names/shapes of the reference Generator, in its registration order."""
+    ch = g_channels(size, small32, channel_multiplier)
+    s = {}
+    for i in range(1, n_mlp + 1):
+        s['style.%d.weight' % i] = (style_dim, style_dim)
+        s['style.%d.bias' % i] = (style_dim,)
+    s['input.const'] = (1, ch[4], 4, 4)
+
+    def modconv(pre, cin, cout, k, upsample):
+        s[pre + '.weight'] = (1, cout, cin, k, k)
+        if upsample:
+            s[pre + '.blur.kernel'] = (4, 4)
+        s[pre + '.modulation.weight'] = (cin, style_dim)
+        s[pre + '.modulation.bias'] = (cin,)
+
+    def styled(pre, cin, cout, upsample):
+        modconv(pre + '.conv', cin, cout, 3, upsample)
+        s[pre + '.noise.weight'] = (1,)
+        s[pre + '.activate.bias'] = (cout,)
+
+    def torgb(pre, cin, upsample):
+        s[pre + '.bias'] = (1, 3, 1, 1)            # own parameter first, then sub-modules (state_dict order)
+        if upsample:
+            s[pre + '.upsample.kernel'] = (4, 4)
+        modconv(pre + '.conv', cin, 3, 1, False)
+
+    styled('conv1', ch[4], ch[4], False)
+    torgb('to_rgb1', ch[4], False)
+    cin = ch[4]
+    log_size = int(math.log2(size))
+    for j, i in enumerate(range(3, log_size + 1)):
+        cout = ch[2 ** i]
+        styled('layers.%d' % (2 * j), cin, cout, True)
+        styled('layers.%d' % (2 * j + 1), cout, cout, False)
+        cin = cout
+    cin = ch[4]
+    for j, i in enumerate(range(3, log_size + 1)):
+        torgb('to_rgbs.%d' % j, ch[2 ** i], True)
+    return s
+
+
+def fill_kernels(sd, shapes):
+    for name in shapes:
+        if name.endswith('blur.kernel') or name.endswith('upsample.kernel'):
+            sd[name] = make_kernel() * 4
+    return sd

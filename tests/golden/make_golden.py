@@ -205,9 +205,11 @@ def gen_sndcgan():
     shapes = O.sndcgan_d_param_shapes()
     ref_shapes = {k: tuple(v.shape) for k, v in D.state_dict().items()}
     assert ref_shapes == shapes, 'D state-dict mismatch'
+    assert list(ref_shapes) == list(shapes), 'D state-dict ORDER'
     gshapes = O.sndcgan_g_param_shapes()
     ref_gshapes = {k: tuple(v.shape) for k, v in G.state_dict().items() if 'num_batches' not in k}
     assert ref_gshapes == gshapes, (set(ref_gshapes) ^ set(gshapes))
+    assert list(ref_gshapes) == list(gshapes), 'G state-dict ORDER' 
 
     sd = O.det_fill(shapes, seed=1234)
     _load_sd(D, sd)
@@ -358,6 +360,7 @@ def gen_stylegan2():
     shapes = S.d_param_shapes(32, True)
     ref_shapes = {kk: tuple(v.shape) for kk, v in D.state_dict().items()}
     assert ref_shapes == shapes, (set(ref_shapes) ^ set(shapes))
+    assert list(ref_shapes) == list(shapes), 'state-dict ORDER'
     sd = S.det_fill_d(shapes, seed=2024)
     D.load_state_dict({kk: v.clone() for kk, v in sd.items()})
     N = 4
@@ -412,8 +415,42 @@ def gen_stylegan2():
     save('stylegan2_d', **out)
 
 
+# ------------------------------------------------------------------------------------------------
+def gen_stylegan2_g():
+    from oracle import stylegan2_oracle as S
+    from models.gan.stylegan2.generator import Generator
+    G = Generator(size=32, n_mlp=8, small32=True)
+    G.train()
+    shapes = {k: tuple(v.shape) for k, v in G.state_dict().items()}
+    assert shapes == S.g_param_shapes(32, True)
+    assert list(shapes) == list(S.g_param_shapes(32, True)), 'state-dict ORDER (the deterministic fill is keyed on it)' 
+    sd = S.fill_kernels(S.det_fill_g(shapes, seed=777), shapes)
+    G.load_state_dict({k: v.clone() for k, v in sd.items()})
+    B = 3
+    g = torch.Generator().manual_seed(41)
+    z = torch.randn(B, 512, generator=g)
+    noise = [torch.randn(B, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), generator=g) for i in range(G.num_layers)]
+    with torch.no_grad():
+        ref0 = G(z, style_mix=0.0, noise=noise)
+        check(S.g_forward(sd, z, 32, noise), ref0, 1e-5, 'G forward (no mixing)')
+        # style mixing: reproduce the reference's draws (CPU generator here: randn, rand, randint in that order)
+        torch.manual_seed(9)
+        ref1 = G(z, style_mix=0.9, noise=noise)
+        torch.manual_seed(9)
+        z_mix = torch.randn(B, 512)
+        nomix = torch.rand(B) >= 0.9
+        mix_layer = torch.randint(G.n_latent, (B,)).masked_fill(nomix, G.n_latent)
+        check(S.g_forward(sd, z, 32, noise, mix=(z_mix, mix_layer)), ref1, 1e-5, 'G forward (mixing)')
+        lat = G.get_latent(z)
+        check(S.mapping(sd, z), lat, 1e-5, 'mapping')
+    out = {'z': z, 'img_nomix': ref0, 'img_mix': ref1, 'z_mix': z_mix, 'mix_layer': mix_layer, 'latent': lat}
+    for i, n in enumerate(noise):
+        out['noise%d' % i] = n
+    save('stylegan2_g', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['losses', 'augment', 'sndcgan', 'adam', 'stylegan2']
+    which = sys.argv[1:] or ['losses', 'augment', 'sndcgan', 'adam', 'stylegan2', 'stylegan2_g']
     for w in which:
         globals()['gen_' + w]()
     print('golden vectors OK')

@@ -164,3 +164,28 @@ def test_r1_step_on_the_same_linear_region(golden):
         ref = osd[k].grad
         e = (prm.grad.cpu() - ref).abs().max().item() / ref.abs().max().clamp_min(1e-30).item()
         assert e < TOL, (k, e)
+
+
+def test_generator_forward_against_reference(golden):
+    """StyleGAN2 generator (row G0): mapping network, modulated convs (input-modulate / output-demodulate form),
+    noise + activation epilogue, ToRGB with upsampled skip; explicit noise, with and without style mixing."""
+    from contrad_amd.models.gan.stylegan2.generator import Generator
+    g = golden('stylegan2_g')
+    G = Generator(size=32, n_mlp=8, small32=True)
+    shapes = S.g_param_shapes(32, True)
+    assert {k: tuple(v.shape) for k, v in G.state_dict().items()} == shapes
+    G.load_state_dict(S.fill_kernels(S.det_fill_g(shapes, seed=777), shapes))
+    G = G.to(DEV).train()
+    z = torch.from_numpy(g['z']).to(DEV)
+    noise = [torch.from_numpy(g['noise%d' % i]).to(DEV) for i in range(G.num_layers)]
+    with torch.no_grad():
+        lat = G._mapping(z, G._prepared())
+        assert rel(lat, g['latent']) < TOL
+        img0 = G(z, style_mix=0.0, noise=noise)
+        assert rel(img0, g['img_nomix']) < TOL
+        img1 = G(z, style_mix=0.9, noise=noise, _mix=(torch.from_numpy(g['z_mix']).to(DEV),
+                                                      torch.from_numpy(g['mix_layer'])))
+        assert rel(img1, g['img_mix']) < TOL
+        # sampling path runs (device RNG for the second latent / noise, CPU RNG for the masks)
+        out = G(G.sample_latent(5))
+        assert out.shape == (5, 3, 32, 32) and torch.isfinite(out).all()
