@@ -116,6 +116,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
   int a_n[PA], a_h[PA], a_w[PA];
   bool a_ok[PA];
   int wg_dn = 0, wg_dh = 0, wg_dw = 0;
+  int wg_pbase = 0;   // WGRAD: first position of the NEXT tile load_a will fetch (advances with the row state)
 
   if constexpr (MODE == MODE_FWD) {
 #pragma unroll
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
     }
   } else {
     const int hw = d.Ho * d.Wo;
+    wg_pbase = p_begin;
     wg_dn = BK / hw;
     const int rem = BK - wg_dn * hw;
     wg_dh = rem / d.Wo;
@@ -190,10 +192,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
   };
 
   // ---------------- global -> register tile loads (no branches, no waits) ----------------
-  auto load_tile = [&](int t) {
+  // A and B are issued separately so the main loop can interleave them with MFMA k-steps.
+  auto load_a_generic = [&](int t) {
     const int k0 = t * BK;
     amask = 0;
-    bmask = 0;
     if constexpr (MODE == MODE_FWD) {
       const int k = k0 + kq * 4;
 #pragma unroll
@@ -215,25 +217,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
           ra[i] = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
-      const int col = n0 + b_c4 * 4;
-#pragma unroll
-      for (int i = 0; i < PB; ++i) {
-        const int kr = k0 + b_r + B_RPP * i;
-        if constexpr (VEC) {
-          const bool ok = kr < Kg && col < Ncol;
-          rb[i] = ld4(p.B + (ok ? (size_t)kr * d.ldw + col : 0));
-          bmask |= (unsigned)ok << i;
-        } else {
-          float v[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const bool ok = kr < Kg && col + j < Ncol;
-            v[j] = p.B[ok ? (size_t)kr * d.ldw + col + j : 0];
-            bmask |= (unsigned)ok << (4 * i + j);
-          }
-          rb[i] = make_float4(v[0], v[1], v[2], v[3]);
-        }
-      }
     } else if constexpr (MODE == MODE_DGRAD) {
       const int k = k0 + kq * 4;
       if constexpr (VEC) {
@@ -247,15 +230,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
           ra[i] = ld4(p.A + (ok ? ((size_t)(a_n[i] * d.Ho + ho) * d.Wo + wo) * d.ldy + co : 0));
           amask |= (unsigned)ok << i;
         }
-#pragma unroll
-        for (int i = 0; i < PB; ++i) {
-          const int c = n0 + krow + 32 * i;
-          const bool ok = kok && c < Ncol;
-          rb[i] = ld4(p.B + (ok ? ((size_t)tapflat * d.C + c) * d.ldw + co : 0));
-          bmask |= (unsigned)ok << i;
-        }
       } else {
-        float va[PA][4], vb[PB][4];
+        float va[PA][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           int th, tw, co, tapflat;
@@ -268,21 +244,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
             va[i][j] = p.A[ok ? ((size_t)(a_n[i] * d.Ho + ho) * d.Wo + wo) * d.ldy + co : 0];
             amask |= (unsigned)ok << (4 * i + j);
           }
-#pragma unroll
-          for (int i = 0; i < PB; ++i) {
-            const int c = n0 + krow + 32 * i;
-            const bool ok = kok && c < Ncol;
-            vb[i][j] = p.B[ok ? ((size_t)tapflat * d.C + c) * d.ldw + co : 0];
-            bmask |= (unsigned)ok << (4 * i + j);
-          }
         }
 #pragma unroll
         for (int i = 0; i < PA; ++i) ra[i] = make_float4(va[i][0], va[i][1], va[i][2], va[i][3]);
-#pragma unroll
-        for (int i = 0; i < PB; ++i) rb[i] = make_float4(vb[i][0], vb[i][1], vb[i][2], vb[i][3]);
       }
     } else {  // WGRAD
-      const int pbase = p_begin + k0;
+      // positions come from the running state (not from t): a repeated call on the last tile then points past
+      // p_end and is fully predicated off instead of pairing tile t's range with tile t+1's coordinates
+      const int pbase = wg_pbase;
+      wg_pbase += BK;
       const int icol = m0 + a_c4 * 4;
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
@@ -311,6 +281,65 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
         if (a_h[i] >= d.Ho) { a_h[i] -= d.Ho; a_n[i] += 1; }
         a_n[i] += wg_dn;
       }
+    }
+  };
+
+  auto load_b_generic = [&](int t) {
+    const int k0 = t * BK;
+    bmask = 0;
+    if constexpr (MODE == MODE_FWD) {
+      const int col = n0 + b_c4 * 4;
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int kr = k0 + b_r + B_RPP * i;
+        if constexpr (VEC) {
+          const bool ok = kr < Kg && col < Ncol;
+          rb[i] = ld4(p.B + (ok ? (size_t)kr * d.ldw + col : 0));
+          bmask |= (unsigned)ok << i;
+        } else {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool ok = kr < Kg && col + j < Ncol;
+            v[j] = p.B[ok ? (size_t)kr * d.ldw + col + j : 0];
+            bmask |= (unsigned)ok << (4 * i + j);
+          }
+          rb[i] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    } else if constexpr (MODE == MODE_DGRAD) {
+      const int k = k0 + kq * 4;
+      if constexpr (VEC) {
+        int th, tw, co, tapflat;
+        dg_decode(k, th, tw, co, tapflat);
+        const bool kok = k < Kg;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+          const int c = n0 + krow + 32 * i;
+          const bool ok = kok && c < Ncol;
+          rb[i] = ld4(p.B + (ok ? ((size_t)tapflat * d.C + c) * d.ldw + co : 0));
+          bmask |= (unsigned)ok << i;
+        }
+      } else {
+        float vb[PB][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int th, tw, co, tapflat;
+          dg_decode(k + j, th, tw, co, tapflat);
+          const bool kok = (k + j) < Kg;
+#pragma unroll
+          for (int i = 0; i < PB; ++i) {
+            const int c = n0 + krow + 32 * i;
+            const bool ok = kok && c < Ncol;
+            vb[i][j] = p.B[ok ? ((size_t)tapflat * d.C + c) * d.ldw + co : 0];
+            bmask |= (unsigned)ok << (4 * i + j);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) rb[i] = make_float4(vb[i][0], vb[i][1], vb[i][2], vb[i][3]);
+      }
+    } else {  // WGRAD
+      const int pbase = p_begin + k0;
       const int col = n0 + b_c4 * 4;
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
@@ -333,6 +362,114 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
     }
   };
 
+  // ---------------- VEC fast path: piecewise, division-free loaders ----------------
+  // Per-row base offsets are computed once; the contraction index of this thread's k-quad is decoded incrementally
+  // (channel offset + tap counters advanced by BK per tile), so one tile's address work is a handful of adds and
+  // compares per row.  The loaders are split into per-row "pieces" that the main loop drops between MFMA k-steps.
+  int a_base[PA], b_base[PB];
+  int st_c = 0, st_h = 0, st_w = 0;      // decode state for the NEXT tile: channel offset, tap row, tap column
+  int cu_c = 0, cu_h = 0, cu_w = 0;      // snapshot for the tile whose pieces are currently being issued
+  bool cu_ok = false;
+  int b_k0 = 0;                          // FWD: first packed-weight row of the next tile; generic: tile counter
+  int gen_t = 0;
+  if constexpr (VEC) {
+    if constexpr (MODE == MODE_FWD) {
+      const int k = kq * 4;
+      const int tap = k / d.C;
+      st_c = k - tap * d.C;
+      st_h = tap / d.KW;
+      st_w = tap - st_h * d.KW;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) a_base[i] = ((a_n[i] * d.H + a_h[i]) * d.W + a_w[i]) * d.ldx;
+#pragma unroll
+      for (int i = 0; i < PB; ++i) b_base[i] = (b_r + B_RPP * i) * d.ldw + n0 + b_c4 * 4;
+    } else if constexpr (MODE == MODE_DGRAD) {
+      const int k = kq * 4;
+      const int ti = k / d.K;
+      st_c = k - ti * d.K;
+      st_h = ti / ntw;
+      st_w = ti - st_h * ntw;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) a_base[i] = ((a_n[i] * d.Ho + a_h[i]) * d.Wo + a_w[i]) * d.ldy;
+#pragma unroll
+      for (int i = 0; i < PB; ++i) b_base[i] = (n0 + krow + 32 * i) * d.ldw;
+    } else {
+#pragma unroll
+      for (int i = 0; i < PB; ++i) b_base[i] = n0 + b_c4 * 4;
+    }
+  }
+
+  // snapshot the decode of the tile about to be loaded and advance the state by BK (called once per tile, before
+  // its first piece).  Past the last tile the tap counters run off the end and everything is predicated off.
+  auto begin_tile = [&]() {
+    if constexpr (VEC && MODE != MODE_WGRAD) {
+      cu_c = st_c; cu_h = st_h; cu_w = st_w;
+      const int cdim = (MODE == MODE_FWD) ? d.C : d.K;
+      const int wdim = (MODE == MODE_FWD) ? d.KW : ntw;
+      cu_ok = (MODE == MODE_FWD) ? (cu_h < d.KH) : (cu_h < nth);
+      st_c += BK;
+      while (st_c >= cdim) {
+        st_c -= cdim;
+        if (++st_w == wdim) { st_w = 0; ++st_h; }
+      }
+    }
+    amask = 0;
+    bmask = 0;
+  };
+
+  auto load_a_piece = [&](int i) {
+    if constexpr (!VEC) {
+      if (i == 0) load_a_generic(gen_t);
+    } else if constexpr (MODE == MODE_FWD) {
+      const int hi = a_h[i] + cu_h, wi = a_w[i] + cu_w;
+      const bool ok = cu_ok && a_ok[i] && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
+      const int off = a_base[i] + (cu_h * d.W + cu_w) * d.ldx + cu_c;
+      ra[i] = ld4(p.A + (ok ? off : 0));
+      amask |= (unsigned)ok << i;
+    } else if constexpr (MODE == MODE_DGRAD) {
+      const int ho = a_h[i] - cu_h, wo = a_w[i] - cu_w;
+      const bool ok = cu_ok && a_ok[i] && (unsigned)ho < (unsigned)d.Ho && (unsigned)wo < (unsigned)d.Wo;
+      const int off = a_base[i] - (cu_h * d.Wo + cu_w) * d.ldy + cu_c;
+      ra[i] = ld4(p.A + (ok ? off : 0));
+      amask |= (unsigned)ok << i;
+    } else {
+      const int pp = wg_pbase + a_r + A_RPP * i;
+      const int icol = m0 + a_c4 * 4;
+      bool ok;
+      const size_t off = wg_a(i, icol, pp < p_end, ok);
+      ra[i] = ld4(p.A + off);
+      amask |= (unsigned)ok << i;
+      a_w[i] += wg_dw;
+      if (a_w[i] >= d.Wo) { a_w[i] -= d.Wo; a_h[i] += 1; }
+      a_h[i] += wg_dh;
+      if (a_h[i] >= d.Ho) { a_h[i] -= d.Ho; a_n[i] += 1; }
+      a_n[i] += wg_dn;
+    }
+  };
+
+  auto load_b_piece = [&](int i) {
+    if constexpr (!VEC) {
+      if (i == 0) { load_b_generic(gen_t); ++gen_t; }
+    } else if constexpr (MODE == MODE_FWD) {
+      const int kr = b_k0 + b_r + B_RPP * i;
+      const bool ok = kr < Kg && (n0 + b_c4 * 4) < Ncol;
+      rb[i] = ld4(p.B + (ok ? b_k0 * d.ldw + b_base[i] : 0));
+      bmask |= (unsigned)ok << i;
+      if (i == PB - 1) b_k0 += BK;
+    } else if constexpr (MODE == MODE_DGRAD) {
+      const int tapflat = (kh0 + d.stride * cu_h) * d.KW + (kw0 + d.stride * cu_w);
+      const bool ok = cu_ok && (n0 + krow + 32 * i) < Ncol;
+      rb[i] = ld4(p.B + (ok ? tapflat * d.C * d.ldw + b_base[i] + cu_c : 0));
+      bmask |= (unsigned)ok << i;
+    } else {
+      const int pp = wg_pbase + b_r + B_RPP * i;
+      const bool ok = pp < p_end && b_base[i] < Ncol;
+      rb[i] = ld4(p.B + (ok ? (size_t)pp * d.ldy + b_base[i] : 0));
+      bmask |= (unsigned)ok << i;
+      if (i == PB - 1) wg_pbase += BK;
+    }
+  };
+
   auto masked = [&](float4 v, unsigned mask, int i) -> float4 {
     if constexpr (VEC) {
       if (!((mask >> i) & 1u)) v = zero4();
@@ -345,35 +482,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
     return v;
   };
 
-  // ---------------- register -> LDS (predicates applied here) ----------------
-  auto store_tile = [&](int buf) {
+  // ---------------- register -> LDS, one row-group per piece (predicates applied here) ----------------
+  auto store_a_piece = [&](int buf, int i) {
     float* As = smem + buf * (A_SZ + B_SZ);
-    float* Bs = As + A_SZ;
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const float4 v = masked(ra[i], amask, i);
-      if constexpr (A_KCONTIG) {
-        const int row = krow + 32 * i;
-        As[(kq * 4 + 0) * LDA + row] = v.x;
-        As[(kq * 4 + 1) * LDA + row] = v.y;
-        As[(kq * 4 + 2) * LDA + row] = v.z;
-        As[(kq * 4 + 3) * LDA + row] = v.w;
-      } else {
-        *reinterpret_cast<float4*>(As + (a_r + A_RPP * i) * LDA + a_c4 * 4) = v;
-      }
+    const float4 v = masked(ra[i], amask, i);
+    if constexpr (A_KCONTIG) {
+      const int row = krow + 32 * i;
+      As[(kq * 4 + 0) * LDA + row] = v.x;
+      As[(kq * 4 + 1) * LDA + row] = v.y;
+      As[(kq * 4 + 2) * LDA + row] = v.z;
+      As[(kq * 4 + 3) * LDA + row] = v.w;
+    } else {
+      *reinterpret_cast<float4*>(As + (a_r + A_RPP * i) * LDA + a_c4 * 4) = v;
     }
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const float4 v = masked(rb[i], bmask, i);
-      if constexpr (B_KCONTIG) {
-        const int row = krow + 32 * i;
-        Bs[(kq * 4 + 0) * LDB + row] = v.x;
-        Bs[(kq * 4 + 1) * LDB + row] = v.y;
-        Bs[(kq * 4 + 2) * LDB + row] = v.z;
-        Bs[(kq * 4 + 3) * LDB + row] = v.w;
-      } else {
-        *reinterpret_cast<float4*>(Bs + (b_r + B_RPP * i) * LDB + b_c4 * 4) = v;
-      }
+  };
+  auto store_b_piece = [&](int buf, int i) {
+    float* Bs = smem + buf * (A_SZ + B_SZ) + A_SZ;
+    const float4 v = masked(rb[i], bmask, i);
+    if constexpr (B_KCONTIG) {
+      const int row = krow + 32 * i;
+      Bs[(kq * 4 + 0) * LDB + row] = v.x;
+      Bs[(kq * 4 + 1) * LDB + row] = v.y;
+      Bs[(kq * 4 + 2) * LDB + row] = v.z;
+      Bs[(kq * 4 + 3) * LDB + row] = v.w;
+    } else {
+      *reinterpret_cast<float4*>(Bs + (b_r + B_RPP * i) * LDB + b_c4 * 4) = v;
     }
   };
 
@@ -388,42 +521,66 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
   const int l31 = lane & 31, lhi = lane >> 5;
 
   if (T > 0) {
-    load_tile(0);
-    store_tile(0);
+    begin_tile();
+#pragma unroll
+    for (int i = 0; i < PA; ++i) load_a_piece(i);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) load_b_piece(i);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) store_a_piece(0, i);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) store_b_piece(0, i);
   }
   __syncthreads();
 
+  // Main loop.  Every wave overlaps its OWN memory work with its OWN MFMA phase (the two waves that share a SIMD run
+  // in lock-step through the shared matrix pipe, so relying on the partner wave to cover the load / LDS-store phases
+  // left the pipe ~30 % idle): the next tile's global loads are dropped, one row-group at a time, between the first
+  // k-steps, its LDS stores (into the other buffer) between the last ones; sched_barriers pin that placement.
+  // There is no "is there a next tile" branch: past the last tile the loaders are predicated off (clamped addresses)
+  // and the stores fill the idle buffer.  (With a branch hipcc cannot pair "loads issued" with "stores executed",
+  // assumes loads may be pending at the back-edge and waits vmcnt right after issuing them.)
+  constexpr int KS = BK / 2;
+  constexpr int A_LD0 = 0, B_LD0 = 4, A_ST0 = KS - 8, B_ST0 = KS - 4;
   for (int t = 0; t < T; ++t) {
     const int cur = t & 1;
-    if (t + 1 < T) load_tile(t + 1);   // in flight during the MFMA phase below
     const float* As = smem + cur * (A_SZ + B_SZ) + wm * WM + l31;
     const float* Bs = smem + cur * (A_SZ + B_SZ) + A_SZ + wn * WN + l31;
-    // software-pipelined operand fetch: fragments of k-step ks+1 are read while the MFMAs of ks execute
     float av[2][TM], bv[2][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) av[0][i] = As[lhi * LDA + i * 32];
 #pragma unroll
     for (int j = 0; j < TN; ++j) bv[0][j] = Bs[lhi * LDB + j * 32];
 #pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const int cb = ks & 1, nb = cb ^ 1;
-      if (ks + 1 < BK / 2) {
+#if !defined(IGEMM_ABLATE_LOADS)
+      if (ks == A_LD0) begin_tile();
+      if (ks >= A_LD0 && ks < A_LD0 + PA) load_a_piece(ks - A_LD0);
+      if (ks >= B_LD0 && ks < B_LD0 + PB) load_b_piece(ks - B_LD0);
+#endif
+      if (ks + 1 < KS) {
         const int k = (ks + 1) * 2 + lhi;
 #pragma unroll
         for (int i = 0; i < TM; ++i) av[nb][i] = As[k * LDA + i * 32];
 #pragma unroll
         for (int j = 0; j < TN; ++j) bv[nb][j] = Bs[k * LDB + j * 32];
       }
-      __builtin_amdgcn_sched_barrier(0);   // keep the next fragments' ds_reads ahead of this step's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][i], bv[cb][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+#if !defined(IGEMM_ABLATE_STORES)
+      if (ks >= A_ST0 && ks < A_ST0 + PA) store_a_piece(cur ^ 1, ks - A_ST0);
+      if (ks >= B_ST0 && ks < B_ST0 + PB) store_b_piece(cur ^ 1, ks - B_ST0);
+#endif
     }
-    if (t + 1 < T) store_tile(cur ^ 1);
+#if !defined(IGEMM_ABLATE_BARRIER)
     __syncthreads();
+#endif
   }
 
   // ---------------- epilogue ----------------
@@ -558,6 +715,10 @@ int check_desc(const contrad_conv_desc* d) {
   CONTRAD_ARG(d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1);
   CONTRAD_ARG(d->ldx >= d->C && d->ldy >= d->K && d->ldw >= d->K);
   CONTRAD_ARG((d->ldw & 3) == 0);
+  // the kernels address elements with 32-bit offsets
+  CONTRAD_ARG((long long)d->N * d->H * d->W * d->ldx < (1ll << 31));
+  CONTRAD_ARG((long long)d->N * d->Ho * d->Wo * d->ldy < (1ll << 31));
+  CONTRAD_ARG((long long)d->KH * d->KW * d->C * d->ldw < (1ll << 31));
   if ((d->C & 3) == 0) CONTRAD_ARG((d->ldx & 3) == 0);
   if ((d->K & 3) == 0) CONTRAD_ARG((d->ldy & 3) == 0);
   return 0;

@@ -78,3 +78,63 @@ def d_step(P, G, D, opt_D, options, images, reducer=None):
     else:
         opt_D.step()
     return d_loss, aux
+
+
+# ----------------------------------------------------------------------------------------------------------
+# StyleGAN2 discriminator steps
+# ----------------------------------------------------------------------------------------------------------
+def r1_loss(D, images, augment_fn):
+    """r1_loss (train_stylegan2.py:106-113): mean_n sum_chw (d D(aug(x)) / d aug(x))^2, differentiable in D's
+    parameters (double backward through the HIP op family of contrad_amd.autograd_ops)."""
+    images_aug = augment_fn(images).detach()
+    images_aug.requires_grad = True
+    d_real = D(images_aug)
+    grad_real, = torch.autograd.grad(outputs=d_real.sum(), inputs=images_aug, create_graph=True, retain_graph=True)
+    return grad_real.pow(2).reshape(grad_real.shape[0], -1).sum(1).mean()
+
+
+def d_step_stylegan2(P, G, D, opt_D, options, images, step, reducer=None, style_mix=0.9):
+    """D-step of train_stylegan2.py:199-212 (BASELINE config 4): single 3N-image D call via loss_D_fn, plus the
+    R1 penalty every ``P.d_reg_every`` steps weighted (0.5*lbd_r1)*r1*d_reg_every (``--no_lazy`` => every step)."""
+    with torch.no_grad():
+        gen_images = G(G.sample_latent(images.size(0)), style_mix=style_mix)
+    d_loss, aux = P.train_fn["D"](P, D, options, images, gen_images)
+    loss = d_loss + aux['penalty']
+    if (step % P.d_reg_every == 0) and P.lbd_r1 > 0:
+        r1 = r1_loss(D, images, P.augment_fn)
+        loss = loss + (0.5 * P.lbd_r1) * r1 * P.d_reg_every
+        aux['r1'] = r1
+    opt_D.zero_grad()
+    loss.backward()
+    world = reducer() if reducer is not None else 1
+    opt_D.step(grad_scale=1.0 / world) if world > 1 else opt_D.step()
+    return d_loss, aux
+
+
+def d_step_stylegan2_contrad(P, G, D, opt_D, options, images, step, reducer=None, style_mix=0.9):
+    """D-step of train_stylegan2_contraD.py:148-164,218-226 (BASELINE config 5): the fakes (N) and the two real
+    views (2N) are augmented SEPARATELY and go through D in two calls; losses on the concatenated embeddings
+    (_loss_D_fn, :95-109); lazy R1 on its own D call."""
+    from .training.gan.contrad import _ContraDContrastive, _GanDLoss
+    N = images.size(0)
+    with torch.no_grad():
+        gen_images = G(G.sample_latent(N), style_mix=style_mix)
+    d_gen, aux_g = D(P.augment_fn(gen_images), sg_linear=True, projection=True, projection2=True)
+    d_real2, aux_r = D(P.augment_fn(torch.cat([images, images], dim=0)), sg_linear=True, projection=True,
+                       projection2=True)
+    proj = torch.cat([aux_r['projection'], aux_g['projection']], dim=0)
+    proj2 = torch.cat([aux_r['projection2'], aux_g['projection2']], dim=0)
+    d_all = torch.cat([d_real2, d_gen], dim=0)
+    simclr, sup = _ContraDContrastive.apply(proj, proj2, N, P.temp, bool(P.distributed))
+    gan, d_real_m, d_gen_m = _GanDLoss.apply(d_all, N, options['loss'])
+    loss = simclr + P.lbd_a * sup + gan
+    aux = {'penalty': gan, 'd_real': d_real_m, 'd_gen': d_gen_m}
+    if (step % P.d_reg_every == 0) and P.lbd_r1 > 0:
+        r1 = r1_loss(D, images, P.augment_fn)
+        loss = loss + (0.5 * P.lbd_r1) * r1 * P.d_reg_every
+        aux['r1'] = r1
+    opt_D.zero_grad()
+    loss.backward()
+    world = reducer() if reducer is not None else 1
+    opt_D.step(grad_scale=1.0 / world) if world > 1 else opt_D.step()
+    return simclr + P.lbd_a * sup, aux

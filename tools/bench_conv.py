@@ -10,8 +10,13 @@ LAYERS = [(32, 64, 128, 4, 2, 1), (16, 128, 128, 3, 1, 1), (16, 128, 256, 4, 2, 
           (8, 256, 512, 4, 2, 1), (4, 512, 512, 3, 1, 1), (1, 8192, 1536, 1, 1, 0)]
 
 
-def timeit(fn, iters=10):
-    for _ in range(3):
+ITERS = int(os.environ.get('CONV_ITERS', '10'))
+WARM = int(os.environ.get('CONV_WARM', '3'))
+
+
+def timeit(fn, iters=None):
+    iters = iters or ITERS
+    for _ in range(WARM):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -27,7 +32,9 @@ def main(B=1536):
     dev = torch.device('cuda')
     tot = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
     totf = 0.0
-    for (H, C, K, k, s, p) in LAYERS:
+    only = os.environ.get('CONV_LAYERS')
+    layers = LAYERS if not only else [LAYERS[int(i)] for i in only.split(',')]
+    for (H, C, K, k, s, p) in layers:
         x = torch.randn(B, H, H, C, device=dev)
         wp = torch.randn(k * k * C, K, device=dev) * 0.05
         Ho = ops.out_size(H, k, s, p)
