@@ -36,6 +36,7 @@ struct IgemmArgs {
   float* C;
   const float* bias;     // FWD
   const float* act_ref;  // DGRAD
+  float* bias_ws;        // WGRAD: [splits][Ncol] partial column sums of gy (bias gradient), or NULL
   contrad_conv_desc d;
   float slope, gain;
   int M, Ncol, Kg;       // FWD / WGRAD gemm dims (DGRAD derives per class)
@@ -496,9 +497,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
       *reinterpret_cast<float4*>(As + (a_r + A_RPP * i) * LDA + a_c4 * 4) = v;
     }
   };
+  // WGRAD bias gradient: the B operand IS gy, so the first M-tile's blocks also accumulate its column sums
+  // (flag multiply instead of a branch keeps the store pieces straight-line).
+  float4 colacc = zero4();
+  const float bias_flag = (MODE == MODE_WGRAD && p.bias_ws != nullptr && tile_m == 0) ? 1.f : 0.f;
   auto store_b_piece = [&](int buf, int i) {
     float* Bs = smem + buf * (A_SZ + B_SZ) + A_SZ;
     const float4 v = masked(rb[i], bmask, i);
+    if constexpr (MODE == MODE_WGRAD && VEC) {
+      colacc.x = fmaf(v.x, bias_flag, colacc.x); colacc.y = fmaf(v.y, bias_flag, colacc.y);
+      colacc.z = fmaf(v.z, bias_flag, colacc.z); colacc.w = fmaf(v.w, bias_flag, colacc.w);
+    }
     if constexpr (B_KCONTIG) {
       const int row = krow + 32 * i;
       Bs[(kq * 4 + 0) * LDB + row] = v.x;
@@ -639,19 +648,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
           }
         }
       }
+    if constexpr (MODE == MODE_WGRAD && VEC) {
+      if (p.bias_ws != nullptr && tile_m == 0) {   // uniform per block
+        // the last (redundant) store piece of the loop added only predicated-off zeros
+        float* red = smem;                           // [B_RPP][BN], main-loop buffers are free after the barrier
+        *reinterpret_cast<float4*>(red + b_r * BN + b_c4 * 4) = colacc;
+        __syncthreads();
+        if (tid < BN) {
+          float sum = 0.f;
+#pragma unroll
+          for (int r = 0; r < B_RPP; ++r) sum += red[r * BN + tid];
+          const int c = n0 + tid;
+          if (c < Ncol) p.bias_ws[(size_t)blockIdx.y * Ncol + c] = sum;
+        }
+      }
+    }
   }
 }
 
 // dwp[i][co] = sum_s ws[s][i][co]   (fixed summation order -> deterministic)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int Kg, int Ncol,
-                                    int ldw, int splits) {
+                                    int ldw, int splits, const float* __restrict__ bias_ws,
+                                    float* __restrict__ dbias) {
   const long long total = (long long)Kg * Ncol;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+  const long long ext = total + (dbias ? Ncol : 0);
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ext;
        e += (long long)gridDim.x * blockDim.x) {
     float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += ws[(long long)k * total + e];
-    const int i = (int)(e / Ncol), c = (int)(e - (long long)i * Ncol);
-    out[(size_t)i * ldw + c] = s;
+    if (e < total) {
+      for (int k = 0; k < splits; ++k) s += ws[(long long)k * total + e];
+      const int i = (int)(e / Ncol), c = (int)(e - (long long)i * Ncol);
+      out[(size_t)i * ldw + c] = s;
+    } else {
+      const int c = (int)(e - total);
+      for (int k = 0; k < splits; ++k) s += bias_ws[(long long)k * Ncol + c];
+      dbias[c] = s;
+    }
   }
 }
 
@@ -807,11 +839,11 @@ extern "C" long long contrad_conv2d_wgrad_workspace_bytes(const contrad_conv_des
   if (check_desc(d)) return -22;
   int bm, bn, tm, tn, splits, pps;
   wgrad_plan(d, &bm, &bn, &tm, &tn, &splits, &pps);
-  return (long long)splits * d->KH * d->KW * d->C * d->K * (long long)sizeof(float);
+  return (long long)splits * ((long long)d->KH * d->KW * d->C + 1) * d->K * (long long)sizeof(float);
 }
 
 extern "C" int contrad_conv2d_wgrad(const contrad_conv_desc* d, const float* x, const float* gy,
-                                    float* dwp, float* workspace, long long workspace_bytes,
+                                    float* dwp, float* dbias, float* workspace, long long workspace_bytes,
                                     contrad_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
@@ -822,6 +854,9 @@ extern "C" int contrad_conv2d_wgrad(const contrad_conv_desc* d, const float* x, 
   wgrad_plan(d, &bm, &bn, &a.tiles_m, &a.tiles_n, &splits, &pps);
   a.A = x; a.B = gy; a.C = workspace; a.d = *d;
   a.M = d->KH * d->KW * d->C; a.Ncol = d->K; a.Kg = a.M;
+  const bool fused_bias = dbias != nullptr && vec_ok(d, MODE_WGRAD);
+  CONTRAD_ARG(dbias == nullptr || fused_bias);   // the fused bias gradient needs the float4 path
+  a.bias_ws = fused_bias ? workspace + (size_t)splits * a.M * a.Ncol : nullptr;
   const long long P = (long long)d->N * d->Ho * d->Wo;
   CONTRAD_ARG(P < (1ll << 31) - 4096);
   a.P = (int)P; a.ptiles_per_split = pps;
@@ -832,7 +867,7 @@ extern "C" int contrad_conv2d_wgrad(const contrad_conv_desc* d, const float* x, 
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, workspace, dwp,
-                     a.M, a.Ncol, d->ldw, splits);
+                     a.M, a.Ncol, d->ldw, splits, a.bias_ws, fused_bias ? dbias : nullptr);
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }

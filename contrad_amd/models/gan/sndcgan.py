@@ -171,14 +171,17 @@ class _DFunction(torch.autograd.Function):
             ops.conv2d_dgrad(g, wps[li], (B, 1, 1, dh), 1, 1, 1, 0, act_ref=hs, slope=_SLOPE, gain=1.0,
                              out=g_hidden[..., j * dh:(j + 1) * dh])
             if need_params:
-                ops.conv2d_wgrad(hs, g, 1, 1, 1, 0, out=gwps[li])
-                ops.colstats(ops.as_rows(g), out=gbias[li].view(1, -1))
+                if g.shape[3] % 4 == 0:
+                    ops.conv2d_wgrad(hs, g, 1, 1, 1, 0, out=gwps[li], dbias=gbias[li])
+                else:                                     # the 1-wide logit layer takes the scalar path
+                    ops.conv2d_wgrad(hs, g, 1, 1, 1, 0, out=gwps[li])
+                    ops.colstats(ops.as_rows(g), out=gbias[li].view(1, -1))
         # ---- heads, first (merged) layer ----
         if need_params:
-            ops.conv2d_wgrad(a6.view(B, 1, 1, plan.feat), g_hidden, 1, 1, 1, 0, out=gmerged)
-            gb_hidden = ops.colstats(ops.as_rows(g_hidden))
+            gb_hidden = torch.empty(3 * dh, device=dev, dtype=torch.float32)
+            ops.conv2d_wgrad(a6.view(B, 1, 1, plan.feat), g_hidden, 1, 1, 1, 0, out=gmerged, dbias=gb_hidden)
             for j in range(3):
-                gbias[7 + j].copy_(gb_hidden[0, j * dh:(j + 1) * dh])
+                gbias[7 + j].copy_(gb_hidden[j * dh:(j + 1) * dh])
         g = None
         if ctx.trunk_grad:
             lo = dh if ctx.sg_linear else 0
@@ -192,9 +195,8 @@ class _DFunction(torch.autograd.Function):
             # ---- trunk ----
             for i in range(6, 0, -1):
                 ci, co, k, s, p = _D_CONVS[i]
-                if need_params:
-                    ops.colstats(ops.as_rows(g), out=gbias[i].view(1, -1))
-                    ops.conv2d_wgrad(acts[i - 1], g, k, k, s, p, out=gwps[i])
+                if need_params:     # weight gradient + bias gradient (column sums of g) in one kernel
+                    ops.conv2d_wgrad(acts[i - 1], g, k, k, s, p, out=gwps[i], dbias=gbias[i])
                 g = ops.conv2d_dgrad(g, wps[i], tuple(acts[i - 1].shape), k, k, s, p, act_ref=acts[i - 1],
                                      slope=_SLOPE, gain=1.0)
             if need_params:

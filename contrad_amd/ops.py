@@ -141,8 +141,8 @@ def _workspace(nbytes, device):
     return buf
 
 
-def conv2d_wgrad(x, gy, KH, KW, stride, pad, ldw=None, out=None):
-    """Returns dwp packed (KH*KW*C, ldw)."""
+def conv2d_wgrad(x, gy, KH, KW, stride, pad, ldw=None, out=None, dbias=None):
+    """Returns dwp packed (KH*KW*C, ldw); optionally also writes the bias gradient sum(gy) into ``dbias`` (K,)."""
     _chk(x, 'x'); _chk(gy, 'gy')
     N, H, W, C = x.shape
     K = gy.shape[3]
@@ -155,7 +155,7 @@ def conv2d_wgrad(x, gy, KH, KW, stride, pad, ldw=None, out=None):
     if nbytes < 0:
         raise RuntimeError('contrad_hip: bad conv descriptor (%d)' % nbytes)
     ws = _workspace(nbytes, x.device)
-    _conv_call(2, d, 'contrad_conv2d_wgrad', ctypes.byref(d), _p(x), _p(gy), _p(out), _p(ws),
+    _conv_call(2, d, 'contrad_conv2d_wgrad', ctypes.byref(d), _p(x), _p(gy), _p(out), _p(dbias), _p(ws),
                ctypes.c_longlong(ws.numel() * 4), _stream())
     return out
 

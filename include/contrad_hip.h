@@ -57,13 +57,15 @@ int contrad_conv2d_dgrad(const contrad_conv_desc* d, const float* gy, const floa
                          const float* act_ref, float slope, float gain, contrad_stream_t stream);
 
 /* dwp[(kh,kw,c),k] = sum_{n,ho,wo} x[n,ho*s-p+kh,wo*s-p+kw,c] * gy[n,ho,wo,k]      (split over the
- * n*ho*wo axis into deterministic partial slabs in `workspace`, then reduced in fixed order). */
+ * n*ho*wo axis into deterministic partial slabs in `workspace`, then reduced in fixed order).
+ * dbias (may be NULL; needs C, K, ldx, ldy multiples of 4): dbias[k] = sum_{n,ho,wo} gy[n,ho,wo,k], the bias
+ * gradient, accumulated for free from the gy tiles the kernel streams anyway. */
 long long contrad_conv2d_wgrad_workspace_bytes(const contrad_conv_desc* d);
 /* Introspection for profiling: block tile (bm x bn x 32) the launcher picks for `mode` (0 fwd, 1 dgrad,
  * 2 wgrad) on this geometry, i.e. which igemm_kernel<mode, bm, bn> instance runs. */
 int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm, int* bn);
 int contrad_conv2d_wgrad(const contrad_conv_desc* d, const float* x, const float* gy, float* dwp,
-                         float* workspace, long long workspace_bytes, contrad_stream_t stream);
+                         float* dbias, float* workspace, long long workspace_bytes, contrad_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Contrastive losses: fused pairwise-cosine + log-sum-exp, S = Z Z^T / temp never written to HBM.

@@ -63,9 +63,13 @@ def test_conv_fwd_dgrad_wgrad(case):
     dx = ops.conv2d_dgrad(gy_nhwc, wp, (N, H, W, C), k, k, s, p)
     assert rel(dx.permute(0, 3, 1, 2).cpu(), gx_ref) < TOL
 
-    dwp = ops.conv2d_wgrad(x_nhwc, gy_nhwc, k, k, s, p)
+    fused_bias = (C % 4 == 0 and K % 4 == 0)
+    db = torch.zeros(K, device=dev) if fused_bias else None
+    dwp = ops.conv2d_wgrad(x_nhwc, gy_nhwc, k, k, s, p, dbias=db)
     dw = ops.unpack_weight(dwp.cpu(), K, C, k, k)
     assert rel(dw, gw_ref) < TOL
+    if fused_bias:      # bias gradient accumulated from the gy tiles the wgrad kernel streams anyway
+        assert rel(db.cpu(), gy.sum((0, 2, 3))) < TOL
 
 
 def test_dgrad_fused_activation_derivative():
