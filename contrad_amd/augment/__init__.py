@@ -30,6 +30,24 @@ def _jitter_range(value, center=1.0, clip_first_on_zero=True):
     return [lo, hi]
 
 
+class _SimCLRFn(torch.autograd.Function):
+    """Differentiable (w.r.t. the images) fused augmentation for the generator step: gradient flows through the
+    bilinear crop/flip gather, the contrast stage and -- as an identity, like RandomHSVFunction.backward
+    (augment/color_jitter.py:97-104) -- through the HSV jitter."""
+
+    @staticmethod
+    def forward(ctx, x, Pd, contrast_first, has_contrast):
+        ctx.save_for_backward(x, Pd)
+        ctx.cfg = (contrast_first, has_contrast)
+        return ops.simclr_augment(x, Pd, contrast_first, has_contrast)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, Pd = ctx.saved_tensors
+        cf, hc = ctx.cfg
+        return ops.simclr_augment_bwd(x, Pd, g, cf, hc), None, None, None
+
+
 class SimCLRAugment(nn.Module):
     """RandomResizeCrop -> HorizontalFlip -> RandomApply(ColorJitter, 0.8) -> RandomApply(Gray, 0.2)
     [-> RandomApply(GaussianBlur, 0.5)] as one module; maps NCHW float [0,1] to the same shape."""
@@ -110,10 +128,12 @@ class SimCLRAugment(nn.Module):
 
     def apply(self, inputs, P, contrast_first, sigma=None):
         """Deterministic device part."""
+        Pd = P.to(inputs.device, non_blocking=True)
         if inputs.requires_grad and torch.is_grad_enabled():
-            raise NotImplementedError('augmentation backward (G-step) is scope row N1 -- not built yet')
+            if sigma is not None:
+                raise NotImplementedError('backward through simclr_hq (large images / blur) is scope row N2')
+            return _SimCLRFn.apply(inputs.contiguous().float(), Pd, contrast_first, self.r_c is not None)
         x = inputs.detach().contiguous().float()
-        Pd = P.to(x.device, non_blocking=True)
         out = ops.simclr_augment(x, Pd, contrast_first, self.r_c is not None)
         if sigma is not None:
             radius, g = self.blur_kernel(x.shape[2], sigma)

@@ -160,6 +160,108 @@ __global__ __launch_bounds__(256) void simclr_small_kernel(AugArgs a) {
   }
 }
 
+// ---------------- backward of the small-image pipeline (generator step: d loss / d input images) ----------------
+// One block per image.  The crop+flip gather is separable (axis-aligned affine grid), so its transpose is
+// dX = Wy^T * dC * Wx with sparse H x H / W x W interpolation matrices built in LDS -- deterministic, no atomics.
+// Colour stages: RandomApply blends are selects; HSV is straight-through (RandomHSVFunction.backward,
+// color_jitter.py:97-104); contrast y = clamp((x-mu)f+mu) gives dx = f*gm + (1-f)*mean(gm), gm = g*[0<=pre<=1];
+// gray gives dx_c = w_c * sum_c' g_c'.  Forward intermediates are recomputed from the saved input.
+__global__ __launch_bounds__(256) void simclr_small_bwd_kernel(AugArgs a, const float* __restrict__ gout,
+                                                               float* __restrict__ gin) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float red[16];
+  __shared__ float mean[3], gmean[3];
+  const int n = blockIdx.x;
+  const int H = a.H, W = a.W, HW = H * W;
+  float* cimg = lds;               // [3][HW] forward crop(+hsv) output = contrast input
+  float* g = cimg + 3 * HW;        // [3][HW] running gradient
+  float* Wy = g + 3 * HW;          // [H][H]  Wy[i][y]
+  float* Wx = Wy + H * H;          // [W][W]  Wx[j][x]
+  float* T = Wx + W * W;           // [HW]
+  const float* pr = a.params + (size_t)n * NPARAM;
+  const float* src = a.x + (size_t)n * 3 * HW;
+  const bool jitter = pr[5] != 0.f, gray = pr[10] != 0.f;
+  const float fc = pr[6], fh = pr[7], fs = pr[8], fv = pr[9];
+
+  for (int e = threadIdx.x; e < H * H + W * W; e += blockDim.x) Wy[e] = 0.f;
+  __syncthreads();
+  // interpolation matrices (row i of Wy: the <= 2 source rows of output row i; likewise columns)
+  for (int i = threadIdx.x; i < H; i += blockDim.x) {
+    const Sampler s = make_sampler(pr, i, 0, H, W);
+    if (s.vy0) Wy[i * H + s.y0] += s.wy0;
+    if (s.vy1) Wy[i * H + s.y1] += s.wy1;
+  }
+  for (int j = threadIdx.x; j < W; j += blockDim.x) {
+    const Sampler s = make_sampler(pr, 0, j, H, W);
+    if (s.vx0) Wx[j * W + s.x0] += s.wx0;
+    if (s.vx1) Wx[j * W + s.x1] += s.wx1;
+  }
+  // forward recompute + load the incoming gradient (through the gray blend)
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    const int i = p / W, j = p - i * W;
+    const Sampler s = make_sampler(pr, i, j, H, W);
+    float r = sample_plane(src, s, W), gg = sample_plane(src + HW, s, W), b = sample_plane(src + 2 * HW, s, W);
+    if (jitter && !a.contrast_first) hsv_jitter(r, gg, b, fh, fs, fv);
+    cimg[p] = r; cimg[HW + p] = gg; cimg[2 * HW + p] = b;
+    const float* go = gout + (size_t)n * 3 * HW;
+    float g0 = go[p], g1 = go[HW + p], g2 = go[2 * HW + p];
+    if (gray) {
+      const float sum = g0 + g1 + g2;
+      g0 = 0.299f * sum; g1 = 0.587f * sum; g2 = 0.114f * sum;
+    }
+    g[p] = g0; g[HW + p] = g1; g[2 * HW + p] = g2;
+  }
+  __syncthreads();
+  if (jitter) {   // uniform per block
+    // HSV is straight-through in either order, so only the contrast stage transforms the gradient
+    for (int c = 0; c < 3; ++c) {
+      float sm = 0.f;
+      if (a.has_contrast)
+        for (int p = threadIdx.x; p < HW; p += blockDim.x) sm += cimg[c * HW + p];
+      sm = block_sum(sm, red);
+      if (threadIdx.x == 0) mean[c] = sm / (float)HW;
+    }
+    __syncthreads();
+    for (int c = 0; c < 3; ++c) {
+      float sm = 0.f;
+      for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+        const float x = cimg[c * HW + p];
+        const float pre = a.has_contrast ? (x - mean[c]) * fc + mean[c] : x;
+        const float gm = (pre >= 0.f && pre <= 1.f) ? g[c * HW + p] : 0.f;   // torch.clamp backward
+        g[c * HW + p] = gm;
+        sm += gm;
+      }
+      sm = block_sum(sm, red);
+      if (threadIdx.x == 0) gmean[c] = sm / (float)HW;
+    }
+    __syncthreads();
+    if (a.has_contrast)
+      for (int e = threadIdx.x; e < 3 * HW; e += blockDim.x) {
+        const int c = e / HW;
+        g[e] = fc * g[e] + (1.f - fc) * gmean[c];
+      }
+    __syncthreads();
+  }
+  // dX_c = Wy^T * G_c * Wx
+  float* gi = gin + (size_t)n * 3 * HW;
+  for (int c = 0; c < 3; ++c) {
+    for (int e = threadIdx.x; e < HW; e += blockDim.x) {      // T[i][x] = sum_j G[i][j] Wx[j][x]
+      const int i = e / W, x = e - i * W;
+      float acc = 0.f;
+      for (int j = 0; j < W; ++j) acc = fmaf(g[c * HW + i * W + j], Wx[j * W + x], acc);
+      T[e] = acc;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < HW; e += blockDim.x) {      // dX[y][x] = sum_i Wy[i][y] T[i][x]
+      const int y = e / W, x = e - y * W;
+      float acc = 0.f;
+      for (int i = 0; i < H; ++i) acc = fmaf(Wy[i * H + y], T[i * W + x], acc);
+      gi[c * HW + e] = acc;
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------- large images ----------------
 // pass 1: per-(image, channel) sums of the contrast input; partial[n][blockIdx.y][3]
 __global__ __launch_bounds__(256) void simclr_stats_kernel(AugArgs a, float* __restrict__ partial) {
@@ -309,6 +411,18 @@ extern "C" int contrad_simclr_augment(const float* x, float* y, const float* par
   hipLaunchKernelGGL(simclr_stats_kernel, dim3(B, nparts), dim3(256), 0, s, a, workspace);
   CONTRAD_CHECK_LAUNCH();
   hipLaunchKernelGGL(simclr_apply_kernel, dim3(B, nparts), dim3(256), 0, s, a, workspace, nparts);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int contrad_simclr_augment_bwd(const float* x, const float* params, const float* grad_out,
+                                          float* grad_in, int B, int H, int W, int contrast_first,
+                                          int has_contrast, contrad_stream_t stream) {
+  CONTRAD_ARG(x && params && grad_out && grad_in && B > 0 && H > 1 && W > 1);
+  const size_t smem = (size_t)(7 * H * W + H * H + W * W) * sizeof(float);
+  CONTRAD_ARG(smem <= 64 * 1024);   // small-image path (<= 44x44); larger images: not built (scope row N2)
+  AugArgs a{x, nullptr, params, B, H, W, contrast_first, has_contrast};
+  hipLaunchKernelGGL(simclr_small_bwd_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, a, grad_out, grad_in);
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }

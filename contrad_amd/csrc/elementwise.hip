@@ -106,6 +106,76 @@ __global__ void bn_relu_apply_kernel(const float* __restrict__ x, float* __restr
   }
 }
 
+// ---- BatchNorm(train) + ReLU backward ----
+// pass 1 (two-stage, deterministic): per channel S1 = sum dyM, S2 = sum dyM * xhat, dyM = dy * [y > 0]
+// thread (tx, ty) layout as colstats_partial_kernel
+__global__ __launch_bounds__(256) void bn_relu_bwd_stats_kernel(const float* __restrict__ dy,
+                                                                const float* __restrict__ x, long long M, int K,
+                                                                int ld, const float* __restrict__ stats, float count,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps,
+                                                                int rows_per_block, float* __restrict__ partial) {
+  __shared__ float red[4][64 * COLS_PER_THREAD + 1];
+  __shared__ float red2[4][64 * COLS_PER_THREAD + 1];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int cbase = blockIdx.y * 64 * COLS_PER_THREAD;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
+  float s[COLS_PER_THREAD], q[COLS_PER_THREAD], mu[COLS_PER_THREAD], rs[COLS_PER_THREAD], ga[COLS_PER_THREAD],
+      be[COLS_PER_THREAD];
+#pragma unroll
+  for (int j = 0; j < COLS_PER_THREAD; ++j) {
+    s[j] = 0.f; q[j] = 0.f;
+    const int c = cbase + tx + 64 * j;
+    if (c < K) {
+      mu[j] = stats[c] / count;
+      rs[j] = rsqrtf(fmaxf(stats[K + c] / count - mu[j] * mu[j], 0.f) + eps);
+      ga[j] = gamma[c]; be[j] = beta[c];
+    } else { mu[j] = 0.f; rs[j] = 0.f; ga[j] = 0.f; be[j] = 0.f; }
+  }
+  for (long long r = r0 + ty; r < r1; r += 4) {
+#pragma unroll
+    for (int j = 0; j < COLS_PER_THREAD; ++j) {
+      const int c = cbase + tx + 64 * j;
+      if (c < K) {
+        const float xh = (x[r * ld + c] - mu[j]) * rs[j];
+        const float g = (xh * ga[j] + be[j] > 0.f) ? dy[r * ld + c] : 0.f;
+        s[j] += g;
+        q[j] = fmaf(g, xh, q[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < COLS_PER_THREAD; ++j) { red[ty][tx + 64 * j] = s[j]; red2[ty][tx + 64 * j] = q[j]; }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * COLS_PER_THREAD; e += blockDim.x) {
+    const int c = cbase + e;
+    if (c < K) {
+      partial[((size_t)blockIdx.x * 2 + 0) * K + c] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+      partial[((size_t)blockIdx.x * 2 + 1) * K + c] = red2[0][e] + red2[1][e] + red2[2][e] + red2[3][e];
+    }
+  }
+}
+
+// pass 2: dx = gamma * rstd * (dyM - S1/n - xhat * S2/n)
+__global__ void bn_relu_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                         float* __restrict__ dx, long long M, int K, int ld,
+                                         const float* __restrict__ stats, float count,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                         const float* __restrict__ bstats) {
+  const long long total = M * K;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const long long r = e / K;
+    const int c = (int)(e - r * K);
+    const float mean = stats[c] / count;
+    const float rstd = rsqrtf(fmaxf(stats[K + c] / count - mean * mean, 0.f) + eps);
+    const float xh = (x[r * ld + c] - mean) * rstd;
+    const float g = (xh * gamma[c] + beta[c] > 0.f) ? dy[r * ld + c] : 0.f;
+    dx[r * ld + c] = gamma[c] * rstd * (g - bstats[c] / count - xh * bstats[K + c] / count);
+  }
+}
+
 __global__ void bn_running_update_kernel(const float* __restrict__ stats, float count, int K,
                                          const float* __restrict__ conv_bias, float momentum,
                                          float* __restrict__ running_mean, float* __restrict__ running_var) {
@@ -244,6 +314,36 @@ extern "C" int contrad_bn_relu_apply(const float* x, float* y, long long M, int 
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(bn_relu_apply_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, x, y, M, K, ldx,
                      ldy, stats, count, gamma, beta, eps, perm_hw);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int contrad_bn_relu_bwd_stats(const float* dy, const float* x, long long M, int K, int ld,
+                                         const float* stats, float count, const float* gamma, const float* beta,
+                                         float eps, float* out2k, float* workspace, long long workspace_bytes,
+                                         contrad_stream_t stream) {
+  CONTRAD_ARG(dy && x && stats && gamma && beta && out2k && workspace && M > 0 && K > 0 && ld >= K);
+  CONTRAD_ARG(workspace_bytes >= contrad_colstats_workspace_bytes(M, K, 1));
+  int rpb, nb;
+  colstats_plan(M, &rpb, &nb);
+  dim3 grid(nb, cdiv(K, 64 * COLS_PER_THREAD));
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_relu_bwd_stats_kernel, grid, dim3(256), 0, s, dy, x, M, K, ld, stats, count, gamma, beta,
+                     eps, rpb, workspace);
+  CONTRAD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colstats_reduce_kernel, dim3(cdiv(2 * K, 64)), dim3(256), 0, s, workspace, nb, 2, K, out2k, 0);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int contrad_bn_relu_bwd_apply(const float* dy, const float* x, float* dx, long long M, int K, int ld,
+                                         const float* stats, float count, const float* gamma, const float* beta,
+                                         float eps, const float* bstats, contrad_stream_t stream) {
+  CONTRAD_ARG(dy && x && dx && stats && gamma && beta && bstats && M > 0 && K > 0 && ld >= K);
+  long long grid = (M * K + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, dy, x, dx, M, K,
+                     ld, stats, count, gamma, beta, eps, bstats);
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }

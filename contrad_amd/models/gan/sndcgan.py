@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.distributed as dist
 
 from ... import ops
+from ... import autograd_ops as A
 from .base import BaseDiscriminator, SNParams, TinyHead, _Act, make_projection
 
 # (cin, cout, k, stride, pad) -- reference sndcgan.py:91-109
@@ -285,6 +286,44 @@ class BNParams(nn.Module):
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
 
 
+def _sync_on(flag):
+    return flag and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class _BNReLUFn(torch.autograd.Function):
+    """BatchNorm (train mode, batch statistics; SyncBN across ranks) + ReLU on an (M, K) row matrix, forward and
+    first-order backward on the HIP kernels (nn.BatchNorm2d + ReLU of G_SNDCGAN, sndcgan.py:25-35,43)."""
+
+    @staticmethod
+    def forward(ctx, x2d, gamma, beta, bn, conv_bias, sync):
+        x2d = x2d.contiguous()
+        stats = ops.colstats(x2d, with_sq=True)
+        count = float(x2d.shape[0])
+        if _sync_on(sync):
+            dist.all_reduce(stats)
+            count *= dist.get_world_size()
+        if bn.training:
+            ops.bn_running_update(stats, count, conv_bias, bn.momentum, bn.running_mean, bn.running_var)
+            bn.num_batches_tracked += 1
+        y = torch.empty_like(x2d)
+        ops.bn_relu_apply(x2d, y, stats, count, gamma, beta, bn.eps)
+        ctx.save_for_backward(x2d, stats, gamma, beta)
+        ctx.cfg = (count, bn.eps, sync)
+        ctx.cb_shape = tuple(conv_bias.shape) if (conv_bias is not None and conv_bias.requires_grad) else None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, stats, gamma, beta = ctx.saved_tensors
+        count, eps, sync = ctx.cfg
+        red = (lambda t: dist.all_reduce(t)) if _sync_on(sync) else None
+        dx, dgamma, dbeta = ops.bn_relu_bwd(dy.contiguous(), x2d, stats, count, gamma, beta, eps, red)
+        # a bias added in front of a batch-statistics BatchNorm cancels exactly: its true gradient is zero (the
+        # reference's autograd returns ~1e-9 round-off noise here); hand Adam an exact zero instead of None
+        dcb = torch.zeros(ctx.cb_shape, device=dy.device, dtype=dy.dtype) if ctx.cb_shape is not None else None
+        return dx, dgamma, dbeta, None, dcb, None
+
+
 class _WB(nn.Module):
     def __init__(self, wshape, nbias):
         super().__init__()
@@ -353,10 +392,42 @@ class G_SNDCGAN(nn.Module):
             bn.num_batches_tracked += 1
         ops.bn_relu_apply(x2d, out2d, stats, count, bn.weight, bn.bias, bn.eps, perm_hw)
 
+    def _forward_with_grad(self, z):
+        """Generator step (train_gan.py:173-176): the same network out of differentiable HIP nodes -- transposed
+        convs are ConvDgradFn (whose backward is the conv forward / wgrad kernels), BatchNorm+ReLU is _BNReLUFn."""
+        N = z.shape[0]
+        hb, wb = self.s_hb, self.s_wb
+        f = 512 * hb * wb
+        entries = [(f, self.nz, 1, 1.0, 0, 0)]
+        groups = [(self.nz, f)]
+        ws = [self.linear.weight]
+        for j, (ci, co, k, s, p) in enumerate(self._CONVT):
+            groups.append((k * k * co, ci))
+            entries.append((ci, co, k * k, 1.0, j + 1, 0))
+            ws.append(self.main[3 * j].weight)
+        wp = A.PackWeightsFn.apply(A.PackMeta(entries, groups), *ws)
+        z = z.contiguous().float()
+        h0 = A.ConvBiasActFn.apply(z.view(N, 1, 1, self.nz), wp[0], self.linear.bias, (f, 1, 1, 1, 0), 1.0, 1.0)
+        y0 = _BNReLUFn.apply(h0.view(N, f), self.norm_init.weight, self.norm_init.bias, self.norm_init, None,
+                             self.sync_bn)
+        x = y0.view(N, 512, hb, wb).permute(0, 2, 3, 1).contiguous()
+        for j in range(3):
+            ci, co, k, s, p = self._CONVT[j]
+            H, W = x.shape[1], x.shape[2]
+            y = A.ConvDgradFn.apply(x, wp[1 + j], (N, 2 * H, 2 * W, co), (ci, k, k, s, p))
+            bn = self.main[3 * j + 1]
+            y2 = _BNReLUFn.apply(y.view(-1, co), bn.weight, bn.bias, bn, self.main[3 * j].bias, self.sync_bn)
+            x = y2.view(N, 2 * H, 2 * W, co)
+        lin = A.RgbDgradFn.apply(x, wp[4], 3, (3, 1.0))
+        return 0.5 * torch.tanh(lin + self.main[9].bias.view(1, 3, 1, 1)) + 0.5
+
     def forward(self, z):
+        if not z.is_cuda:
+            raise RuntimeError('contrad_amd.G_SNDCGAN runs on the MI355X HIP path only (no CPU fallback)')
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError('generator backward (G-step) is scope row N1 -- not built yet; call under '
-                                      'torch.no_grad() / set_grad(G, False) as the discriminator step does')
+            if not self.training:
+                raise NotImplementedError('eval-mode BatchNorm (running statistics) is not on the training path')
+            return self._forward_with_grad(z)
         if not self.training:
             raise NotImplementedError('eval-mode BatchNorm (running statistics) is not on the D-step path')
         if not z.is_cuda:

@@ -484,3 +484,32 @@ def modconv_epilogue_(x, demod, noise, noise_w, bias):
     lib().call('contrad_modconv_epilogue', _p(x), _p(demod), _p(noise), _p(noise_w), _p(bias), _p(x), N,
                ctypes.c_longlong(H * W), K, _stream())
     return x
+
+
+def simclr_augment_bwd(x, params, grad_out, contrast_first, has_contrast):
+    B, C, H, W = x.shape
+    gin = torch.empty_like(x)
+    lib().call('contrad_simclr_augment_bwd', _p(x), _p(params), _p(grad_out.contiguous()), _p(gin), B, H, W,
+               int(contrast_first), int(has_contrast), _stream())
+    return gin
+
+
+def bn_relu_bwd(dy2d, x2d, stats, count, gamma, beta, eps, reduce_fn=None):
+    """Returns (dx2d, dgamma, dbeta).  reduce_fn(out2k) -> global count multiplier hook for SyncBN."""
+    M, K = x2d.shape
+    ld = _ld(x2d)
+    if _ld(dy2d) != ld:
+        raise RuntimeError('contrad_hip: dy and x must share the leading dimension')
+    out = torch.empty((2, K), device=x2d.device, dtype=torch.float32)
+    nbytes = lib().raw('contrad_colstats_workspace_bytes')(ctypes.c_longlong(M), K, 1)
+    ws = _workspace(nbytes, x2d.device)
+    lib().call('contrad_bn_relu_bwd_stats', _p(dy2d), _p(x2d), ctypes.c_longlong(M), K, ld, _p(stats), float(count),
+               _p(gamma), _p(beta), float(eps), _p(out), _p(ws), ctypes.c_longlong(ws.numel() * 4), _stream())
+    if reduce_fn is not None:
+        reduce_fn(out)
+    dx = torch.empty_like(x2d)
+    if _ld(dx) != ld:
+        raise RuntimeError('contrad_hip: bn backward expects dense rows')
+    lib().call('contrad_bn_relu_bwd_apply', _p(dy2d), _p(x2d), _p(dx), ctypes.c_longlong(M), K, ld, _p(stats),
+               float(count), _p(gamma), _p(beta), float(eps), _p(out), _stream())
+    return dx, out[1], out[0]

@@ -160,6 +160,15 @@ int contrad_colstats(const float* x, long long M, int K, int ld, int with_sq, fl
 int contrad_bn_relu_apply(const float* x, float* y, long long M, int K, int ldx, int ldy, const float* stats,
                           float count, const float* gamma, const float* beta, float eps, int perm_hw,
                           contrad_stream_t stream);
+/* Backward of BatchNorm(train)+ReLU: out2k = {S1[c] = sum dyM, S2[c] = sum dyM*xhat} (dyM = dy*[bn(x) > 0]);
+ * for SyncBatchNorm all-reduce out2k and use the global count; then dx = gamma*rstd*(dyM - S1/n - xhat*S2/n).
+ * d gamma = S2, d beta = S1.  `x` is the pre-normalisation activation, `stats` the forward {sum, sumsq}. */
+int contrad_bn_relu_bwd_stats(const float* dy, const float* x, long long M, int K, int ld, const float* stats,
+                              float count, const float* gamma, const float* beta, float eps, float* out2k,
+                              float* workspace, long long workspace_bytes, contrad_stream_t stream);
+int contrad_bn_relu_bwd_apply(const float* dy, const float* x, float* dx, long long M, int K, int ld,
+                              const float* stats, float count, const float* gamma, const float* beta, float eps,
+                              const float* bstats, contrad_stream_t stream);
 int contrad_bn_running_update(const float* stats, float count, int K, const float* conv_bias, float momentum,
                               float* running_mean, float* running_var, contrad_stream_t stream);
 /* contrad.loss_D_fn's GAN term (training/gan/contrad.py:51-64) on logits[3N] (stride ld): kind 0 nonsat,
@@ -205,6 +214,13 @@ long long contrad_simclr_workspace_bytes(int B, int H, int W);
 int contrad_simclr_augment(const float* x, float* y, const float* params, int B, int H, int W,
                            int contrast_first, int has_contrast, float* workspace,
                            long long workspace_bytes, contrad_stream_t stream);
+/* Backward of contrad_simclr_augment for the generator step (gradient flows through the augmentation into G,
+ * training/gan/contrad.py:73-82): grad_in = d loss / d x given grad_out = d loss / d y.  Bilinear gather
+ * transpose, contrast backward, straight-through HSV (augment/color_jitter.py:97-104), gray backward.
+ * Small images only (7*H*W + H*H + W*W floats of LDS <= 64 KiB, i.e. CIFAR). */
+int contrad_simclr_augment_bwd(const float* x, const float* params, const float* grad_out, float* grad_in,
+                               int B, int H, int W, int contrast_first, int has_contrast,
+                               contrad_stream_t stream);
 /* RandomApply(GaussianBlur) (augment/__init__.py:53-78): separable (2*radius+1)-tap blur with reflect
  * padding on samples whose blur_mask != 0, copy-through otherwise; tmp is a scratch image batch. */
 int contrad_gaussian_blur_masked(const float* x, float* tmp, float* y, const float* params,

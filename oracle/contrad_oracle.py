@@ -157,7 +157,26 @@ def hsv2rgb(hsv):
     return v - c * t
 
 
+class _StraightThroughHSV(torch.autograd.Function):
+    """RandomHSVFunction (color_jitter.py:81-104): forward = the HSV jitter, backward = identity on x."""
+
+    @staticmethod
+    def forward(ctx, x, f_h, f_s, f_v):
+        return _adjust_hsv_values(x, f_h, f_s, f_v)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.clone(), None, None, None
+
+
 def adjust_hsv(x, f_h, f_s, f_v):
+    """RandomHSVFunction.apply: values as color_jitter.py:83-95, gradient straight-through (:97-104)."""
+    if x.requires_grad:
+        return _StraightThroughHSV.apply(x, f_h, f_s, f_v)
+    return _adjust_hsv_values(x, f_h, f_s, f_v)
+
+
+def _adjust_hsv_values(x, f_h, f_s, f_v):
     """RandomHSVFunction.forward (color_jitter.py:83-95), incl. the 255/360 hue quirk."""
     B = x.size(0)
     hsv = rgb2hsv(x)
@@ -364,6 +383,15 @@ def sndcgan_d_forward(sd, x, sg_linear=False, training=True, act_masks=None, hid
     feats = sndcgan_d_features(sd, x, training, act_masks)
     out, proj, proj2 = d_heads(sd, feats, sg_linear, training, hidden_masks)
     return out, proj, proj2, feats
+
+
+def gan_g_loss(d_gen, kind):
+    """contrad.loss_G_fn's loss (training/gan/contrad.py:75-81)."""
+    if kind == 'nonsat':
+        return F.softplus(-d_gen).mean()
+    if kind == 'lsgan':
+        return 0.5 * ((d_gen - 1.0) ** 2).mean()
+    return -d_gen.mean()
 
 
 def contrad_loss_d(d_forward, images_aug3n, N, temp=0.1, lbd_a=1.0, loss='nonsat'):

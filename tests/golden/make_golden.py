@@ -306,6 +306,64 @@ def gen_sndcgan():
 
 
 # ------------------------------------------------------------------------------------------------
+def gen_sndcgan_gstep():
+    """Generator step (train_gan.py:170-177): G(z) with grad -> loss_G_fn = softplus(-D(augment(G(z)))) -> G grads."""
+    import augment as A
+    from models.gan import get_architecture
+    from training.gan import contrad as ref_contrad
+    from argparse import Namespace
+    _refshim.bind_cifar_defaults()
+    G, D = get_architecture('sndcgan', (32, 32, 3))
+    G.train(); D.train()
+    sd = O.det_fill(O.sndcgan_d_param_shapes(), seed=1234)
+    _load_sd(D, sd)
+    gsd = O.det_fill(O.sndcgan_g_param_shapes(), seed=4321)
+    gfull = dict(G.state_dict()); gfull.update({k: v.clone() for k, v in gsd.items()}); G.load_state_dict(gfull)
+    for p in D.parameters():
+        p.requires_grad = False
+    N = 6
+    g = torch.Generator().manual_seed(123)
+    z = torch.rand(N, 128, generator=g) * 2 - 1
+    aug = A.simclr()
+    seed = 31
+    P = Namespace(augment_fn=aug, temp=0.1, lbd_a=1.0, distributed=False)
+    gen = G(z)
+    torch.manual_seed(seed); np.random.seed(seed)
+    g_loss = ref_contrad.loss_G_fn(P, D, {'loss': 'nonsat'}, None, gen)
+    G.zero_grad()
+    g_loss.backward()
+    ref_grads = {k: v.grad.clone() for k, v in G.named_parameters()}
+
+    # oracle
+    osd = {k: v.clone() for k, v in sd.items()}
+    ogsd = {k: v.clone() for k, v in gsd.items()}
+    gparams = [k for k in ogsd if not ('running' in k)]
+    for k in gparams:
+        ogsd[k].requires_grad_()
+    ogen = O.sndcgan_g_forward(ogsd, z)
+    torch.manual_seed(seed); np.random.seed(seed)
+    p = O.sample_simclr_params(N, 32, 32, O.SIMCLR_CIFAR)
+    oaug = O.simclr_apply(ogen, p)
+    od = O.sndcgan_d_forward(osd, oaug, sg_linear=False)[0]
+    ol = O.gan_g_loss(od, 'nonsat')
+    ol.backward()
+    check(ogen, gen, 1e-6, 'gstep gen')
+    check(ol, g_loss, 1e-6, 'gstep loss')
+    gerr = 0.0
+    for k, gref in ref_grads.items():
+        gerr = max(gerr, check(ogsd[k].grad, gref, 2e-5, 'gstep grad ' + k))
+    print('  sndcgan G-step: max grad err vs reference %.2e, loss %.5f' % (gerr, g_loss.item()))
+    out = {'z': z, 'seed': seed, 'N': N, 'gen': gen, 'g_loss': g_loss}
+    for k, gref in ref_grads.items():
+        out['gradnorm/' + k] = gref.norm()
+        if gref.numel() <= 8192:
+            out['grad/' + k] = gref
+        else:
+            out['gradhead/' + k] = gref.reshape(-1)[:512]
+    save('sndcgan_gstep', **out)
+
+
+# ------------------------------------------------------------------------------------------------
 def gen_adam():
     g = torch.Generator().manual_seed(5)
     p = torch.randn(1000, generator=g)
@@ -450,7 +508,7 @@ def gen_stylegan2_g():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['losses', 'augment', 'sndcgan', 'adam', 'stylegan2', 'stylegan2_g']
+    which = sys.argv[1:] or ['losses', 'augment', 'sndcgan', 'sndcgan_gstep', 'adam', 'stylegan2', 'stylegan2_g']
     for w in which:
         globals()['gen_' + w]()
     print('golden vectors OK')

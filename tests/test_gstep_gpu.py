@@ -1,0 +1,145 @@
+"""GPU parity of the generator step (scope row N1): differentiable fused augmentation, BatchNorm+ReLU backward,
+G_SNDCGAN built from differentiable HIP nodes, D's backward-to-input, against the reference goldens / oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from contrad_amd import ops
+from contrad_amd.augment import SimCLRAugment
+from contrad_amd.engine import set_grad
+from contrad_amd.models.gan import get_architecture
+from contrad_amd.training.gan import contrad as hip_contrad
+from oracle import contrad_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+FLIP_TOL = 3e-2
+DEV = 'cuda'
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def l2(a, b):
+    a, b = torch.as_tensor(a).double().cpu().reshape(-1), torch.as_tensor(b).double().cpu().reshape(-1)
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_augment_backward_matches_oracle(seed):
+    """d(sum(out * w)) / d(images) through crop+flip gather, contrast, straight-through HSV and gray."""
+    B = 16
+    torch.manual_seed(seed); np.random.seed(seed)
+    x = torch.rand(B, 3, 32, 32)
+    w = torch.randn(B, 3, 32, 32)
+    p = O.sample_simclr_params(B, 32, 32, O.SIMCLR_CIFAR)
+    xr = x.clone().requires_grad_()
+    (O.simclr_apply(xr, p) * w).sum().backward()
+    aug = SimCLRAugment(scale=(0.2, 1.0))
+    P = torch.zeros(B, ops.AUG_NPARAM)
+    th = p['theta']
+    P[:, 0], P[:, 1], P[:, 2], P[:, 3] = th[:, 0, 0], th[:, 1, 1], th[:, 0, 2], th[:, 1, 2]
+    for i, k in enumerate(['flip_sign', 'jitter_mask', 'f_contrast', 'f_h', 'f_s', 'f_v', 'gray_mask']):
+        P[:, 4 + i] = p[k]
+    xd = x.to(DEV).requires_grad_()
+    out = aug.apply(xd, P, p['contrast_first'])
+    (out * w.to(DEV)).sum().backward()
+    # clamp boundaries (pre-activation exactly at 0/1 after fp32 rounding) can flip single pixels: L2 criterion
+    assert l2(xd.grad, xr.grad) < 2e-3, l2(xd.grad, xr.grad)
+
+
+def test_bn_relu_backward():
+    g = torch.Generator().manual_seed(4)
+    M, K = 700, 96
+    x = torch.randn(M, K, generator=g)
+    gamma, beta = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
+    dy = torch.randn(M, K, generator=g)
+    xr, gr, br = x.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    y = F.relu(F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5))
+    y.backward(dy)
+    xd = x.to(DEV)
+    stats = ops.colstats(xd, with_sq=True)
+    dx, dg, db = ops.bn_relu_bwd(dy.to(DEV), xd, stats, float(M), gamma.to(DEV), beta.to(DEV), 1e-5)
+    assert rel(dx, xr.grad) < TOL and rel(dg, gr.grad) < TOL and rel(db, br.grad) < TOL
+
+
+def build():
+    G, D = get_architecture('sndcgan', (32, 32, 3))
+    D.load_state_dict(O.det_fill(O.sndcgan_d_param_shapes(), seed=1234))
+    gsd = dict(G.state_dict()); gsd.update(O.det_fill(O.sndcgan_g_param_shapes(), seed=4321)); G.load_state_dict(gsd)
+    return G.to(DEV).train(), D.to(DEV).train()
+
+
+class _P(object):
+    temp, lbd_a, distributed = 0.1, 1.0, False
+
+
+def test_generator_step_matches_reference(golden):
+    g = golden('sndcgan_gstep')
+    G, D = build()
+    set_grad(G, True); set_grad(D, False)
+    z = torch.from_numpy(g['z']).to(DEV)
+    gen = G(z)
+    assert rel(gen, g['gen']) < TOL
+    P = _P()
+    P.augment_fn = SimCLRAugment(scale=(0.2, 1.0))
+    seed = int(g['seed'])
+    torch.manual_seed(seed); np.random.seed(seed)
+    g_loss = hip_contrad.loss_G_fn(P, D, {'loss': 'nonsat'}, None, gen)
+    assert abs(g_loss.item() - float(g['g_loss'])) < TOL * abs(float(g['g_loss']))
+    g_loss.backward()
+    grads = {k: p.grad for k, p in G.named_parameters()}
+    assert all(p.grad is None for p in D.parameters())
+    for k in g.files:
+        if k.startswith('gradnorm/'):
+            name = k[len('gradnorm/'):]
+            ref = float(g[k])
+            if ref < 1e-7:          # ConvT / linear biases in front of a BatchNorm: exactly-zero gradient up to noise
+                assert grads[name].norm().item() < 1e-5, name
+            else:
+                assert abs(grads[name].norm().item() - ref) < 2e-2 * ref, (name, grads[name].norm().item(), ref)
+        elif k.startswith('grad/'):
+            name = k[5:]
+            if float(g['gradnorm/' + name]) >= 1e-7:
+                assert l2(grads[name], g[k]) < FLIP_TOL, name
+
+
+def test_generator_step_on_the_same_linear_region():
+    """Strict check vs the oracle with the leaky-relu regions of D recorded from the HIP run (ReLU / clamp flips in
+    G and the augmentation are absent for this seed)."""
+    N = 8
+    G, D = build()
+    set_grad(G, True); set_grad(D, False)
+    D._record_activations = True
+    g = torch.Generator().manual_seed(77)
+    z = torch.rand(N, 128, generator=g) * 2 - 1
+    P = _P()
+    P.augment_fn = SimCLRAugment(scale=(0.2, 1.0))
+    torch.manual_seed(13); np.random.seed(13)
+    gen = G(z.to(DEV))
+    g_loss = hip_contrad.loss_G_fn(P, D, {'loss': 'nonsat'}, None, gen)
+    g_loss.backward()
+    acts, hidden = D._last_activations
+    masks = [(t > 0).permute(0, 3, 1, 2).cpu() for t in acts]
+    hm = (hidden.view(N, -1) > 0).cpu()
+    osd = O.det_fill(O.sndcgan_d_param_shapes(), seed=1234)
+    ogsd = O.det_fill(O.sndcgan_g_param_shapes(), seed=4321)
+    for k in ogsd:
+        if 'running' not in k:
+            ogsd[k].requires_grad_()
+    ogen = O.sndcgan_g_forward(ogsd, z)
+    torch.manual_seed(13); np.random.seed(13)
+    p = O.sample_simclr_params(N, 32, 32, O.SIMCLR_CIFAR)
+    od = O.sndcgan_d_forward(osd, O.simclr_apply(ogen, p), sg_linear=False, act_masks=masks,
+                             hidden_masks=(hm[:, :512], hm[:, 512:1024], hm[:, 1024:]))[0]
+    ol = O.gan_g_loss(od, 'nonsat')
+    ol.backward()
+    assert abs(g_loss.item() - ol.item()) < TOL * abs(ol.item())
+    for k, prm in G.named_parameters():
+        ref = ogsd[k].grad
+        if ref.norm().item() < 1e-7:
+            continue
+        assert l2(prm.grad, ref) < 5e-3, (k, l2(prm.grad, ref))
