@@ -128,7 +128,7 @@ class SimCLRAugment(nn.Module):
 
     def apply(self, inputs, P, contrast_first, sigma=None):
         """Deterministic device part."""
-        Pd = P.to(inputs.device, non_blocking=True)
+        Pd = P.to(inputs.device)      # (B,12) parameter block; synchronous pageable upload (see G.sample_latent)
         if inputs.requires_grad and torch.is_grad_enabled():
             if sigma is not None:
                 raise NotImplementedError('backward through simclr_hq (large images / blur) is scope row N2')

@@ -360,6 +360,10 @@ class G_SNDCGAN(nn.Module):
         self._packed_key = None
 
     def sample_latent(self, n_samples):
+        # U(-1,1) from the CPU generator, as the reference (sndcgan.py:50-52).  The pageable upload is synchronous
+        # on purpose: it bounds the host's run-ahead to one step.  (Asynchronous pinned uploads let the host queue
+        # >= 3 steps ahead, at which point the ROCm 7.2 runtime stalls and drains the whole queue every third step:
+        # measured 31.4 vs 22.8 ms/step at N = 512, tools/dbg_runahead.py.)
         _device = next(self.parameters()).device
         return torch.empty(n_samples, self.nz).uniform_(-1, 1).to(_device)
 
