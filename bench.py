@@ -159,8 +159,18 @@ def main():
         name, (tsum, fsum, cnt) = dom
         achieved = fsum / tsum / 1e12
         conv_time = sum(a[0] for a in agg.values())
+        # HBM traffic per launch of the dominant kernel: from the committed rocprofv3 --pmc passes of this same
+        # command (profiles/r01_bench_n1_pmc.*; separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_bench_n1_pmc.json')))
+            if pmc.get('kernel') == name and world == 1:
+                traffic, traffic_src = pmc['traffic_bytes_per_launch'], 'profiles/r01_bench_n1_pmc.json'
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic,
+                    "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                     "launches_per_step": cnt / args.steps, "avg_launch_ms": round(tsum / cnt * 1e3, 4),
                     "algorithmic_gflop_per_launch": round(fsum / cnt / 1e9, 2),
                     "conv_engine_share_of_step": round(conv_time / dt, 3),
