@@ -82,6 +82,40 @@ class ConvWgradFn(Function):
         return g_x, g_gy, None, None
 
 
+class ConvWgradBiasFn(Function):
+    """(dwp, dbias) = (wgrad(x, gy), sum_{n,h,w} gy) in ONE kernel: the bias gradient is accumulated from the gy
+    tiles the weight-gradient kernel streams anyway.  Both outputs are linear in gy, so the backward is again made
+    of the family's nodes."""
+
+    @staticmethod
+    def forward(ctx, x, gy, geom, wp_shape):
+        K, KH, KW, s, p = geom
+        x, gy = _cont(x), _cont(gy)
+        ctx.save_for_backward(x, gy)
+        ctx.geom = geom
+        out = torch.zeros(wp_shape, device=x.device, dtype=torch.float32)
+        db = torch.empty(K, device=x.device, dtype=torch.float32)
+        ops.conv2d_wgrad(x, gy, KH, KW, s, p, out=out, dbias=db)
+        return out, db
+
+    @staticmethod
+    def backward(ctx, h, hb):
+        x, gy = ctx.saved_tensors
+        g_x = g_gy = None
+        if h is not None:
+            h = _cont(h)
+            g_x = ConvDgradFn.apply(gy, h, tuple(x.shape), ctx.geom) if ctx.needs_input_grad[0] else None
+            g_gy = Conv2dFn.apply(x, h, ctx.geom) if ctx.needs_input_grad[1] else None
+        if hb is not None and ctx.needs_input_grad[1]:
+            e = hb.view((1,) * (gy.dim() - 1) + (-1,)).expand(gy.shape)
+            g_gy = e if g_gy is None else g_gy + e
+        return g_x, g_gy, None, None
+
+
+def _fused_bias_ok(x, K):
+    return x.shape[-1] % 4 == 0 and K % 4 == 0
+
+
 class ActBwdFn(Function):
     """g_pre = g_post * lrelu'(.) * gain, with the linear region read from the activation OUTPUT ``y``
     (FusedLeakyReLUFunctionBackward, op/fused_act.py:20-55: linear in g, its own backward is the same op)."""
@@ -132,8 +166,12 @@ class ConvBiasActFn(Function):
         geom, slope, gain = ctx.cfg
         g_pre = gy if (slope == 1.0 and gain == 1.0) else ActBwdFn.apply(gy, y, slope, gain)
         gx = ConvDgradFn.apply(g_pre, wp, tuple(x.shape), geom) if ctx.needs_input_grad[0] else None
-        gw = ConvWgradFn.apply(x, g_pre, geom, tuple(wp.shape)) if ctx.needs_input_grad[1] else None
-        gb = ColSumFn.apply(g_pre) if ctx.needs_input_grad[2] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and _fused_bias_ok(x, geom[0]):
+            gw, gb = ConvWgradBiasFn.apply(x, g_pre, geom, tuple(wp.shape))
+        else:
+            gw = ConvWgradFn.apply(x, g_pre, geom, tuple(wp.shape)) if ctx.needs_input_grad[1] else None
+            gb = ColSumFn.apply(g_pre) if ctx.needs_input_grad[2] else None
         return gx, gw, gb, None, None, None
 
 

@@ -73,6 +73,57 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(UpfirdnArgs a) {
   }
 }
 
+// up = down = 1 fast path (Blur and its backward -- every upfirdn2d call of the discriminator): each thread produces a
+// vertical strip of R outputs for one (x, 4 channels), so an input row it loads feeds up to kh outputs from
+// registers: (R + kh - 1) * kw loads for R outputs instead of kh * kw each (7 vs 16 per output at R = 4).
+template <int R>
+__global__ __launch_bounds__(256) void upfirdn2d_strip_kernel(UpfirdnArgs a) {
+  __shared__ float fir[MAX_FIR * MAX_FIR];  // flipped
+  for (int e = threadIdx.x; e < a.kh * a.kw; e += blockDim.x) {
+    const int ky = e / a.kw, kx = e - ky * a.kw;
+    fir[e] = a.kernel[(a.kh - 1 - ky) * a.kw + (a.kw - 1 - kx)];
+  }
+  __syncthreads();
+  const int mv = a.minor >> 2;
+  const int strips = (a.out_h + R - 1) / R;
+  const long long total = (long long)a.major * strips * a.out_w * mv;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % mv) * 4;
+    long long t = e / mv;
+    const int ox = (int)(t % a.out_w);
+    t /= a.out_w;
+    const int oy0 = (int)(t % strips) * R;
+    const int m = (int)(t / strips);
+    float4 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int iy0 = oy0 - a.pad_y0;                  // input row feeding (output row oy0, tap ky = 0)
+    for (int dy = 0; dy < R + a.kh - 1; ++dy) {
+      const int iy = iy0 + dy;
+      if ((unsigned)iy >= (unsigned)a.in_h) continue;
+      for (int kx = 0; kx < a.kw; ++kx) {
+        const int ix = ox + kx - a.pad_x0;
+        if ((unsigned)ix >= (unsigned)a.in_w) continue;
+        const float4 v = *reinterpret_cast<const float4*>(a.in + (((size_t)m * a.in_h + iy) * a.in_w + ix) * a.minor + c);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int ky = dy - r;                     // tap row of this input row for output row oy0 + r
+          if (ky >= 0 && ky < a.kh) {
+            const float w = fir[ky * a.kw + kx];
+            acc[r].x = fmaf(w, v.x, acc[r].x); acc[r].y = fmaf(w, v.y, acc[r].y);
+            acc[r].z = fmaf(w, v.z, acc[r].z); acc[r].w = fmaf(w, v.w, acc[r].w);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (oy0 + r < a.out_h)
+        *reinterpret_cast<float4*>(a.out + (((size_t)m * a.out_h + oy0 + r) * a.out_w + ox) * a.minor + c) = acc[r];
+  }
+}
+
 // y = act(x + b[(i / step_b) % size_b]) * scale  (grad 0) | x * act'(ref) * scale (grad 1) | 0 (grad 2)
 // act 1: linear, act 3: leaky relu with slope alpha  -- the reference's act*10+grad switch
 __global__ void fused_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ b,
@@ -208,6 +259,14 @@ extern "C" int contrad_upfirdn2d(const float* input, const float* kernel, float*
   a.out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
   CONTRAD_ARG(a.out_h > 0 && a.out_w > 0);
   const bool vec = (minor & 3) == 0;
+  if (vec && up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && a.out_h >= 4) {
+    const long long tot = (long long)major * ((a.out_h + 3) / 4) * a.out_w * (minor / 4);
+    long long g = (tot + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(upfirdn2d_strip_kernel<4>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, a);
+    CONTRAD_CHECK_LAUNCH();
+    return 0;
+  }
   const long long total = (long long)major * a.out_h * a.out_w * (vec ? minor / 4 : minor);
   long long grid = (total + 255) / 256;
   if (grid > 16384) grid = 16384;
