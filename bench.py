@@ -78,6 +78,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='dev: run all collective code paths on a 1-rank RCCL group (single GPU)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -88,13 +90,22 @@ def main():
                          % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if os.environ.get('NCCL_DEBUG', '').upper() == 'VERSION':
+        os.environ['NCCL_DEBUG'] = 'WARN'     # the RCCL version banner goes to STDOUT; keep it to the one JSON line
+    if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29566')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)     # "nccl" is RCCL on ROCm
+        if args.force_dist:
+            import contrad_amd.engine as _eng
+            _eng.FORCE_DIST = True
 
     from contrad_amd import config, ops
     from contrad_amd.augment import get_augment
-    from contrad_amd.engine import GradAllReducer, d_step, set_grad
+    from contrad_amd.engine import GradAllReducer, OverlappedGradReducer, d_step, set_grad
     from contrad_amd.models.gan import get_architecture
     from contrad_amd.optim import FusedAdam
     from contrad_amd.training.gan import setup
@@ -114,18 +125,23 @@ def main():
         G, D = get_architecture('sndcgan', (32, 32, 3))
         torch.manual_seed(0 + rank)
     G, D = G.to(dev).train(), D.to(dev).train()
-    P = argparse.Namespace(mode='contrad', aug='simclr', temp=0.1, lbd_a=1.0, distributed=(world > 1))
+    P = argparse.Namespace(mode='contrad', aug='simclr', temp=0.1, lbd_a=1.0, distributed=multi)
     P = setup(P)
     P.augment_fn = get_augment(mode=P.aug).to(dev)
     options = {'loss': opt['loss'], 'batch_size': n_local}
     opt_D = FusedAdam(D.parameters(), lr=opt['lr'], betas=tuple(opt['beta']))
-    reducer = GradAllReducer(D.parameters()) if world > 1 else None
+    reducer = None
+    if multi:
+        if os.environ.get('CONTRAD_NO_OVERLAP'):
+            reducer = GradAllReducer(D.parameters())          # two flat collectives after the backward
+        else:
+            D.enable_grad_overlap(OverlappedGradReducer())      # per-layer collectives hidden behind the backward
     set_grad(G, False); set_grad(D, True)
     images = torch.rand(n_local, 3, 32, 32, device=dev)      # synthetic CIFAR-shaped batch, resident in HBM
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -139,7 +155,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -191,7 +207,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -11,8 +11,16 @@ import torch
 import torch.distributed as dist
 
 
-def _dist_on():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+# Test hook: run every collective code path on a 1-rank process group (set by bench.py --force-dist / tests).
+FORCE_DIST = False
+
+
+def dist_on():
+    """True when this process is one rank of a multi-rank job (or the 1-rank test hook is set)."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_DIST)
+
+
+_dist_on = dist_on
 
 
 class GradAllReducer(object):
@@ -51,6 +59,34 @@ class GradAllReducer(object):
         return dist.get_world_size()
 
 
+class OverlappedGradReducer(object):
+    """Gradient exchange overlapped with the backward pass (what DDP's bucketed reducer does for the reference,
+    train_gan.py:311-313), at the granularity the fused discriminator backward produces gradients: each layer's
+    PACKED weight-gradient slab is all-reduced (SUM, async on RCCL's stream) as soon as its wgrad kernel is enqueued
+    -- the three merged head layers (2/3 of D_SNDCGAN's parameters) first, so their exchange hides behind the whole
+    trunk backward.  The spectral-norm weight-gradient transform that follows is linear in the packed gradient and
+    uses identical weights on every rank, so reducing before it is equivalent to reducing the final gradients."""
+
+    def __init__(self):
+        self.handles = []
+
+    def active(self):
+        return _dist_on() or (dist.is_available() and dist.is_initialized() and getattr(self, 'force', False))
+
+
+    def reduce_async(self, t):
+        if self.active():
+            self.handles.append(dist.all_reduce(t, async_op=True))
+
+    def wait(self):
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+
+    def world(self):
+        return dist.get_world_size() if self.active() else 1
+
+
 def sample_generator(G, num_samples, enable_grad=True):
     """_sample_generator of train_gan.py:96-100."""
     latent = G.sample_latent(num_samples)
@@ -72,7 +108,11 @@ def d_step(P, G, D, opt_D, options, images, reducer=None):
     loss = d_loss + aux['penalty']
     opt_D.zero_grad()
     loss.backward()
-    world = reducer() if reducer is not None else 1
+    comm = getattr(D, '_grad_comm', None)
+    if comm is not None:                      # gradients were exchanged inside the backward (overlapped)
+        world = comm.world()
+    else:
+        world = reducer() if reducer is not None else 1
     if world > 1:
         opt_D.step(grad_scale=1.0 / world)
     else:

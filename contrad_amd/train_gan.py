@@ -20,7 +20,7 @@ import torch.distributed as dist
 
 from . import config
 from .augment import get_augment
-from .engine import GradAllReducer, sample_generator, set_grad
+from .engine import GradAllReducer, OverlappedGradReducer, sample_generator, set_grad
 from .models.gan import get_architecture
 from .optim import FusedAdam
 from .training.gan import setup
@@ -112,7 +112,8 @@ def train_step(P, opt, G, D, opt_G, opt_D, images, step, reducers):
         loss = d_loss + aux['penalty']
         opt_D.zero_grad()
         loss.backward()
-        world = red_D() if red_D is not None else 1
+        comm = getattr(D, '_grad_comm', None)
+        world = comm.world() if comm is not None else (red_D() if red_D is not None else 1)
         opt_D.step(grad_scale=1.0 / world) if world > 1 else opt_D.step()
     set_grad(G, True); set_grad(D, False)
     gen_images = sample_generator(G, images.size(0))
@@ -182,7 +183,13 @@ def main(argv=None):
             log_file.write(msg + '\n'); log_file.flush()
 
     P.augment_fn = get_augment(mode=P.aug).to(dev)
-    reducers = (GradAllReducer(G.parameters()), GradAllReducer(D.parameters())) if world > 1 else (None, None)
+    reducers = (None, None)
+    if world > 1:
+        reducers = (GradAllReducer(G.parameters()), None)
+        if hasattr(D, 'enable_grad_overlap'):
+            D.enable_grad_overlap(OverlappedGradReducer())
+        else:
+            reducers = (reducers[0], GradAllReducer(D.parameters()))
     use_synth = P.synthetic
     if not use_synth:
         try:

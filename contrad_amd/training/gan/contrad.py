@@ -39,8 +39,9 @@ class _ContraDContrastive(torch.autograd.Function):
         D = proj.shape[1]
         z1, inv1 = ops.l2norm_fwd(proj[:2 * N])
         z2, inv2 = ops.l2norm_fwd(proj2)
+        from ...engine import dist_on
         world, rank = 1, 0
-        if distributed and dist.is_initialized() and dist.get_world_size() > 1:
+        if distributed and dist_on():
             world, rank = dist.get_world_size(), dist.get_rank()
             packed = torch.cat([z1, z2], dim=0)                      # (5N, D): one message per rank
             g = all_gather_rows(packed)                              # (W, 5N, D) over RCCL / xGMI

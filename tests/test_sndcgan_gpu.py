@@ -187,3 +187,34 @@ def test_eval_mode_and_input_gradient():
     o.sum().backward()
     assert rel(out, o.detach()) < TOL
     assert rel(xd.grad, xr.grad) < TOL
+
+
+def test_overlapped_gradient_exchange_single_rank_rccl():
+    """The in-backward gradient exchange on a 1-rank RCCL group: every async all-reduce / wait is exercised and the
+    gradients must be bitwise those of the plain backward (SUM over one rank)."""
+    import torch.distributed as dist
+    from contrad_amd.engine import OverlappedGradReducer
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29533', rank=0, world_size=1,
+                                device_id=torch.device('cuda', 0))
+    try:
+        g = torch.Generator().manual_seed(8)
+        x = torch.rand(12, 3, 32, 32, generator=g).to(DEV)
+
+        def grads(overlap):
+            _, D = build()
+            if overlap:
+                comm = OverlappedGradReducer()
+                comm.force = True
+                D.enable_grad_overlap(comm)
+            o, a = D(x, sg_linear=True, projection=True, projection2=True)
+            (o.sum() + a['projection'].pow(2).sum() + a['projection2'].sum()).backward()
+            return {k: p.grad.clone() for k, p in D.named_parameters()}
+
+        ga, gb = grads(False), grads(True)
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), k
+    finally:
+        if own:
+            dist.destroy_process_group()
