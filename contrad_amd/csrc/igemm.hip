@@ -27,7 +27,14 @@
 namespace {
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
-constexpr int BK = 32;
+#ifndef IGEMM_BK
+#define IGEMM_BK 16
+#endif
+constexpr int BK = IGEMM_BK;          // K-tile depth.  16 (33 KB LDS, <= 128 VGPRs -> 4 blocks = 16 waves per CU) measured
+                                      // +3.5 % over 32 (2 blocks per CU) on the SNDCGAN layers (tools/ab_bk.sh)
+#ifndef IGEMM_MIN_WAVES
+#define IGEMM_MIN_WAVES 4
+#endif
 constexpr int NTHREADS = 256;
 
 struct IgemmArgs {
@@ -55,14 +62,16 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 // (C % 4 == 0, K % 4 == 0, leading dimensions % 4 == 0); the !VEC instantiation covers odd shapes (Cin = 3,
 // Cout = 1) with per-element gathers and is only ever a tiny share of a step.
 template <int MODE, int BM, int BN, bool VEC>
-__global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
+__global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_kernel(const IgemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool A_KCONTIG = (MODE != MODE_WGRAD);
   constexpr bool B_KCONTIG = (MODE == MODE_DGRAD);
   constexpr int LDA = BM + (A_KCONTIG ? 1 : 4);
   constexpr int LDB = BN + (B_KCONTIG ? 1 : 4);
   constexpr int A_SZ = BK * LDA, B_SZ = BK * LDB;
-  constexpr int PA = BM / 32, PB = BN / 32;  // float4 prefetch registers per operand
+  constexpr int PA = BM * BK / 1024, PB = BN * BK / 1024;  // float4 prefetch registers per operand
+  constexpr int KQ = BK / 4;                 // k-quads per row of a K-contiguous tile
+  constexpr int KROWS = NTHREADS / KQ;       // rows covered per pass by the K-contiguous loader
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int EPV = VEC ? 1 : 4;           // predicate bits per float4
 
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
 
   // ---------------- loader state ----------------
   // K-contiguous operand: thread owns k-quad kq (4 consecutive k) of rows r + 32*i.
-  const int kq = tid & 7, krow = tid >> 3;
+  const int kq = tid % KQ, krow = tid / KQ;
   // Row-contiguous operand: thread owns 4 consecutive columns c4*4 of k-rows r + RPP*i.
   constexpr int A_RPP = 1024 / BM, B_RPP = 1024 / BN;
   const int a_c4 = tid % (BM / 4), a_r = tid / (BM / 4);
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
   if constexpr (MODE == MODE_FWD) {
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-      const int m = m0 + krow + 32 * i;
+      const int m = m0 + krow + KROWS * i;
       a_ok[i] = m < M;
       const int mm = a_ok[i] ? m : 0;
       const int wo = mm % d.Wo, t = mm / d.Wo;
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
   } else if constexpr (MODE == MODE_DGRAD) {
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-      const int m = m0 + krow + 32 * i;
+      const int m = m0 + krow + KROWS * i;
       a_ok[i] = m < M;
       const int mm = a_ok[i] ? m : 0;
       const int wq = mm % Wc, t = mm / Wc;
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
         const bool kok = k < Kg;
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-          const int c = n0 + krow + 32 * i;
+          const int c = n0 + krow + KROWS * i;
           const bool ok = kok && c < Ncol;
           rb[i] = ld4(p.B + (ok ? ((size_t)tapflat * d.C + c) * d.ldw + co : 0));
           bmask |= (unsigned)ok << i;
@@ -330,7 +339,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
           const bool kok = (k + j) < Kg;
 #pragma unroll
           for (int i = 0; i < PB; ++i) {
-            const int c = n0 + krow + 32 * i;
+            const int c = n0 + krow + KROWS * i;
             const bool ok = kok && c < Ncol;
             vb[i][j] = p.B[ok ? ((size_t)tapflat * d.C + c) * d.ldw + co : 0];
             bmask |= (unsigned)ok << (4 * i + j);
@@ -393,7 +402,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
       for (int i = 0; i < PA; ++i) a_base[i] = ((a_n[i] * d.Ho + a_h[i]) * d.Wo + a_w[i]) * d.ldy;
 #pragma unroll
-      for (int i = 0; i < PB; ++i) b_base[i] = (n0 + krow + 32 * i) * d.ldw;
+      for (int i = 0; i < PB; ++i) b_base[i] = (n0 + krow + KROWS * i) * d.ldw;
     } else {
 #pragma unroll
       for (int i = 0; i < PB; ++i) b_base[i] = n0 + b_c4 * 4;
@@ -459,7 +468,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
       if (i == PB - 1) b_k0 += BK;
     } else if constexpr (MODE == MODE_DGRAD) {
       const int tapflat = (kh0 + d.stride * cu_h) * d.KW + (kw0 + d.stride * cu_w);
-      const bool ok = cu_ok && (n0 + krow + 32 * i) < Ncol;
+      const bool ok = cu_ok && (n0 + krow + KROWS * i) < Ncol;
       rb[i] = ld4(p.B + (ok ? tapflat * d.C * d.ldw + b_base[i] + cu_c : 0));
       bmask |= (unsigned)ok << i;
     } else {
@@ -488,7 +497,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
     float* As = smem + buf * (A_SZ + B_SZ);
     const float4 v = masked(ra[i], amask, i);
     if constexpr (A_KCONTIG) {
-      const int row = krow + 32 * i;
+      const int row = krow + KROWS * i;
       As[(kq * 4 + 0) * LDA + row] = v.x;
       As[(kq * 4 + 1) * LDA + row] = v.y;
       As[(kq * 4 + 2) * LDA + row] = v.z;
@@ -509,7 +518,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
       colacc.z = fmaf(v.z, bias_flag, colacc.z); colacc.w = fmaf(v.w, bias_flag, colacc.w);
     }
     if constexpr (B_KCONTIG) {
-      const int row = krow + 32 * i;
+      const int row = krow + KROWS * i;
       Bs[(kq * 4 + 0) * LDB + row] = v.x;
       Bs[(kq * 4 + 1) * LDB + row] = v.y;
       Bs[(kq * 4 + 2) * LDB + row] = v.z;
@@ -550,7 +559,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
   // and the stores fill the idle buffer.  (With a branch hipcc cannot pair "loads issued" with "stores executed",
   // assumes loads may be pending at the back-edge and waits vmcnt right after issuing them.)
   constexpr int KS = BK / 2;
-  constexpr int A_LD0 = 0, B_LD0 = 4, A_ST0 = KS - 8, B_ST0 = KS - 4;
+  constexpr int A_LD0 = 0, B_LD0 = PA, A_ST0 = KS - PA - PB, B_ST0 = KS - PB;
+  static_assert(A_ST0 >= B_LD0 + PB, "not enough k-steps to schedule the load and store pieces");
   for (int t = 0; t < T; ++t) {
     const int cur = t & 1;
     const float* As = smem + cur * (A_SZ + B_SZ) + wm * WM + l31;
