@@ -22,6 +22,7 @@
 // blockIdx.x is remapped XCD-aware (common.h) with the N-tile index fastest, so the blocks that share an
 // activation tile run on the same XCD/L2.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/contrad_hip.h"
 
 namespace {
@@ -721,6 +722,52 @@ int launch(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
   return 0;
 }
 
+#include "igemm_lean.h"
+
+template <int MODE, int BM, int BN>
+int launch_lean(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
+  static bool attr_set = false;  // benign race: idempotent
+  constexpr size_t smem = lean_smem_bytes<MODE, BM, BN>();
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lean_kernel<MODE, BM, BN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((igemm_lean_kernel<MODE, BM, BN>), grid, dim3(NTHREADS), smem, stream, a);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+// Does the shape fit the lean loop (igemm_lean.h)?  pps = WGRAD position tiles per split.
+bool lean_ok(const contrad_conv_desc* d, int mode, long long pps) {
+  static const bool enabled = []() { const char* e = getenv("CONTRAD_IGEMM_LEAN"); return !(e && e[0] == '0'); }();
+  if (!enabled || BK != 16) return false;
+  const long long lim = 1ll << 31;
+  if (d->KH * d->KW > 32) return false;
+  if ((long long)d->KH * d->KW * d->C * d->ldw * 4 >= lim) return false;   // packed weight addressed with byte offsets
+  const long long img_x = (long long)d->H * d->W * d->ldx * 4, img_y = (long long)d->Ho * d->Wo * d->ldy * 4;
+  if (mode == MODE_FWD) {
+    if ((d->C & 15) || (d->ldx & 3) || (d->K & 3)) return false;
+    const long long imgs = 128 / ((long long)d->Ho * d->Wo) + 2;            // images one 128-row M-tile can touch
+    return imgs * img_x < lim;
+  }
+  if (mode == MODE_DGRAD) {
+    if ((d->K & 15) || (d->ldy & 3)) return false;
+    const long long imgs = 128 / ((long long)cdiv(d->H, d->stride) * cdiv(d->W, d->stride)) + 2;
+    return imgs * img_y < lim;
+  }
+  if ((d->C & 3) || (d->ldx & 3) || (d->K & 3) || (d->ldy & 3)) return false;
+  const long long P = (long long)d->N * d->Ho * d->Wo;
+  if (P % 16) return false;
+  const int gw = d->Wo < 16 ? d->Wo : 16;
+  if (gw <= 0 || 16 % gw || d->Wo % gw) return false;
+  const int gh = d->Ho < 16 / gw ? d->Ho : 16 / gw;
+  if ((16 / gw) % gh || d->Ho % gh) return false;
+  const long long imgs = pps * 16 / ((long long)d->Ho * d->Wo) + 2;         // images one split walks over
+  return imgs * img_x < lim && pps * 16 * d->ldy * 4 < lim;
+}
+
 // float4-addressable operands?  (the !VEC kernels are instantiated for the 64x64 tile only)
 bool vec_ok(const contrad_conv_desc* d, int mode) {
   const bool c4 = (d->C & 3) == 0 && (d->ldx & 3) == 0;
@@ -742,6 +789,12 @@ void pick_tile(long long M, int Ncol, bool vec, int* bm, int* bn) {
 
 template <int MODE>
 int dispatch(const IgemmArgs& a, int bm, int bn, bool vec, dim3 grid, hipStream_t s) {
+  if (vec && lean_ok(&a.d, MODE, a.ptiles_per_split)) {
+    if (bm == 128 && bn == 128) return launch_lean<MODE, 128, 128>(a, grid, s);
+    if (bm == 128 && bn == 64) return launch_lean<MODE, 128, 64>(a, grid, s);
+    if (bm == 64 && bn == 128) return launch_lean<MODE, 64, 128>(a, grid, s);
+    return launch_lean<MODE, 64, 64>(a, grid, s);
+  }
   if (!vec) return launch<MODE, 64, 64, false>(a, grid, s);
   if (bm == 128 && bn == 128) return launch<MODE, 128, 128, true>(a, grid, s);
   if (bm == 128 && bn == 64) return launch<MODE, 128, 64, true>(a, grid, s);

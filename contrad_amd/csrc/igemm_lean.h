@@ -1,0 +1,432 @@
+// Lean main loop of the implicit-GEMM engine (included by igemm.hip; shares IgemmArgs / the mode enum).
+//
+// Why a second kernel: on gfx950 every VALU / SALU instruction a wave issues between its MFMAs takes matrix-pipe
+// time away from the SIMD (tools/micro/mfma_valu.hip: +16 plain VALU per 4-MFMA k-step = 155 -> 135 TF/s, 64-bit adds
+// and v_cndmask cost double, SALU about half) -- the fp32 MFMA ceiling is reached only by a loop that is almost
+// nothing but MFMA + memory instructions.  This kernel therefore moves ALL index arithmetic out of the loop:
+//
+//   * operands are fetched with raw BUFFER loads: voffset = a per-thread byte offset fixed in the prologue,
+//     soffset = a wave-uniform (SGPR) per-tile offset, and "this element is padding / past the edge" is expressed
+//     as voffset = 0x80000000, which the hardware range check turns into a zero fill -- no predicate masks,
+//     no 64-bit address arithmetic, no selects on the data;
+//   * shapes are restricted so that one K-tile (16 deep) never straddles a filter tap (FWD: Cin % 16 == 0,
+//     DGRAD: Cout % 16 == 0) or, for WGRAD, is a fixed 16-position patch of the output grid: the tap / patch walk
+//     is scalar code, the per-thread part collapses to "base | sign-extended invalid bit";
+//   * K-contiguous operands (im2col rows of x, rows of gy, the packed weight read along cout) are stored in LDS as
+//     [k/4][row][4] "quads": one ds_write_b128 per global float4 (no transpose) and one ds_read_b128 per lane per
+//     four k-steps.  The MFMA consumes k in the permuted order k = 8h + 4*(lane>>5) + j (h = half of the tile,
+//     j = k-step in the half) -- a contraction is order-free as long as A and B agree;
+//   * row-contiguous operands (packed weight rows, WGRAD's position-major x / gy) are stored [k][cols] unpadded with
+//     the column XOR-swizzled by bit 2 of k (conflict-free ds_read_b32 for both lane halves, leading dimension a
+//     multiple of 64 dwords so the compiler can pair reads as ds_read2st64_b32 with immediate offsets);
+//   * the LDS double buffer is selected by adding a scalar to five per-thread base registers per tile.
+//
+// Anything that does not fit (odd channel counts, non-power-of-two WGRAD grids, > 32 taps) runs on the general
+// kernel in igemm.hip.  The two kernels produce bit-identical sums only for equal k order, which they do not share:
+// parity tests compare each against the fp32 oracle with the stated tolerance.
+#pragma once
+
+constexpr unsigned LEAN_OOB = 0x80000000u;       // voffset of an element that must read as zero: out of range whether or
+                                                 // not the hardware adds soffset (< 2^31) before the range check
+constexpr unsigned LEAN_RANGE = 0x80000000u;     // num_records of every descriptor (offsets are block-relative)
+
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  // (the builtin returns a GCC vector_size(16) type; bit_cast it, an implicit conversion to an ext_vector splats .x)
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t lean_rsrc(const float* base, bool on) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, on ? (int)LEAN_RANGE : 0, 0x00020000);
+}
+
+template <int MODE, int BM, int BN>
+__global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(const IgemmArgs p) {
+  static_assert(BK == 16, "the lean loop is written for a 16-deep K-tile");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr bool A_Q = (MODE != MODE_WGRAD);   // A K-contiguous in memory -> quad layout
+  constexpr bool B_Q = (MODE == MODE_DGRAD);
+  constexpr int QSA = BM * 4 + 16, QSB = BN * 4 + 16;   // quad stride (+16: the 4 quads of a row-group hit 4 bank groups)
+  constexpr int A_SZ = A_Q ? 4 * QSA : 16 * BM;
+  constexpr int B_SZ = B_Q ? 4 * QSB : 16 * BN;
+  constexpr int BUF = A_SZ + B_SZ;
+  constexpr int PA = BM / 64, PB = BN / 64;             // float4 prefetch registers per operand
+  constexpr int A_RPP = 1024 / BM, B_RPP = 1024 / BN;   // k-rows per pass of the row-layout loader
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+
+  const contrad_conv_desc& d = p.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = b % p.tiles_n, tile_m = b / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // loader coordinates: quad loader = (row qrow + 64 i, k-quad kq); row loader = (k-row r + RPP i, column quad c4)
+  const int kq = tid & 3, qrow = tid >> 2;
+  const int a_c4 = tid % (BM / 4), a_r = tid / (BM / 4);
+  const int b_c4 = tid % (BN / 4), b_r = tid / (BN / 4);
+
+  int M = p.M, Ncol = p.Ncol;
+  int T = 0;                       // K-tiles this block contracts over
+  const float* baseA = p.A;        // descriptor bases (block-relative, so byte offsets stay far below 2^31)
+  const float* baseB = p.B;
+  unsigned va[PA], vb[PB];         // per-thread byte offsets (fixed)
+  unsigned inv[PA];                // FWD / DGRAD: bit t set = tap t of this row is padding;  WGRAD: unused
+  int ch[PA], cw[PA];              // WGRAD: input row / column of the element at patch origin (0, 0)
+
+  // wave-uniform walk state (of the NEXT tile to be loaded)
+  int u_tap = 0, u_a = 0, u_b = 0, u_c0 = 0;   // FWD: tap, kh, kw, c0   DGRAD: ti, th, tw, co0
+  int u_n = 0, u_h = 0, u_w = 0;               // WGRAD: patch origin (image, ho, wo)
+  int ph = 0, pw = 0, Hc = 0, Wc = 0, kh0 = 0, kw0 = 0, nth = 0, ntw = 1, bh = 0, bw = 0;   // DGRAD class
+  int gw = 1, gh = 1, gn = 1, n_begin = 0;                                                    // WGRAD patch
+
+  if constexpr (MODE == MODE_FWD) {
+    T = p.Kg / BK;
+    const int HoWo = d.Ho * d.Wo;
+    const int n_first = m0 / HoWo;
+    baseA = p.A + ((long long)n_first * d.H * d.W - (d.pad * d.W + d.pad)) * d.ldx;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int m = m0 + qrow + 64 * i;
+      const bool ok = m < M;
+      const int mm = ok ? m : m0;
+      const int wo = mm % d.Wo, t = mm / d.Wo;
+      const int ho = t % d.Ho, n = t / d.Ho;
+      va[i] = (unsigned)(((((n - n_first) * d.H + ho * d.stride) * d.W + wo * d.stride) * d.ldx + kq * 4) * 4);
+      unsigned bits = 0;
+      int tap = 0;
+      for (int kh = 0; kh < d.KH; ++kh)
+        for (int kw = 0; kw < d.KW; ++kw, ++tap) {
+          const int hi = ho * d.stride - d.pad + kh, wi = wo * d.stride - d.pad + kw;
+          const bool valid = ok && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
+          bits |= (valid ? 0u : 1u) << tap;
+        }
+      inv[i] = bits;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int col = n0 + b_c4 * 4;
+      vb[i] = (col < Ncol) ? (unsigned)((((b_r + B_RPP * i) * d.ldw) + col) * 4) : LEAN_OOB;
+    }
+  } else if constexpr (MODE == MODE_DGRAD) {
+    const int s = d.stride;
+    ph = blockIdx.y / s;
+    pw = blockIdx.y % s;
+    Hc = (d.H - ph + s - 1) / s;
+    Wc = (d.W - pw + s - 1) / s;
+    kh0 = (ph + d.pad) % s;
+    kw0 = (pw + d.pad) % s;
+    nth = (kh0 < d.KH) ? (d.KH - kh0 + s - 1) / s : 0;
+    ntw = (kw0 < d.KW) ? (d.KW - kw0 + s - 1) / s : 0;
+    bh = (ph + d.pad - kh0) / s;
+    bw = (pw + d.pad - kw0) / s;
+    M = d.N * Hc * Wc;
+    Ncol = d.C;
+    T = nth * ntw * d.K / BK;
+    if (ntw == 0) ntw = 1;
+    if (m0 >= M) return;  // uniform per block, before any barrier
+    const int HcWc = Hc * Wc;
+    const int n_first = m0 / HcWc;
+    baseA = p.A + ((long long)n_first * d.Ho * d.Wo - ((nth - 1) * d.Wo + (ntw - 1))) * d.ldy;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int m = m0 + qrow + 64 * i;
+      const bool ok = m < M;
+      const int mm = ok ? m : m0;
+      const int wq = mm % Wc, t = mm / Wc;
+      const int n = t / Hc;
+      const int ah = t % Hc + bh, aw = wq + bw;   // ho = ah - th, wo = aw - tw
+      va[i] = (unsigned)(((((n - n_first) * d.Ho + ah) * d.Wo + aw) * d.ldy + kq * 4) * 4);
+      unsigned bits = 0;
+      int ti = 0;
+      for (int th = 0; th < nth; ++th)
+        for (int tw = 0; tw < ntw; ++tw, ++ti) {
+          const bool valid = ok && (unsigned)(ah - th) < (unsigned)d.Ho && (unsigned)(aw - tw) < (unsigned)d.Wo;
+          bits |= (valid ? 0u : 1u) << ti;
+        }
+      inv[i] = bits;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int c = n0 + qrow + 64 * i;
+      vb[i] = (c < Ncol) ? (unsigned)((c * d.ldw + kq * 4) * 4) : LEAN_OOB;
+    }
+  } else {
+    const int tiles_total = p.P / BK;
+    const int t_begin = blockIdx.y * p.ptiles_per_split;
+    T = min(p.ptiles_per_split, tiles_total - t_begin);
+    if (T < 0) T = 0;
+    gw = min(d.Wo, 16);
+    gh = min(d.Ho, 16 / gw);
+    gn = 16 / (gw * gh);
+    const int tpr = d.Wo / gw, tpi = tpr * (d.Ho / gh);   // patches per output row / per image
+    u_w = (t_begin % tpr) * gw;
+    u_h = ((t_begin / tpr) % (d.Ho / gh)) * gh;
+    u_n = (t_begin / tpi) * gn;
+    n_begin = u_n;
+    baseA = p.A + ((long long)n_begin * d.H * d.W - (d.pad * d.W + d.pad)) * d.ldx;
+    baseB = p.B + (long long)t_begin * BK * d.ldy;
+    const int ic = m0 + a_c4 * 4;
+    const bool colok = ic < p.Kg;
+    const int icc = colok ? ic : 0;
+    const int tap = icc / d.C, c = icc - tap * d.C;
+    const int kh = tap / d.KW, kw = tap - kh * d.KW;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int r = a_r + A_RPP * i;
+      const int dw = r % gw, dh = (r / gw) % gh, dn = r / (gw * gh);
+      ch[i] = colok ? dh * d.stride - d.pad + kh : -(1 << 30);   // a column past Kg never validates
+      cw[i] = dw * d.stride - d.pad + kw;
+      va[i] = (unsigned)((((dn * d.H + dh * d.stride + kh) * d.W + dw * d.stride + kw) * d.ldx + c) * 4);
+      inv[i] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int col = n0 + b_c4 * 4;
+      vb[i] = (col < Ncol) ? (unsigned)((((b_r + B_RPP * i) * d.ldy) + col) * 4) : LEAN_OOB;
+    }
+  }
+
+  // ---------------- per-tile (wave-uniform) state and loaders ----------------
+  float4 ra[PA], rb[PB];
+  unsigned soffA = 0, soffB = 0;
+  int t_next = 0;
+  __amdgpu_buffer_rsrc_t rsA = lean_rsrc(baseA, false), rsB = lean_rsrc(baseB, false);
+
+  // fix the scalar offsets / descriptors of tile t_next, then step the walk
+  auto begin_tile = [&]() {
+    const bool on = t_next < T;          // past the last tile: descriptors with 0 records -> every load is a zero fill
+    rsA = lean_rsrc(baseA, on);
+    rsB = lean_rsrc(baseB, on);
+    if constexpr (MODE == MODE_FWD) {
+      soffA = (unsigned)(((u_a * d.W + u_b) * d.ldx + u_c0) * 4);
+      soffB = (unsigned)(t_next * BK * d.ldw * 4);
+    } else if constexpr (MODE == MODE_DGRAD) {
+      soffA = (unsigned)((((nth - 1 - u_a) * d.Wo + (ntw - 1 - u_b)) * d.ldy + u_c0) * 4);
+      const int tapflat = (kh0 + d.stride * u_a) * d.KW + (kw0 + d.stride * u_b);
+      soffB = (unsigned)((tapflat * d.C * d.ldw + u_c0) * 4);
+    } else {
+      soffA = (unsigned)(((((u_n - n_begin) * d.H + u_h * d.stride) * d.W + u_w * d.stride) * d.ldx) * 4);
+      soffB = (unsigned)(t_next * BK * d.ldy * 4);
+    }
+  };
+  auto end_tile = [&]() {   // advance the walk to the tile after t_next
+    ++t_next;
+    if constexpr (MODE == MODE_FWD) {
+      u_c0 += BK;
+      if (u_c0 == d.C) { u_c0 = 0; ++u_tap; ++u_b; if (u_b == d.KW) { u_b = 0; ++u_a; } }
+    } else if constexpr (MODE == MODE_DGRAD) {
+      u_c0 += BK;
+      if (u_c0 == d.K) { u_c0 = 0; ++u_tap; ++u_b; if (u_b == ntw) { u_b = 0; ++u_a; } }
+    } else {
+      u_w += gw;
+      if (u_w == d.Wo) { u_w = 0; u_h += gh; if (u_h == d.Ho) { u_h = 0; u_n += gn; } }
+    }
+  };
+  auto load_a_piece = [&](int i) {
+    unsigned v;
+    if constexpr (MODE == MODE_WGRAD) {
+      const bool ok = (unsigned)(u_h * d.stride + ch[i]) < (unsigned)d.H && (unsigned)(u_w * d.stride + cw[i]) < (unsigned)d.W;
+      v = ok ? va[i] : LEAN_OOB;
+    } else {
+      v = va[i] | ((inv[i] >> u_tap) << 31);
+    }
+    ra[i] = bload4(rsA, v, soffA);
+  };
+  auto load_b_piece = [&](int i) { rb[i] = bload4(rsB, vb[i], soffB); };
+
+  // ---------------- LDS addressing (dword indices relative to the current buffer) ----------------
+  int wrA, wrB, rdA[TM], rdB[TN];
+  if constexpr (A_Q) {
+    wrA = kq * QSA + qrow * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) rdA[i] = lhi * QSA + (wm * WM + i * 32 + l31) * 4;
+  } else {
+    wrA = a_r * BM + ((a_c4 * 4) ^ (((a_r >> 2) & 1) * 32));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) rdA[i] = 4 * lhi * BM + ((wm * WM + i * 32 + l31) ^ (32 * lhi));
+  }
+  if constexpr (B_Q) {
+    wrB = A_SZ + kq * QSB + qrow * 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) rdB[j] = A_SZ + lhi * QSB + (wn * WN + j * 32 + l31) * 4;
+  } else {
+    wrB = A_SZ + b_r * BN + ((b_c4 * 4) ^ (((b_r >> 2) & 1) * 32));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) rdB[j] = A_SZ + 4 * lhi * BN + ((wn * WN + j * 32 + l31) ^ (32 * lhi));
+  }
+
+  // WGRAD bias gradient: B IS gy, so the first M-tile's blocks also accumulate its column sums
+  float4 colacc = zero4();
+  const bool do_bias = (MODE == MODE_WGRAD) && p.bias_ws != nullptr && tile_m == 0;   // uniform per block
+
+  auto store_a_piece = [&](int bufoff, int i) {
+    float* dst = smem + bufoff + wrA + (A_Q ? i * 256 : i * A_RPP * BM);
+    *reinterpret_cast<float4*>(dst) = ra[i];
+  };
+  auto store_b_piece = [&](int bufoff, int i) {
+    float* dst = smem + bufoff + wrB + (B_Q ? i * 256 : i * B_RPP * BN);
+    *reinterpret_cast<float4*>(dst) = rb[i];
+    if constexpr (MODE == MODE_WGRAD) {
+      if (do_bias) { colacc.x += rb[i].x; colacc.y += rb[i].y; colacc.z += rb[i].z; colacc.w += rb[i].w; }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (T > 0) {
+    begin_tile();
+#pragma unroll
+    for (int i = 0; i < PA; ++i) load_a_piece(i);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) load_b_piece(i);
+    end_tile();
+#pragma unroll
+    for (int i = 0; i < PA; ++i) store_a_piece(0, i);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) store_b_piece(0, i);
+  }
+  __syncthreads();
+
+  // Main loop: 8 k-steps of TM x TN MFMAs per tile; the next tile's global loads ride between the first k-steps,
+  // its LDS stores (other buffer) between the last ones; fragments of the whole tile are fetched at the top.
+  constexpr int KS = BK / 2;
+  constexpr int A_LD0 = 0, B_LD0 = PA, A_ST0 = KS - PA - PB, B_ST0 = KS - PB;
+  static_assert(A_ST0 >= B_LD0 + PB, "not enough k-steps to schedule the load and store pieces");
+  for (int t = 0; t < T; ++t) {
+    const int cur = (t & 1) * BUF, nxt = BUF - cur;
+    float fa[2][TM][4], fb[2][TN][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (A_Q) {
+          const float4 q = *reinterpret_cast<const float4*>(smem + cur + rdA[i] + 2 * h * QSA);
+          fa[h][i][0] = q.x; fa[h][i][1] = q.y; fa[h][i][2] = q.z; fa[h][i][3] = q.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fa[h][i][j] = smem[cur + rdA[i] + (8 * h + j) * BM];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        if constexpr (B_Q) {
+          const float4 q = *reinterpret_cast<const float4*>(smem + cur + rdB[i] + 2 * h * QSB);
+          fb[h][i][0] = q.x; fb[h][i][1] = q.y; fb[h][i][2] = q.z; fb[h][i][3] = q.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fb[h][i][j] = smem[cur + rdB[i] + (8 * h + j) * BN];
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int h = ks >> 2, j = ks & 3;
+      if (ks == A_LD0) begin_tile();
+      if (ks >= A_LD0 && ks < A_LD0 + PA) load_a_piece(ks - A_LD0);
+      if (ks >= B_LD0 && ks < B_LD0 + PB) load_b_piece(ks - B_LD0);
+      if (ks == B_LD0 + PB - 1) end_tile();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj)
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][i][j], fb[h][jj][j], acc[i][jj], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks >= A_ST0 && ks < A_ST0 + PA) store_a_piece(nxt, ks - A_ST0);
+      if (ks >= B_ST0 && ks < B_ST0 + PB) store_b_piece(nxt, ks - B_ST0);
+    }
+    __syncthreads();
+  }
+
+  // ---------------- epilogue (same as the general kernel) ----------------
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+  if constexpr (MODE == MODE_DGRAD) {
+    long long* rowoff = reinterpret_cast<long long*>(smem);
+    if (tid < BM) {
+      const int m = m0 + tid;
+      long long off = -1;
+      if (m < M) {
+        const int wq = m % Wc, t2 = m / Wc;
+        const int hq = t2 % Hc, n = t2 / Hc;
+        off = ((long long)(n * d.H + hq * d.stride + ph) * d.W + (wq * d.stride + pw)) * d.ldx;
+      }
+      rowoff[tid] = off;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const long long off = rowoff[row];
+        if (off < 0) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int c = n0 + wn * WN + j * 32 + l31;
+          if (c < Ncol) {
+            float v = acc[i][j][r];
+            if (p.act_ref) v *= (p.act_ref[off + c] > 0.f) ? p.gain : p.gain * p.slope;
+            p.C[off + c] = v;
+          }
+        }
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int c = n0 + wn * WN + j * 32 + l31;
+          if (c < Ncol) {
+            float v = acc[i][j][r];
+            if constexpr (MODE == MODE_FWD) {
+              if (p.bias) v += p.bias[c];
+              v = (v > 0.f) ? v : v * p.slope;
+              v *= p.gain;
+              p.C[(size_t)m * d.ldy + c] = v;
+            } else {
+              p.C[((size_t)blockIdx.y * M + m) * Ncol + c] = v;
+            }
+          }
+        }
+      }
+    if constexpr (MODE == MODE_WGRAD) {
+      if (do_bias) {
+        float* red = smem;   // [B_RPP][BN]; the main-loop buffers are free after the last barrier
+        // the store pieces of the last iteration added the zero fill of the tile past the end: harmless
+        *reinterpret_cast<float4*>(red + b_r * BN + b_c4 * 4) = colacc;
+        __syncthreads();
+        if (tid < BN) {
+          float sum = 0.f;
+#pragma unroll
+          for (int r = 0; r < B_RPP; ++r) sum += red[r * BN + tid];
+          const int c = n0 + tid;
+          if (c < Ncol) p.bias_ws[(size_t)blockIdx.y * Ncol + c] = sum;
+        }
+      }
+    }
+  }
+}
+
+// smem: two buffers of A + B (<= 2 * (2112 + 2112) floats = 33 KB), or the epilogue's row table
+template <int MODE, int BM, int BN>
+constexpr size_t lean_smem_bytes() {
+  const int a = (MODE != MODE_WGRAD) ? 4 * (BM * 4 + 16) : 16 * BM;
+  const int b = (MODE == MODE_DGRAD) ? 4 * (BN * 4 + 16) : 16 * BN;
+  size_t main_loop = 2 * (size_t)(a + b) * sizeof(float);
+  size_t epi = (size_t)BM * sizeof(long long);
+  return main_loop > epi ? main_loop : epi;
+}

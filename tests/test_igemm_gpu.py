@@ -25,6 +25,16 @@ CASES = [
     (7, 1, 1, 512, 1, 1, 1, 0),        # linear 512 -> 1 (Cout = 1)
     (70, 1, 1, 8192, 384, 1, 1, 0),    # wide linear (heads)
     (3, 6, 6, 516, 32, 3, 1, 1),       # Cin = 513 padded to 516 (last_conv)
+    # lean-loop geometry (igemm_lean.h): K-tiles inside one tap, WGRAD 16-position patches
+    (4, 64, 64, 32, 64, 3, 1, 1),      # wide rows: patch = 16 consecutive wo, Wo = 64
+    (2, 64, 64, 16, 32, 3, 2, 1),      # Cin = 16 (one K-tile per tap), stride 2, Ho = 32
+    (32, 1, 1, 256, 128, 1, 1, 0),     # linear: patch = 16 images
+    (16, 2, 2, 64, 64, 3, 1, 1),       # 2x2 maps: patch = 4 images, every tap but the centre is padding somewhere
+    (8, 4, 4, 64, 96, 4, 2, 1),        # Cout = 96: ragged column tile
+    (3, 16, 16, 48, 80, 3, 1, 1),      # Kg = 432: ragged WGRAD row tile
+    (2, 20, 12, 32, 48, 3, 1, 1),      # Wo = 12: lean FWD / DGRAD with a ragged M tile, general WGRAD
+    (70, 8, 8, 64, 64, 3, 1, 1),       # M-tiles that start in the middle of an image (descriptor rebasing)
+    (6, 16, 16, 72, 136, 3, 1, 1),     # Cin % 16 != 0: the general float4 kernel at the big tile
 ]
 
 
