@@ -80,7 +80,12 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-dist', action='store_true',
                     help='dev: run all collective code paths on a 1-rank RCCL group (single GPU)')
+    ap.add_argument('--dev-local-batch', type=int, default=0,
+                    help='dev: single-GPU run at this batch (what one rank of an N-GPU job sees); not the headline config')
     args = ap.parse_args()
+    global GLOBAL_BATCH
+    if args.dev_local_batch:
+        GLOBAL_BATCH = args.dev_local_batch
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -115,7 +120,7 @@ def main():
                                             os.path.join(config.CONFIG_ROOT, 'defaults', 'augment.gin'),
                                             os.path.join(config.CONFIG_ROOT, 'gan', 'cifar10', 'c10_b512.gin')])
     opt = config.get_bindings('options')
-    assert opt['batch_size'] == GLOBAL_BATCH and GLOBAL_BATCH % world == 0
+    assert (opt['batch_size'] == GLOBAL_BATCH or args.dev_local_batch) and GLOBAL_BATCH % world == 0
     n_local = GLOBAL_BATCH // world                          # train_gan.py:247
 
     torch.manual_seed(0 + rank); np.random.seed(0 + rank)

@@ -63,7 +63,7 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 // (C % 4 == 0, K % 4 == 0, leading dimensions % 4 == 0); the !VEC instantiation covers odd shapes (Cin = 3,
 // Cout = 1) with per-element gathers and is only ever a tiny share of a step.
 template <int MODE, int BM, int BN, bool VEC>
-__global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_kernel(const IgemmArgs p) {
+__global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {   // (4 would spill the DGRAD 128x128 instance)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool A_KCONTIG = (MODE != MODE_WGRAD);
   constexpr bool B_KCONTIG = (MODE == MODE_DGRAD);
@@ -764,6 +764,7 @@ bool lean_ok(const contrad_conv_desc* d, int mode, long long pps) {
   if (gw <= 0 || 16 % gw || d->Wo % gw) return false;
   const int gh = d->Ho < 16 / gw ? d->Ho : 16 / gw;
   if ((16 / gw) % gh || d->Ho % gh) return false;
+  if (d->pad > gh * d->stride || d->pad > gw * d->stride) return false;     // interior patches must never touch padding
   const long long imgs = pps * 16 / ((long long)d->Ho * d->Wo) + 2;         // images one split walks over
   return imgs * img_x < lim && pps * 16 * d->ldy * 4 < lim;
 }
@@ -777,14 +778,18 @@ bool vec_ok(const contrad_conv_desc* d, int mode) {
   return c4 && k4;                                      // WGRAD: x rows and gy rows
 }
 
-// Tile choice: biggest tile that still yields enough blocks to fill 256 CUs x 2 blocks.
-void pick_tile(long long M, int Ncol, bool vec, int* bm, int* bn) {
+// Tile choice: the biggest tile that still yields >= 3 blocks per CU (4 are resident); measured on the lean
+// kernels at 3N = 192 / 384 / 1536 images (tools/ab_tile.sh): below that fill the 64x64 tile (TM = TN = 1) wins even
+// though it does 4x the LDS traffic per flop.  mult = independent grids of this size (DGRAD parity classes).
+void pick_tile(long long M, int Ncol, bool vec, int mult, int* bm, int* bn) {
   if (!vec) { *bm = 64; *bn = 64; return; }
-  *bn = (Ncol > 64) ? 128 : 64;
-  const long long tn = (Ncol + *bn - 1) / *bn;
-  *bm = 128;
-  if (((M + 127) / 128) * tn < 512 && M > 64) *bm = 64;
-  if (*bm == 64 && *bn == 128 && ((M + 63) / 64) * tn < 384) *bn = 64;
+  static const int forced = []() { const char* e = getenv("CONTRAD_IGEMM_TILE"); return e ? atoi(e) : 0; }();  // dev: "128064"
+  if (forced) { *bm = forced / 1000; *bn = forced % 1000; return; }
+  static const int cand[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
+  for (int i = (Ncol > 64 ? 0 : 2); i < 4; ++i) {
+    *bm = cand[i][0]; *bn = cand[i][1];
+    if (cdivll(M, *bm) * cdivll(Ncol, *bn) * mult >= 768) return;
+  }
 }
 
 template <int MODE>
@@ -858,7 +863,7 @@ extern "C" int contrad_conv2d_fwd(const contrad_conv_desc* d, const float* x, co
   a.M = (int)M; a.Ncol = d->K; a.Kg = d->KH * d->KW * d->C;
   int bm, bn;
   const bool vec = vec_ok(d, MODE_FWD);
-  pick_tile(M, d->K, vec, &bm, &bn);
+  pick_tile(M, d->K, vec, 1, &bm, &bn);
   a.tiles_m = cdiv(a.M, bm); a.tiles_n = cdiv(a.Ncol, bn);
   return dispatch<MODE_FWD>(a, bm, bn, vec, dim3(a.tiles_m * a.tiles_n), (hipStream_t)stream);
 }
@@ -878,7 +883,7 @@ extern "C" int contrad_conv2d_dgrad(const contrad_conv_desc* d, const float* gy,
   CONTRAD_ARG(Mc < (1ll << 31));
   int bm, bn;
   const bool vec = vec_ok(d, MODE_DGRAD);
-  pick_tile(Mc, d->C, vec, &bm, &bn);
+  pick_tile(Mc, d->C, vec, s * s, &bm, &bn);
   a.tiles_m = cdiv((int)Mc, bm); a.tiles_n = cdiv(d->C, bn);
   return dispatch<MODE_DGRAD>(a, bm, bn, vec, dim3(a.tiles_m * a.tiles_n, s * s), (hipStream_t)stream);
 }
@@ -888,9 +893,10 @@ extern "C" int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm
   if (rc) return rc;
   CONTRAD_ARG(bm && bn && mode >= 0 && mode <= 2);
   if (mode == MODE_FWD) {
-    pick_tile((long long)d->N * d->Ho * d->Wo, d->K, vec_ok(d, MODE_FWD), bm, bn);
+    pick_tile((long long)d->N * d->Ho * d->Wo, d->K, vec_ok(d, MODE_FWD), 1, bm, bn);
   } else if (mode == MODE_DGRAD) {
-    pick_tile((long long)d->N * cdiv(d->H, d->stride) * cdiv(d->W, d->stride), d->C, vec_ok(d, MODE_DGRAD), bm, bn);
+    pick_tile((long long)d->N * cdiv(d->H, d->stride) * cdiv(d->W, d->stride), d->C, vec_ok(d, MODE_DGRAD),
+              d->stride * d->stride, bm, bn);
   } else {
     int tm, tn, sp, pps;
     wgrad_plan(d, bm, bn, &tm, &tn, &sp, &pps);

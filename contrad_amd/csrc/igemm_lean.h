@@ -73,8 +73,9 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
   const float* baseA = p.A;        // descriptor bases (block-relative, so byte offsets stay far below 2^31)
   const float* baseB = p.B;
   unsigned va[PA], vb[PB];         // per-thread byte offsets (fixed)
-  unsigned inv[PA];                // FWD / DGRAD: bit t set = tap t of this row is padding;  WGRAD: unused
-  int ch[PA], cw[PA];              // WGRAD: input row / column of the element at patch origin (0, 0)
+  unsigned inv[PA];                // FWD / DGRAD: bit t set = tap t of this row is padding
+                                   // WGRAD: bit 0/1/2/3 set = padding when the patch is in the top / bottom row,
+                                   //        left / right column of the output grid (interior patches never pad)
 
   // wave-uniform walk state (of the NEXT tile to be loaded)
   int u_tap = 0, u_a = 0, u_b = 0, u_c0 = 0;   // FWD: tap, kh, kw, c0   DGRAD: ti, th, tw, co0
@@ -177,10 +178,12 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     for (int i = 0; i < PA; ++i) {
       const int r = a_r + A_RPP * i;
       const int dw = r % gw, dh = (r / gw) % gh, dn = r / (gw * gh);
-      ch[i] = colok ? dh * d.stride - d.pad + kh : -(1 << 30);   // a column past Kg never validates
-      cw[i] = dw * d.stride - d.pad + kw;
-      va[i] = (unsigned)((((dn * d.H + dh * d.stride + kh) * d.W + dw * d.stride + kw) * d.ldx + c) * 4);
-      inv[i] = 0;
+      const int chh = dh * d.stride - d.pad + kh, cww = dw * d.stride - d.pad + kw;   // input coords at patch origin 0
+      const int hb = (d.Ho - gh) * d.stride, wb = (d.Wo - gw) * d.stride;
+      inv[i] = ((unsigned)chh < (unsigned)d.H ? 0u : 1u) | ((unsigned)(hb + chh) < (unsigned)d.H ? 0u : 2u) |
+               ((unsigned)cww < (unsigned)d.W ? 0u : 4u) | ((unsigned)(wb + cww) < (unsigned)d.W ? 0u : 8u);
+      va[i] = colok ? (unsigned)((((dn * d.H + dh * d.stride + kh) * d.W + dw * d.stride + kw) * d.ldx + c) * 4)
+                    : LEAN_OOB;     // a column past Kg never validates
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
@@ -192,6 +195,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
   // ---------------- per-tile (wave-uniform) state and loaders ----------------
   float4 ra[PA], rb[PB];
   unsigned soffA = 0, soffB = 0;
+  unsigned edge = 0;   // WGRAD: which borders of the output grid the next patch touches (bits as in inv)
   int t_next = 0;
   __amdgpu_buffer_rsrc_t rsA = lean_rsrc(baseA, false), rsB = lean_rsrc(baseB, false);
 
@@ -210,6 +214,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     } else {
       soffA = (unsigned)(((((u_n - n_begin) * d.H + u_h * d.stride) * d.W + u_w * d.stride) * d.ldx) * 4);
       soffB = (unsigned)(t_next * BK * d.ldy * 4);
+      edge = (u_h == 0 ? 1u : 0u) | (u_h == d.Ho - gh ? 2u : 0u) | (u_w == 0 ? 4u : 0u) | (u_w == d.Wo - gw ? 8u : 0u);
     }
   };
   auto end_tile = [&]() {   // advance the walk to the tile after t_next
@@ -228,8 +233,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
   auto load_a_piece = [&](int i) {
     unsigned v;
     if constexpr (MODE == MODE_WGRAD) {
-      const bool ok = (unsigned)(u_h * d.stride + ch[i]) < (unsigned)d.H && (unsigned)(u_w * d.stride + cw[i]) < (unsigned)d.W;
-      v = ok ? va[i] : LEAN_OOB;
+      v = (inv[i] & edge) ? LEAN_OOB : va[i];
     } else {
       v = va[i] | ((inv[i] >> u_tap) << 31);
     }
@@ -270,7 +274,10 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     float* dst = smem + bufoff + wrB + (B_Q ? i * 256 : i * B_RPP * BN);
     *reinterpret_cast<float4*>(dst) = rb[i];
     if constexpr (MODE == MODE_WGRAD) {
-      if (do_bias) { colacc.x += rb[i].x; colacc.y += rb[i].y; colacc.z += rb[i].z; colacc.w += rb[i].w; }
+      if (do_bias) {   // the empty asm keeps this a real uniform branch: if-converted it costs 8 VALU + 4 selects per
+        asm volatile("" ::: "memory");   // tile in EVERY block, and only 1 block in tiles_m needs it
+        colacc.x += rb[i].x; colacc.y += rb[i].y; colacc.z += rb[i].z; colacc.w += rb[i].w;
+      }
     }
   };
 

@@ -28,7 +28,7 @@ def timeit(fn, iters=None):
     return e0.elapsed_time(e1) / iters
 
 
-def main(B=1536):
+def main(B=int(os.environ.get('CONV_BATCH', '1536'))):
     dev = torch.device('cuda')
     tot = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
     totf = 0.0
