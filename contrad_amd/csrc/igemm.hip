@@ -904,6 +904,18 @@ extern "C" int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm
   return 0;
 }
 
+extern "C" int contrad_conv2d_path(const contrad_conv_desc* d, int mode) {
+  if (check_desc(d) || mode < 0 || mode > 2) return -22;
+  if (!vec_ok(d, mode)) return 0;
+  long long pps = 0;
+  if (mode == MODE_WGRAD) {
+    int bm, bn, tm, tn, sp, p;
+    wgrad_plan(d, &bm, &bn, &tm, &tn, &sp, &p);
+    pps = p;
+  }
+  return lean_ok(d, mode, pps) ? 2 : 1;
+}
+
 extern "C" long long contrad_conv2d_wgrad_workspace_bytes(const contrad_conv_desc* d) {
   if (check_desc(d)) return -22;
   int bm, bn, tm, tn, splits, pps;

@@ -10,7 +10,9 @@
 //   backward: dZ_i  = inv_temp * sum_j (G_ij + G_ji) z_j,  G_ij = c * (exp(S_ij - lse_i) - T_ij) for anchor i
 //             (S is recomputed tile by tile; the weight tile goes through LDS into a second MFMA GEMM).
 //
-// Both GEMMs run on v_mfma_f32_32x32x2_f32.  A block owns 64 rows and walks the columns in tiles of 64.
+// Both GEMMs run on v_mfma_f32_32x32x2_f32.  A block owns 64 rows and every S-th 64-column tile (grid = row tiles x
+// S column splits, S chosen so that ~256 blocks exist: 2N = 1024 rows alone would occupy 16 of the 256 CUs).  The
+// per-split partial (max, sum, target) triples / partial dZ slabs go to a workspace and are merged in a fixed order.
 #include "common.h"
 #include "../../include/contrad_hip.h"
 
@@ -80,8 +82,7 @@ __device__ __forceinline__ f32x16 s_tile(const float* Ar, const float* Zr, int r
 }
 
 template <int DP>
-__global__ __launch_bounds__(256) void contrast_fwd_kernel(ContrastArgs a, float* __restrict__ lse_out,
-                                                           float* __restrict__ rowloss_out) {
+__global__ __launch_bounds__(256) void contrast_fwd_kernel(ContrastArgs a, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LD = DP + 1;
   float* Ar = smem;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void contrast_fwd_kernel(ContrastArgs a, float
 #pragma unroll
   for (int r = 0; r < 16; ++r) { m[r] = -INFINITY; s[r] = 0.f; tsum[r] = 0.f; }
 
-  for (int c0 = 0; c0 < a.R; c0 += CT) {
+  for (int c0 = blockIdx.y * CT; c0 < a.R; c0 += gridDim.y * CT) {
     __syncthreads();
     stage_rows<DP>(Zr, a.z, c0, a.R, a.D);
     __syncthreads();
@@ -150,19 +151,34 @@ __global__ __launch_bounds__(256) void contrast_fwd_kernel(ContrastArgs a, float
       const float mn = fmaxf(q0[0], q1[0]);
       const float sa = (q0[0] == -INFINITY) ? 0.f : q0[1] * __expf(q0[0] - mn);
       const float sb = (q1[0] == -INFINITY) ? 0.f : q1[1] * __expf(q1[0] - mn);
-      const float lse = mn + __logf(sa + sb);
-      lse_out[i] = lse;
-      rowloss_out[i] = is_anchor(a, i) ? (lse - (q0[2] + q1[2])) : 0.f;
+      float* o = part + ((size_t)blockIdx.y * a.R + i) * 3;   // this split's (max, sum exp, target) of row i
+      o[0] = mn; o[1] = sa + sb; o[2] = q0[2] + q1[2];
     }
   }
 }
 
-// loss = c * sum_i rowloss[i], fixed order (single block)
-__global__ void contrast_loss_reduce_kernel(const float* __restrict__ rowloss, int R, float c,
+// Merge the S column splits of every row (fixed order), emit lse / rowloss, and reduce
+// loss = c * sum_i rowloss[i] (single block -> one fixed summation order).
+__global__ void contrast_loss_reduce_kernel(ContrastArgs a, const float* __restrict__ part, int S, float c,
+                                            float* __restrict__ lse_out, float* __restrict__ rowloss_out,
                                             float* __restrict__ loss_out) {
   __shared__ float red[16];
   float v = 0.f;
-  for (int i = threadIdx.x; i < R; i += blockDim.x) v += rowloss[i];
+  for (int i = threadIdx.x; i < a.R; i += blockDim.x) {
+    float mn = -INFINITY;
+    for (int s = 0; s < S; ++s) mn = fmaxf(mn, part[((size_t)s * a.R + i) * 3]);
+    float sum = 0.f, t = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float* q = part + ((size_t)s * a.R + i) * 3;
+      if (q[0] != -INFINITY) sum += q[1] * __expf(q[0] - mn);
+      t += q[2];
+    }
+    const float lse = mn + __logf(sum);
+    lse_out[i] = lse;
+    const float rl = is_anchor(a, i) ? (lse - t) : 0.f;
+    rowloss_out[i] = rl;
+    v += rl;
+  }
   v = block_sum(v, red);
   if (threadIdx.x == 0) loss_out[0] = v * c;
 }
@@ -170,7 +186,7 @@ __global__ void contrast_loss_reduce_kernel(const float* __restrict__ rowloss, i
 template <int DP>
 __global__ __launch_bounds__(256) void contrast_bwd_kernel(ContrastArgs a, const float* __restrict__ lse,
                                                            float coef, const float* __restrict__ gscale,
-                                                           float* __restrict__ dz) {
+                                                           float* __restrict__ dz, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LD = DP + 1;
   constexpr int LDW = RT + 1;
@@ -196,7 +212,7 @@ __global__ __launch_bounds__(256) void contrast_bwd_kernel(ContrastArgs a, const
 #pragma unroll
     for (int r = 0; r < 16; ++r) dacc[t][r] = 0.f;
 
-  for (int c0 = 0; c0 < a.R; c0 += CT) {
+  for (int c0 = blockIdx.y * CT; c0 < a.R; c0 += gridDim.y * CT) {
     __syncthreads();
     stage_rows<DP>(Zr, a.z, c0, a.R, a.D);
     if (tid < CT) lse_c[tid] = (c0 + tid < a.R) ? lse[c0 + tid] : 0.f;
@@ -235,8 +251,22 @@ __global__ __launch_bounds__(256) void contrast_bwd_kernel(ContrastArgs a, const
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = r0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      if (i < a.R && dcol < a.D) dz[(size_t)i * a.D + dcol] = dacc[t][r] * scale;
+      if (i < a.R && dcol < a.D) {
+        if (gridDim.y == 1) dz[(size_t)i * a.D + dcol] = dacc[t][r] * scale;
+        else part[((size_t)blockIdx.y * a.R + i) * a.D + dcol] = dacc[t][r];   // unscaled slab of this split
+      }
     }
+  }
+}
+
+// dz = scale * sum_s part[s]  (fixed order)
+__global__ void contrast_bwd_reduce_kernel(const float* __restrict__ part, int S, long long n, float coef_temp,
+                                           const float* __restrict__ gscale, float* __restrict__ dz) {
+  const float scale = coef_temp * (gscale ? gscale[0] : 1.f);
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += part[(size_t)s * n + e];
+    dz[e] = v * scale;
   }
 }
 
@@ -278,7 +308,7 @@ template <int DP>
 size_t bwd_smem() { return (size_t)(2 * 64 * (DP + 1) + 64 * 65 + 128) * sizeof(float); }
 
 template <int DP>
-int launch_fwd(const ContrastArgs& a, float* lse, float* rowloss, hipStream_t s) {
+int launch_fwd(const ContrastArgs& a, int S, float* part, hipStream_t s) {
   static bool set = false;
   if (!set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&contrast_fwd_kernel<DP>),
@@ -286,14 +316,13 @@ int launch_fwd(const ContrastArgs& a, float* lse, float* rowloss, hipStream_t s)
     if (e != hipSuccess) return (int)e;
     set = true;
   }
-  hipLaunchKernelGGL((contrast_fwd_kernel<DP>), dim3(cdiv(a.R, RT)), dim3(256), fwd_smem<DP>(), s, a, lse,
-                     rowloss);
+  hipLaunchKernelGGL((contrast_fwd_kernel<DP>), dim3(cdiv(a.R, RT), S), dim3(256), fwd_smem<DP>(), s, a, part);
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }
 template <int DP>
-int launch_bwd(const ContrastArgs& a, const float* lse, float coef, const float* gscale, float* dz,
-               hipStream_t s) {
+int launch_bwd(const ContrastArgs& a, int S, const float* lse, float coef, const float* gscale, float* dz,
+               float* part, hipStream_t s) {
   static bool set = false;
   if (!set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&contrast_bwd_kernel<DP>),
@@ -301,8 +330,8 @@ int launch_bwd(const ContrastArgs& a, const float* lse, float coef, const float*
     if (e != hipSuccess) return (int)e;
     set = true;
   }
-  hipLaunchKernelGGL((contrast_bwd_kernel<DP>), dim3(cdiv(a.R, RT)), dim3(256), bwd_smem<DP>(), s, a, lse,
-                     coef, gscale, dz);
+  hipLaunchKernelGGL((contrast_bwd_kernel<DP>), dim3(cdiv(a.R, RT), S), dim3(256), bwd_smem<DP>(), s, a, lse,
+                     coef, gscale, dz, part);
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }
@@ -314,38 +343,65 @@ int check(int R, int D, int N, int mode) {
   return 0;
 }
 float anchor_coef(int N, int mode) { return mode == 0 ? 1.f / (2.f * N) : 1.f / (float)N; }
+// column splits: ~256 blocks in total, never more splits than column tiles
+int splits(int R) {
+  const int tiles = cdiv(R, RT);
+  int S = 256 / tiles;
+  if (S < 1) S = 1;
+  if (S > tiles) S = tiles;
+  return S;
+}
 
 }  // namespace
 
+extern "C" long long contrad_contrast_workspace_bytes(int R, int D) {
+  if (R <= 0 || D <= 0) return -22;
+  const long long per = (long long)R * (D > 3 ? D : 3);
+  return (long long)splits(R) * per * (long long)sizeof(float);
+}
+
 extern "C" int contrad_contrast_fwd(const float* z, int R, int D, int N, int mode, float inv_temp,
-                                    float* lse, float* rowloss, float* loss, contrad_stream_t stream) {
+                                    float* lse, float* rowloss, float* loss, float* workspace,
+                                    long long workspace_bytes, contrad_stream_t stream) {
   int rc = check(R, D, N, mode);
   if (rc) return rc;
-  CONTRAD_ARG(z && lse && rowloss && loss);
+  CONTRAD_ARG(z && lse && rowloss && loss && workspace);
+  CONTRAD_ARG(workspace_bytes >= contrad_contrast_workspace_bytes(R, D));
   ContrastArgs a{z, R, D, N, mode, inv_temp};
   hipStream_t s = (hipStream_t)stream;
-  if (D <= 64) rc = launch_fwd<64>(a, lse, rowloss, s);
-  else if (D <= 128) rc = launch_fwd<128>(a, lse, rowloss, s);
-  else rc = launch_fwd<256>(a, lse, rowloss, s);
+  const int S = splits(R);
+  if (D <= 64) rc = launch_fwd<64>(a, S, workspace, s);
+  else if (D <= 128) rc = launch_fwd<128>(a, S, workspace, s);
+  else rc = launch_fwd<256>(a, S, workspace, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(contrast_loss_reduce_kernel, dim3(1), dim3(256), 0, s, rowloss, R, anchor_coef(N, mode),
-                     loss);
+  hipLaunchKernelGGL(contrast_loss_reduce_kernel, dim3(1), dim3(256), 0, s, a, workspace, S, anchor_coef(N, mode),
+                     lse, rowloss, loss);
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int contrad_contrast_bwd(const float* z, const float* lse, int R, int D, int N, int mode,
-                                    float inv_temp, const float* grad_scale, float* dz,
-                                    contrad_stream_t stream) {
+                                    float inv_temp, const float* grad_scale, float* dz, float* workspace,
+                                    long long workspace_bytes, contrad_stream_t stream) {
   int rc = check(R, D, N, mode);
   if (rc) return rc;
-  CONTRAD_ARG(z && lse && dz);
+  CONTRAD_ARG(z && lse && dz && workspace);
+  CONTRAD_ARG(workspace_bytes >= contrad_contrast_workspace_bytes(R, D));
   ContrastArgs a{z, R, D, N, mode, inv_temp};
   hipStream_t s = (hipStream_t)stream;
   const float c = anchor_coef(N, mode);
-  if (D <= 64) return launch_bwd<64>(a, lse, c, grad_scale, dz, s);
-  if (D <= 128) return launch_bwd<128>(a, lse, c, grad_scale, dz, s);
-  return launch_bwd<256>(a, lse, c, grad_scale, dz, s);
+  const int S = splits(R);
+  if (D <= 64) rc = launch_bwd<64>(a, S, lse, c, grad_scale, dz, workspace, s);
+  else if (D <= 128) rc = launch_bwd<128>(a, S, lse, c, grad_scale, dz, workspace, s);
+  else rc = launch_bwd<256>(a, S, lse, c, grad_scale, dz, workspace, s);
+  if (rc || S == 1) return rc;
+  const long long n = (long long)R * D;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(contrast_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, s, workspace, S, n, c * inv_temp,
+                     grad_scale, dz);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int contrad_l2norm_fwd(const float* u, int ldu, float* z, float* inv_norm, int R, int D,

@@ -51,27 +51,40 @@ def out_size(h, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1
 
 
-# Optional per-launch profiler (bench.py): when set to a list, every conv-engine launch is bracketed by events on
-# the launch stream and appended as (kernel_name, algorithmic_flops, start_event, end_event).
+# Optional per-launch profiler (bench.py): when set to a list, conv-engine launches are bracketed by events on the
+# launch stream and appended as (kernel_name, algorithmic_flops, start_event, end_event).  kernel_name is the device
+# kernel's name as rocprofv3 prints it.  PROFILE_ONLY (a kernel name) restricts the bracketing to that kernel: every
+# event pair costs ~10 us of stream time, so the timed region of bench.py instruments the dominant kernel only.
+# (A WGRAD bracket spans the split-K main kernel and its wgrad_reduce_kernel: one C-ABI call launches both.)
 PROFILE = None
-_MODE_NAMES = ('FWD', 'DGRAD', 'WGRAD')
+PROFILE_ONLY = None
+
+
+def conv_kernel_name(mode, d):
+    bm, bn = ctypes.c_int(0), ctypes.c_int(0)
+    lib().call('contrad_conv2d_tile', ctypes.byref(d), mode, ctypes.byref(bm), ctypes.byref(bn))
+    path = lib().raw('contrad_conv2d_path')(ctypes.byref(d), mode)
+    if path == 2:
+        return 'igemm_lean_kernel<%d, %d, %d>' % (mode, bm.value, bn.value)
+    return 'igemm_kernel<%d, %d, %d, %s>' % (mode, bm.value, bn.value, 'true' if path == 1 else 'false')
 
 
 def _conv_call(mode, d, name, *args):
     if PROFILE is None:
         lib().call(name, *args)
         return
-    bm, bn = ctypes.c_int(0), ctypes.c_int(0)
-    lib().call('contrad_conv2d_tile', ctypes.byref(d), mode, ctypes.byref(bm), ctypes.byref(bn))
+    kname = conv_kernel_name(mode, d)
+    if PROFILE_ONLY is not None and kname != PROFILE_ONLY:
+        lib().call(name, *args)
+        return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     st = torch.cuda.current_stream()
     e0.record(st)
     lib().call(name, *args)
     e1.record(st)
+    # algorithmic flops; for a strided dgrad this equals the forward count (only contributing taps are multiplied)
     flops = 2.0 * d.N * d.Ho * d.Wo * d.K * d.C * d.KH * d.KW
-    if mode == 1 and d.stride > 1:
-        pass  # algorithmic dgrad flops == forward flops (only contributing taps are multiplied)
-    PROFILE.append(('igemm_kernel<%s,%d,%d>' % (_MODE_NAMES[mode], bm.value, bn.value), flops, e0, e1))
+    PROFILE.append((kname, flops, e0, e1))
 
 
 def make_desc(N, H, W, C, K, KH, KW, stride, pad, ldx, ldy, ldw):
@@ -189,16 +202,20 @@ def contrast_fwd(z, N, mode, temperature):
     lse = torch.empty((R,), device=z.device, dtype=torch.float32)
     rowloss = torch.empty((R,), device=z.device, dtype=torch.float32)
     loss = torch.empty((1,), device=z.device, dtype=torch.float32)
+    nbytes = lib().raw('contrad_contrast_workspace_bytes')(R, D)
+    ws = _workspace(nbytes, z.device)
     lib().call('contrad_contrast_fwd', _p(z), R, D, N, mode, 1.0 / temperature, _p(lse), _p(rowloss), _p(loss),
-               _stream())
+               _p(ws), nbytes, _stream())
     return loss, lse
 
 
 def contrast_bwd(z, lse, N, mode, temperature, grad_scale=None):
     R, D = z.shape
     dz = torch.empty((R, D), device=z.device, dtype=torch.float32)
+    nbytes = lib().raw('contrad_contrast_workspace_bytes')(R, D)
+    ws = _workspace(nbytes, z.device)
     lib().call('contrad_contrast_bwd', _p(z), _p(lse), R, D, N, mode, 1.0 / temperature, _p(grad_scale), _p(dz),
-               _stream())
+               _p(ws), nbytes, _stream())
     return dz
 
 

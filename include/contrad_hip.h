@@ -64,6 +64,9 @@ long long contrad_conv2d_wgrad_workspace_bytes(const contrad_conv_desc* d);
 /* Introspection for profiling: block tile (bm x bn x 32) the launcher picks for `mode` (0 fwd, 1 dgrad,
  * 2 wgrad) on this geometry, i.e. which igemm_kernel<mode, bm, bn> instance runs. */
 int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm, int* bn);
+/* Which kernel family serves this shape: 0 = general scalar-gather (igemm_kernel<..., false>), 1 = general float4
+ * (igemm_kernel<..., true>), 2 = lean loop (igemm_lean_kernel); negative = bad descriptor.  Profiling aid. */
+int contrad_conv2d_path(const contrad_conv_desc* d, int mode);
 int contrad_conv2d_wgrad(const contrad_conv_desc* d, const float* x, const float* gy, float* dwp,
                          float* dbias, float* workspace, long long workspace_bytes, contrad_stream_t stream);
 
@@ -73,12 +76,17 @@ int contrad_conv2d_wgrad(const contrad_conv_desc* d, const float* x, const float
  * (training/gan/contrad.py:8-32; mode 1, R = 3N, anchors = rows 2N..3N) incl. their autograd backward,
  * and F.normalize (contrad.py:43,48).
  * ---------------------------------------------------------------------------------------------- */
+/* Scratch for the column-split partials of either call (the R x R work is spread over ~256 blocks; the
+ * per-split (max, sum, target) triples / dZ slabs are merged in a fixed order -> deterministic). */
+long long contrad_contrast_workspace_bytes(int R, int D);
 /* z[R,D] row-normalised. Writes lse[R], rowloss[R] (scratch) and loss[0] = mean anchor loss. */
 int contrad_contrast_fwd(const float* z, int R, int D, int N, int mode, float inv_temp, float* lse,
-                         float* rowloss, float* loss, contrad_stream_t stream);
+                         float* rowloss, float* loss, float* workspace, long long workspace_bytes,
+                         contrad_stream_t stream);
 /* dz[R,D] = (grad_scale ? grad_scale[0] : 1) * d loss / d z   (lse from contrad_contrast_fwd). */
 int contrad_contrast_bwd(const float* z, const float* lse, int R, int D, int N, int mode, float inv_temp,
-                         const float* grad_scale, float* dz, contrad_stream_t stream);
+                         const float* grad_scale, float* dz, float* workspace, long long workspace_bytes,
+                         contrad_stream_t stream);
 /* z = u / max(||u||_2, eps) per row; inv_norm[R] kept for the backward. */
 int contrad_l2norm_fwd(const float* u, int ldu, float* z, float* inv_norm, int R, int D, float eps,
                        contrad_stream_t stream);

@@ -103,7 +103,7 @@ def test_generator_last_layer_tanh():
     assert rel(out, ref) < TOL
 
 
-@pytest.mark.parametrize('M,K', [(1000, 128), (37, 1), (5000, 1536), (4096, 8192)])
+@pytest.mark.parametrize('M,K', [(1000, 128), (37, 1), (5000, 1536), (4096, 8192), (20000, 64), (1003, 68), (513, 4), (31, 516)])
 def test_colstats(M, K):
     g = torch.Generator().manual_seed(M)
     x = torch.randn(M, K, generator=g)
