@@ -781,8 +781,9 @@ bool vec_ok(const contrad_conv_desc* d, int mode) {
 // Tile choice: the biggest tile that still yields >= 3 blocks per CU (4 are resident); measured on the lean
 // kernels at 3N = 192 / 384 / 1536 images (tools/ab_tile.sh): below that fill the 64x64 tile (TM = TN = 1) wins even
 // though it does 4x the LDS traffic per flop.  mult = independent grids of this size (DGRAD parity classes).
-void pick_tile(long long M, int Ncol, bool vec, int mult, int* bm, int* bn) {
+void pick_tile(long long M, int Ncol, bool vec, bool lean, int mult, int* bm, int* bn) {
   if (!vec) { *bm = 64; *bn = 64; return; }
+  if (lean && Ncol <= 32) { *bm = 128; *bn = 32; return; }   // lean only: 4 x 1 waves, no MFMA columns wasted
   static const int forced = []() { const char* e = getenv("CONTRAD_IGEMM_TILE"); return e ? atoi(e) : 0; }();  // dev: "128064"
   if (forced) { *bm = forced / 1000; *bn = forced % 1000; return; }
   static const int cand[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
@@ -795,6 +796,7 @@ void pick_tile(long long M, int Ncol, bool vec, int mult, int* bm, int* bn) {
 template <int MODE>
 int dispatch(const IgemmArgs& a, int bm, int bn, bool vec, dim3 grid, hipStream_t s) {
   if (vec && lean_ok(&a.d, MODE, a.ptiles_per_split)) {
+    if (bn == 32) return launch_lean<MODE, 128, 32>(a, grid, s);
     if (bm == 128 && bn == 128) return launch_lean<MODE, 128, 128>(a, grid, s);
     if (bm == 128 && bn == 64) return launch_lean<MODE, 128, 64>(a, grid, s);
     if (bm == 64 && bn == 128) return launch_lean<MODE, 64, 128>(a, grid, s);
@@ -843,6 +845,7 @@ int wgrad_plan(const contrad_conv_desc* d, int* bm, int* bn, int* tiles_m, int* 
   if (pps > ptiles) pps = ptiles;
   *ptiles_per_split = (int)pps;
   *splits = (int)cdivll(ptiles, pps);
+  if (d->K <= 32 && *bm == 128 && vec_ok(d, MODE_WGRAD) && lean_ok(d, MODE_WGRAD, pps)) *bn = 32;   // (tiles_n stays 1)
   return 0;
 }
 
@@ -863,7 +866,7 @@ extern "C" int contrad_conv2d_fwd(const contrad_conv_desc* d, const float* x, co
   a.M = (int)M; a.Ncol = d->K; a.Kg = d->KH * d->KW * d->C;
   int bm, bn;
   const bool vec = vec_ok(d, MODE_FWD);
-  pick_tile(M, d->K, vec, 1, &bm, &bn);
+  pick_tile(M, d->K, vec, vec && lean_ok(d, MODE_FWD, 0), 1, &bm, &bn);
   a.tiles_m = cdiv(a.M, bm); a.tiles_n = cdiv(a.Ncol, bn);
   return dispatch<MODE_FWD>(a, bm, bn, vec, dim3(a.tiles_m * a.tiles_n), (hipStream_t)stream);
 }
@@ -883,7 +886,7 @@ extern "C" int contrad_conv2d_dgrad(const contrad_conv_desc* d, const float* gy,
   CONTRAD_ARG(Mc < (1ll << 31));
   int bm, bn;
   const bool vec = vec_ok(d, MODE_DGRAD);
-  pick_tile(Mc, d->C, vec, s * s, &bm, &bn);
+  pick_tile(Mc, d->C, vec, vec && lean_ok(d, MODE_DGRAD, 0), s * s, &bm, &bn);
   a.tiles_m = cdiv((int)Mc, bm); a.tiles_n = cdiv(d->C, bn);
   return dispatch<MODE_DGRAD>(a, bm, bn, vec, dim3(a.tiles_m * a.tiles_n, s * s), (hipStream_t)stream);
 }
@@ -893,10 +896,11 @@ extern "C" int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm
   if (rc) return rc;
   CONTRAD_ARG(bm && bn && mode >= 0 && mode <= 2);
   if (mode == MODE_FWD) {
-    pick_tile((long long)d->N * d->Ho * d->Wo, d->K, vec_ok(d, MODE_FWD), 1, bm, bn);
+    pick_tile((long long)d->N * d->Ho * d->Wo, d->K, vec_ok(d, MODE_FWD), vec_ok(d, MODE_FWD) && lean_ok(d, MODE_FWD, 0),
+              1, bm, bn);
   } else if (mode == MODE_DGRAD) {
     pick_tile((long long)d->N * cdiv(d->H, d->stride) * cdiv(d->W, d->stride), d->C, vec_ok(d, MODE_DGRAD),
-              d->stride * d->stride, bm, bn);
+              vec_ok(d, MODE_DGRAD) && lean_ok(d, MODE_DGRAD, 0), d->stride * d->stride, bm, bn);
   } else {
     int tm, tn, sp, pps;
     wgrad_plan(d, bm, bn, &tm, &tn, &sp, &pps);

@@ -46,17 +46,23 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
   constexpr bool A_Q = (MODE != MODE_WGRAD);   // A K-contiguous in memory -> quad layout
   constexpr bool B_Q = (MODE == MODE_DGRAD);
   constexpr int QSA = BM * 4 + 16, QSB = BN * 4 + 16;   // quad stride (+16: the 4 quads of a row-group hit 4 bank groups)
+  constexpr int LDB = BN < 64 ? 64 : BN;                // row layout: >= 64 columns so the XOR-32 swizzle stays inside a row
   constexpr int A_SZ = A_Q ? 4 * QSA : 16 * BM;
-  constexpr int B_SZ = B_Q ? 4 * QSB : 16 * BN;
+  constexpr int B_SZ = B_Q ? 4 * QSB : 16 * LDB;
   constexpr int BUF = A_SZ + B_SZ;
-  constexpr int PA = BM / 64, PB = BN / 64;             // float4 prefetch registers per operand
+  constexpr int PA = BM / 64, PB = BN < 64 ? 1 : BN / 64;   // float4 prefetch registers per operand
   constexpr int A_RPP = 1024 / BM, B_RPP = 1024 / BN;   // k-rows per pass of the row-layout loader
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  // BN = 32 (StyleGAN2's 32-channel layers at 512x512): the B tile is 128 float4, so only threads with b_r < 16
+  // (row layout) / qrow < 32 (quad layout) own a piece of it; the 4 waves stack 4 x 1 over the rows.
+  constexpr bool B_HALF = BN < 64;
+  constexpr int WAVES_N = BN < 64 ? 1 : 2, WAVES_M = 4 / WAVES_N;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+  static_assert(TM >= 1 && TN >= 1, "tile too small for the wave arrangement");
 
   const contrad_conv_desc& d = p.d;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int l31 = lane & 31, lhi = lane >> 5;
 
   const int b = xcd_remap(blockIdx.x, gridDim.x);
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       const int col = n0 + b_c4 * 4;
-      vb[i] = (col < Ncol) ? (unsigned)((((b_r + B_RPP * i) * d.ldw) + col) * 4) : LEAN_OOB;
+      vb[i] = (col < Ncol && b_r + B_RPP * i < BK) ? (unsigned)((((b_r + B_RPP * i) * d.ldw) + col) * 4) : LEAN_OOB;
     }
   } else if constexpr (MODE == MODE_DGRAD) {
     const int s = d.stride;
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       const int c = n0 + qrow + 64 * i;
-      vb[i] = (c < Ncol) ? (unsigned)((c * d.ldw + kq * 4) * 4) : LEAN_OOB;
+      vb[i] = (c < Ncol && qrow + 64 * i < BN) ? (unsigned)((c * d.ldw + kq * 4) * 4) : LEAN_OOB;
     }
   } else {
     const int tiles_total = p.P / BK;
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       const int col = n0 + b_c4 * 4;
-      vb[i] = (col < Ncol) ? (unsigned)((((b_r + B_RPP * i) * d.ldy) + col) * 4) : LEAN_OOB;
+      vb[i] = (col < Ncol && b_r + B_RPP * i < BK) ? (unsigned)((((b_r + B_RPP * i) * d.ldy) + col) * 4) : LEAN_OOB;
     }
   }
 
@@ -257,9 +263,9 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
 #pragma unroll
     for (int j = 0; j < TN; ++j) rdB[j] = A_SZ + lhi * QSB + (wn * WN + j * 32 + l31) * 4;
   } else {
-    wrB = A_SZ + b_r * BN + ((b_c4 * 4) ^ (((b_r >> 2) & 1) * 32));
+    wrB = A_SZ + b_r * LDB + ((b_c4 * 4) ^ (((b_r >> 2) & 1) * 32));
 #pragma unroll
-    for (int j = 0; j < TN; ++j) rdB[j] = A_SZ + 4 * lhi * BN + ((wn * WN + j * 32 + l31) ^ (32 * lhi));
+    for (int j = 0; j < TN; ++j) rdB[j] = A_SZ + 4 * lhi * LDB + ((wn * WN + j * 32 + l31) ^ (32 * lhi));
   }
 
   // WGRAD bias gradient: B IS gy, so the first M-tile's blocks also accumulate its column sums
@@ -270,9 +276,10 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     float* dst = smem + bufoff + wrA + (A_Q ? i * 256 : i * A_RPP * BM);
     *reinterpret_cast<float4*>(dst) = ra[i];
   };
+  const bool b_owner = !B_HALF || (B_Q ? qrow < BN : b_r < BK);   // does this thread own a piece of the B tile?
   auto store_b_piece = [&](int bufoff, int i) {
-    float* dst = smem + bufoff + wrB + (B_Q ? i * 256 : i * B_RPP * BN);
-    *reinterpret_cast<float4*>(dst) = rb[i];
+    float* dst = smem + bufoff + wrB + (B_Q ? i * 256 : i * B_RPP * LDB);
+    if (b_owner) *reinterpret_cast<float4*>(dst) = rb[i];
     if constexpr (MODE == MODE_WGRAD) {
       if (do_bias) {   // the empty asm keeps this a real uniform branch: if-converted it costs 8 VALU + 4 selects per
         asm volatile("" ::: "memory");   // tile in EVERY block, and only 1 block in tiles_m needs it
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
           fb[h][i][0] = q.x; fb[h][i][1] = q.y; fb[h][i][2] = q.z; fb[h][i][3] = q.w;
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) fb[h][i][j] = smem[cur + rdB[i] + (8 * h + j) * BN];
+          for (int j = 0; j < 4; ++j) fb[h][i][j] = smem[cur + rdB[i] + (8 * h + j) * LDB];
         }
       }
     }
@@ -414,6 +421,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
       if (do_bias) {
         float* red = smem;   // [B_RPP][BN]; the main-loop buffers are free after the last barrier
         // the store pieces of the last iteration added the zero fill of the tile past the end: harmless
+        // (threads that own no piece of a BN = 32 tile loaded zero fills only: their colacc is 0)
         *reinterpret_cast<float4*>(red + b_r * BN + b_c4 * 4) = colacc;
         __syncthreads();
         if (tid < BN) {
@@ -432,7 +440,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
 template <int MODE, int BM, int BN>
 constexpr size_t lean_smem_bytes() {
   const int a = (MODE != MODE_WGRAD) ? 4 * (BM * 4 + 16) : 16 * BM;
-  const int b = (MODE == MODE_DGRAD) ? 4 * (BN * 4 + 16) : 16 * BN;
+  const int b = (MODE == MODE_DGRAD) ? 4 * (BN * 4 + 16) : 16 * (BN < 64 ? 64 : BN);
   size_t main_loop = 2 * (size_t)(a + b) * sizeof(float);
   size_t epi = (size_t)BM * sizeof(long long);
   return main_loop > epi ? main_loop : epi;

@@ -35,6 +35,9 @@ CASES = [
     (2, 20, 12, 32, 48, 3, 1, 1),      # Wo = 12: lean FWD / DGRAD with a ragged M tile, general WGRAD
     (70, 8, 8, 64, 64, 3, 1, 1),       # M-tiles that start in the middle of an image (descriptor rebasing)
     (6, 16, 16, 72, 136, 3, 1, 1),     # Cin % 16 != 0: the general float4 kernel at the big tile
+    (2, 32, 32, 32, 32, 3, 1, 1),      # 32 -> 32 channels (StyleGAN2 at 512x512): the 128x32 tile in all three modes
+    (3, 16, 16, 64, 16, 3, 1, 1),      # Cout = 16: half-empty 32-column tile; DGRAD contraction of one K-tile per tap
+    (2, 16, 16, 16, 32, 3, 2, 1),      # Cin = 16 -> DGRAD writes a 16-column tile
 ]
 
 
