@@ -51,6 +51,7 @@ struct IgemmArgs {
   int tiles_m, tiles_n;
   int P;                 // WGRAD: total positions n*ho*wo
   int ptiles_per_split;  // WGRAD
+  int ny;                // lean kernels: grid.y folded into the 1-D grid (DGRAD classes / WGRAD splits)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -734,7 +735,9 @@ int launch_lean(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_lean_kernel<MODE, BM, BN>), grid, dim3(NTHREADS), smem, stream, a);
+  IgemmArgs b = a;
+  b.ny = (int)grid.y;
+  hipLaunchKernelGGL((igemm_lean_kernel<MODE, BM, BN>), dim3(grid.x * grid.y), dim3(NTHREADS), smem, stream, b);
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }

@@ -65,8 +65,23 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int l31 = lane & 31, lhi = lane >> 5;
 
-  const int b = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = b % p.tiles_n, tile_m = b / p.tiles_n;
+  // 1-D grid, remapped so that each XCD (own L2) owns a contiguous run of ids.  Decode order = who shares operands:
+  //   FWD    tile_n fastest                      (the N-tiles of one M-tile read the same im2col rows)
+  //   DGRAD  tile_n, then parity class, tile_m   (the s*s classes of one M-tile read the same gy pixels)
+  //   WGRAD  all (tile_m, tile_n) of one split   (every tile of a split reads the same positions of x and gy)
+  // Before this the 9..36 tiles of a WGRAD split sat on 8 different XCDs and HBM traffic was 6.5x the algorithmic bytes.
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  int by, tile_n, tile_m;
+  if constexpr (MODE == MODE_WGRAD) {
+    const int tiles = p.tiles_m * p.tiles_n;
+    by = lin / tiles;
+    const int b = lin - by * tiles;
+    tile_n = b % p.tiles_n; tile_m = b / p.tiles_n;
+  } else {
+    tile_n = lin % p.tiles_n;
+    const int r = lin / p.tiles_n;
+    by = r % p.ny; tile_m = r / p.ny;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // loader coordinates: quad loader = (row qrow + 64 i, k-quad kq); row loader = (k-row r + RPP i, column quad c4)
@@ -119,8 +134,8 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     }
   } else if constexpr (MODE == MODE_DGRAD) {
     const int s = d.stride;
-    ph = blockIdx.y / s;
-    pw = blockIdx.y % s;
+    ph = by / s;
+    pw = by % s;
     Hc = (d.H - ph + s - 1) / s;
     Wc = (d.W - pw + s - 1) / s;
     kh0 = (ph + d.pad) % s;
@@ -162,7 +177,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     }
   } else {
     const int tiles_total = p.P / BK;
-    const int t_begin = blockIdx.y * p.ptiles_per_split;
+    const int t_begin = by * p.ptiles_per_split;
     T = min(p.ptiles_per_split, tiles_total - t_begin);
     if (T < 0) T = 0;
     gw = min(d.Wo, 16);
@@ -212,7 +227,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     rsB = lean_rsrc(baseB, on);
     if constexpr (MODE == MODE_FWD) {
       soffA = (unsigned)(((u_a * d.W + u_b) * d.ldx + u_c0) * 4);
-      soffB = (unsigned)(t_next * BK * d.ldw * 4);
+      soffB = (unsigned)((u_tap * d.C + u_c0) * d.ldw * 4);
     } else if constexpr (MODE == MODE_DGRAD) {
       soffA = (unsigned)((((nth - 1 - u_a) * d.Wo + (ntw - 1 - u_b)) * d.ldy + u_c0) * 4);
       const int tapflat = (kh0 + d.stride * u_a) * d.KW + (kw0 + d.stride * u_b);
@@ -226,11 +241,15 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
   auto end_tile = [&]() {   // advance the walk to the tile after t_next
     ++t_next;
     if constexpr (MODE == MODE_FWD) {
-      u_c0 += BK;
-      if (u_c0 == d.C) { u_c0 = 0; ++u_tap; ++u_b; if (u_b == d.KW) { u_b = 0; ++u_a; } }
+      // contraction order: all taps of one 16-channel chunk, then the next chunk.  The KH*KW taps of a chunk re-read the
+      // same few input pixels (64 B each) in consecutive tiles -> L1/L2 hits; tap-major order swept the block's whole
+      // input window (all channels) once per tap, 128 blocks per XCD x ~100 KB did not fit the 4 MB L2, and the
+      // kernel fetched 5x its algorithmic bytes from HBM.
+      ++u_tap; ++u_b;
+      if (u_b == d.KW) { u_b = 0; ++u_a; if (u_a == d.KH) { u_a = 0; u_tap = 0; u_c0 += BK; } }
     } else if constexpr (MODE == MODE_DGRAD) {
-      u_c0 += BK;
-      if (u_c0 == d.K) { u_c0 = 0; ++u_tap; ++u_b; if (u_b == ntw) { u_b = 0; ++u_a; } }
+      ++u_tap; ++u_b;
+      if (u_b == ntw) { u_b = 0; ++u_a; if (u_a == nth) { u_a = 0; u_tap = 0; u_c0 += BK; } }
     } else {
       u_w += gw;
       if (u_w == d.Wo) { u_w = 0; u_h += gh; if (u_h == d.Ho) { u_h = 0; u_n += gn; } }
@@ -412,7 +431,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
               v *= p.gain;
               p.C[(size_t)m * d.ldy + c] = v;
             } else {
-              p.C[((size_t)blockIdx.y * M + m) * Ncol + c] = v;
+              p.C[((size_t)by * M + m) * Ncol + c] = v;
             }
           }
         }
@@ -429,7 +448,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
 #pragma unroll
           for (int r = 0; r < B_RPP; ++r) sum += red[r * BN + tid];
           const int c = n0 + tid;
-          if (c < Ncol) p.bias_ws[(size_t)blockIdx.y * Ncol + c] = sum;
+          if (c < Ncol) p.bias_ws[(size_t)by * Ncol + c] = sum;
         }
       }
     }
