@@ -39,21 +39,63 @@ __device__ __forceinline__ int find_layer(const BlockMap& m, int n, int b) {
 __device__ __forceinline__ size_t scr_base(const contrad_sn_batch& b, int l) { return (size_t)b.scratch_off[l]; }
 
 // ---- phase 1: vt[i] = sum_k W[k][i] u[k]; partial |vt|^2 per block ----
-__global__ void sn_phase1_kernel(contrad_sn_batch b, BlockMap map, float* __restrict__ scratch) {
+// Block = 1024 threads = 64 column quads (256 columns, one partial slot) x 16 row slices: every thread streams float4s
+// of rows ks, ks+16, ... with 4 independent loads in flight, the 16 slices are summed through LDS in a fixed order.
+// (One thread per column walking all K rows with dependent 4-byte loads took 190 us for 74 MB of weights.)
+constexpr int P1_SLICES = 16;
+__global__ __launch_bounds__(1024) void sn_phase1_kernel(contrad_sn_batch b, BlockMap map, float* __restrict__ scratch) {
+  __shared__ float4 part[P1_SLICES][64];
   __shared__ float red[16];
   const int l = find_layer(map, b.n, blockIdx.x);
   const contrad_sn_layer& L = b.layers[l];
   const int chunk = blockIdx.x - map.start[l];
   const int IN = L.C * L.T;
   float* scr = scratch + scr_base(b, l);
-  const int i = chunk * SN_THREADS + threadIdx.x;
-  float acc = 0.f;
-  if (i < IN) {
-    const float* w = L.w + i;
-    for (int k = 0; k < L.K; ++k) acc += w[(size_t)k * IN] * L.u[k];
-    scr[3 * MAXP + i] = acc;
+  const int cq = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  const int i = chunk * SN_THREADS + cq * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if ((IN & 3) == 0 && ((uintptr_t)L.w & 15) == 0) {
+    if (i < IN) {
+      const float* w = L.w + i;
+      int k = ks;
+      for (; k + 3 * P1_SLICES < L.K; k += 4 * P1_SLICES) {
+        const float4 w0 = *reinterpret_cast<const float4*>(w + (size_t)k * IN);
+        const float4 w1 = *reinterpret_cast<const float4*>(w + (size_t)(k + P1_SLICES) * IN);
+        const float4 w2 = *reinterpret_cast<const float4*>(w + (size_t)(k + 2 * P1_SLICES) * IN);
+        const float4 w3 = *reinterpret_cast<const float4*>(w + (size_t)(k + 3 * P1_SLICES) * IN);
+        const float u0 = L.u[k], u1 = L.u[k + P1_SLICES], u2 = L.u[k + 2 * P1_SLICES], u3 = L.u[k + 3 * P1_SLICES];
+        acc.x += w0.x * u0; acc.y += w0.y * u0; acc.z += w0.z * u0; acc.w += w0.w * u0;
+        acc.x += w1.x * u1; acc.y += w1.y * u1; acc.z += w1.z * u1; acc.w += w1.w * u1;
+        acc.x += w2.x * u2; acc.y += w2.y * u2; acc.z += w2.z * u2; acc.w += w2.w * u2;
+        acc.x += w3.x * u3; acc.y += w3.y * u3; acc.z += w3.z * u3; acc.w += w3.w * u3;
+      }
+      for (; k < L.K; k += P1_SLICES) {
+        const float4 w0 = *reinterpret_cast<const float4*>(w + (size_t)k * IN);
+        const float u0 = L.u[k];
+        acc.x += w0.x * u0; acc.y += w0.y * u0; acc.z += w0.z * u0; acc.w += w0.w * u0;
+      }
+    }
+  } else {
+    float* a = reinterpret_cast<float*>(&acc);
+    for (int k = ks; k < L.K; k += P1_SLICES) {
+      const float uk = L.u[k];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i + j < IN) a[j] += L.w[(size_t)k * IN + i + j] * uk;
+    }
   }
-  const float ss = block_sum(acc * acc, red);
+  part[ks][cq] = acc;
+  __syncthreads();
+  float ss = 0.f;
+  if (ks == 0) {
+    float4 t = part[0][cq];
+    for (int q = 1; q < P1_SLICES; ++q) { const float4 v = part[q][cq]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    const float* a = reinterpret_cast<const float*>(&t);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i + j < IN) { scr[3 * MAXP + i + j] = a[j]; ss += a[j] * a[j]; }
+  }
+  ss = block_sum(ss, red);
   if (threadIdx.x == 0) scr[chunk] = ss;
 }
 
@@ -86,7 +128,23 @@ __global__ void sn_phase2_kernel(contrad_sn_batch b, BlockMap map, int training,
   float acc = 0.f;
   if (k < L.K) {
     const float* w = L.w + (size_t)k * IN;
-    for (int i = lane; i < IN; i += 64) acc += w[i] * vsrc[i];
+    if ((IN & 3) == 0 && ((uintptr_t)L.w & 15) == 0 && ((uintptr_t)vsrc & 15) == 0) {
+      float a0 = 0.f, a1 = 0.f;
+      int i = lane * 4;
+      for (; i + 256 < IN; i += 512) {
+        const float4 w0 = *reinterpret_cast<const float4*>(w + i), v0 = *reinterpret_cast<const float4*>(vsrc + i);
+        const float4 w1 = *reinterpret_cast<const float4*>(w + i + 256), v1 = *reinterpret_cast<const float4*>(vsrc + i + 256);
+        a0 += w0.x * v0.x + w0.y * v0.y + w0.z * v0.z + w0.w * v0.w;
+        a1 += w1.x * v1.x + w1.y * v1.y + w1.z * v1.z + w1.w * v1.w;
+      }
+      for (; i < IN; i += 256) {
+        const float4 w0 = *reinterpret_cast<const float4*>(w + i), v0 = *reinterpret_cast<const float4*>(vsrc + i);
+        a0 += w0.x * v0.x + w0.y * v0.y + w0.z * v0.z + w0.w * v0.w;
+      }
+      acc = a0 + a1;
+    } else {
+      for (int i = lane; i < IN; i += 64) acc += w[i] * vsrc[i];
+    }
     acc = wave_sum(acc) * inv;
     if (lane == 0) scr[3 * MAXP + IN + k] = acc;
   }
@@ -251,7 +309,7 @@ int tiles_of(const contrad_sn_layer& L) {
 }  // namespace
 
 extern "C" long long contrad_sn_scratch_floats(int K, int C, int T) {
-  return 3ll * MAXP + (long long)C * T + K + 16;
+  return (3ll * MAXP + (long long)C * T + K + 16 + 3) & ~3ll;   // multiple of 4 floats: every layer's slab stays 16-B aligned
 }
 
 extern "C" int contrad_sn_weight_prep(const contrad_sn_batch* b, int training, float eps, float* scratch,
@@ -272,7 +330,7 @@ extern "C" int contrad_sn_weight_prep(const contrad_sn_batch* b, int training, f
   }
   if (any_sn) {
     if (training && m1.start[b->n] > 0) {
-      hipLaunchKernelGGL(sn_phase1_kernel, dim3(m1.start[b->n]), dim3(SN_THREADS), 0, s, *b, m1, scratch);
+      hipLaunchKernelGGL(sn_phase1_kernel, dim3(m1.start[b->n]), dim3(64 * P1_SLICES), 0, s, *b, m1, scratch);
       CONTRAD_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(sn_phase2_kernel, dim3(m2.start[b->n]), dim3(256), 0, s, *b, m2, training, eps, scratch);
