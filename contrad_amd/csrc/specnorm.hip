@@ -99,10 +99,12 @@ __global__ __launch_bounds__(1024) void sn_phase1_kernel(contrad_sn_batch b, Blo
   if (threadIdx.x == 0) scr[chunk] = ss;
 }
 
-__device__ __forceinline__ float sum_partials(const float* p, int n) {
+// Sum of n per-block partial slots, by the whole block (fixed tree -> every block, and every kernel that needs the same
+// sum, gets the bit-identical value).  One thread walking up to 384 dependent loads cost more than the block's real work.
+__device__ __forceinline__ float sum_partials(const float* p, int n, float* red) {
   float s = 0.f;
-  for (int i = 0; i < n; ++i) s += p[i];
-  return s;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += p[i];
+  return block_sum(s, red);
 }
 
 // ---- phase 2: t[k] = sum_i W[k][i] vhat[i]; one wave per row; partial |t|^2 per block ----
@@ -120,7 +122,7 @@ __global__ void sn_phase2_kernel(contrad_sn_batch b, BlockMap map, int training,
   const float* vsrc;
   if (training) {
     const int np1 = cdiv_dev(IN, SN_THREADS);
-    inv = 1.f / fmaxf(sqrtf(sum_partials(scr, np1)), eps);
+    inv = 1.f / fmaxf(sqrtf(sum_partials(scr, np1, red)), eps);
     vsrc = scr + 3 * MAXP;
   } else {
     vsrc = L.v;
@@ -158,6 +160,7 @@ __global__ void sn_phase2_kernel(contrad_sn_batch b, BlockMap map, int training,
 __global__ void sn_phase3_kernel(contrad_sn_batch b, BlockMap map, int training, float eps,
                                  float* __restrict__ scratch, float* __restrict__ sigma_out) {
   __shared__ float tile[32][257];
+  __shared__ float red[16];
   const int l = find_layer(map, b.n, blockIdx.x);
   const contrad_sn_layer& L = b.layers[l];
   const int chunk = blockIdx.x - map.start[l];
@@ -179,12 +182,12 @@ __global__ void sn_phase3_kernel(contrad_sn_batch b, BlockMap map, int training,
     float sigma;
     if (training) {
       const int np2 = cdiv_dev(L.K, 4);
-      const float nt2 = sum_partials(scr + MAXP, np2);
+      const float nt2 = sum_partials(scr + MAXP, np2, red);
       const float inv_t = 1.f / fmaxf(sqrtf(nt2), eps);
       sigma = nt2 * inv_t;
-      if (chunk == 0) {
+      if (chunk == 0) {   // (uniform per block)
         const int np1 = cdiv_dev(IN, SN_THREADS);
-        const float inv_v = 1.f / fmaxf(sqrtf(sum_partials(scr, np1)), eps);
+        const float inv_v = 1.f / fmaxf(sqrtf(sum_partials(scr, np1, red)), eps);
         for (int k = threadIdx.x; k < L.K; k += blockDim.x) {
           const float uk = t[k] * inv_t;
           L.u[k] = uk;
@@ -197,9 +200,10 @@ __global__ void sn_phase3_kernel(contrad_sn_batch b, BlockMap map, int training,
         }
       }
     } else {
-      // sigma = u . (W v): fixed-order dot by every block (K <= a few thousand)
-      sigma = 0.f;
-      for (int k = 0; k < L.K; ++k) sigma += L.u[k] * t[k];
+      // sigma = u . (W v): the same fixed-tree dot in every block
+      float part = 0.f;
+      for (int k = threadIdx.x; k < L.K; k += blockDim.x) part += L.u[k] * t[k];
+      sigma = block_sum(part, red);
       if (chunk == 0) {
         if (L.u_snap) for (int k = threadIdx.x; k < L.K; k += blockDim.x) L.u_snap[k] = L.u[k];
         if (L.v_snap) for (int i = threadIdx.x; i < IN; i += blockDim.x) L.v_snap[i] = L.v[i];
@@ -251,6 +255,7 @@ __global__ void sn_bwd_dot_kernel(contrad_sn_batch b, BlockMap map, float* __res
 __global__ void sn_bwd_write_kernel(contrad_sn_batch b, BlockMap map, BlockMap dotmap,
                                     const float* __restrict__ scratch, const float* __restrict__ sigma) {
   __shared__ float tile[32][257];
+  __shared__ float red[16];
   const int l = find_layer(map, b.n, blockIdx.x);
   const contrad_sn_layer& L = b.layers[l];
   const int chunk = blockIdx.x - map.start[l];
@@ -266,7 +271,7 @@ __global__ void sn_bwd_write_kernel(contrad_sn_batch b, BlockMap map, BlockMap d
   if (L.fixed_scale > 0.f) {
     inv_sigma = L.fixed_scale;
   } else {
-    dot = sum_partials(scr + 2 * MAXP, dotmap.start[l + 1] - dotmap.start[l]);
+    dot = sum_partials(scr + 2 * MAXP, dotmap.start[l + 1] - dotmap.start[l], red);
     inv_sigma = 1.f / sigma[l];
   }
   const int kk = threadIdx.x & 31;
