@@ -5,7 +5,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libcontrad_hip.so')
+LIB_PATH = os.environ.get('CONTRAD_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libcontrad_hip.so')   # (env: dev A/B builds)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'contrad_hip.h')
 
 

@@ -332,11 +332,26 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
   // Main loop: 8 k-steps of TM x TN MFMAs per tile; the next tile's global loads ride between the first k-steps,
   // its LDS stores (other buffer) between the last ones; fragments of the whole tile are fetched at the top.
   constexpr int KS = BK / 2;
-  constexpr int A_LD0 = 0, B_LD0 = PA, A_ST0 = KS - PA - PB, B_ST0 = KS - PB;
-  static_assert(A_ST0 >= B_LD0 + PB, "not enough k-steps to schedule the load and store pieces");
+#ifndef IGEMM_ST_SHIFT
+#define IGEMM_ST_SHIFT 1   // k-steps of MFMA left after the last LDS store of a tile (dev A/B knob: 0 -> 1 = +0.5 %)
+#endif
+  constexpr int A_LD0 = 0, B_LD0 = PA, A_ST0 = KS - PA - PB - IGEMM_ST_SHIFT, B_ST0 = KS - PB - IGEMM_ST_SHIFT;
+  static_assert(A_ST0 >= A_LD0 + PA - 1 && B_ST0 >= B_LD0 + PB - 1 && A_ST0 >= 0,
+                "a piece must be stored after its own load was issued");
   for (int t = 0; t < T; ++t) {
     const int cur = (t & 1) * BUF, nxt = BUF - cur;
     float fa[2][TM][4], fb[2][TN][4];
+#if defined(LEAN_ABLATE_FRAGS)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[h][i][j] = (float)(t + i + j);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) fb[h][i][j] = (float)(t - i - j);
+      }
+#else
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -360,14 +375,17 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
         }
       }
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int h = ks >> 2, j = ks & 3;
+#if !defined(LEAN_ABLATE_LOADS)     // (ablation builds give WRONG results: timing only, tools/build_variant.sh)
       if (ks == A_LD0) begin_tile();
       if (ks >= A_LD0 && ks < A_LD0 + PA) load_a_piece(ks - A_LD0);
       if (ks >= B_LD0 && ks < B_LD0 + PB) load_b_piece(ks - B_LD0);
       if (ks == B_LD0 + PB - 1) end_tile();
+#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -375,10 +393,14 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
         for (int jj = 0; jj < TN; ++jj)
           acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][i][j], fb[h][jj][j], acc[i][jj], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+#if !defined(LEAN_ABLATE_STORES)
       if (ks >= A_ST0 && ks < A_ST0 + PA) store_a_piece(nxt, ks - A_ST0);
       if (ks >= B_ST0 && ks < B_ST0 + PB) store_b_piece(nxt, ks - B_ST0);
+#endif
     }
+#if !defined(LEAN_ABLATE_BARRIER)
     __syncthreads();
+#endif
   }
 
   // ---------------- epilogue (same as the general kernel) ----------------

@@ -52,7 +52,15 @@ void run(const char* name, int blocks, int iters) {
   hipFree(out);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) {   // short-lived blocks, like the conv engine's (blocks, K-tiles per block)
+    const int cfg[5][2] = {{3072, 72}, {1536, 144}, {768, 288}, {1024, 216}, {30720, 72}};
+    for (auto& c : cfg) {
+      run<1>("mfma + lds frag reads", c[0], c[1]);
+      run<2>("mfma + lds reads + barrier", c[0], c[1]);
+    }
+    return 0;
+  }
   for (int blocks : {256, 512, 1024, 4096}) {
     run<0>("mfma only", blocks, 4096 * 256 / blocks * 4);
     run<1>("mfma + lds frag reads", blocks, 4096 * 256 / blocks * 4);
