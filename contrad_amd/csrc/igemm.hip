@@ -852,13 +852,73 @@ int wgrad_plan(const contrad_conv_desc* d, int* bm, int* bn, int* tiles_m, int* 
   return 0;
 }
 
+// y[m][c] = gain * lrelu(sum_s ws[s][m][c] + bias[c])   (fixed summation order)
+__global__ void fwd_reduce_kernel(const float* __restrict__ ws, int splits, long long M, int Ncol,
+                                  const float* __restrict__ bias, float slope, float gain, float* __restrict__ y,
+                                  int ldy) {
+  const long long total = M * Ncol;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int k = 0; k < splits; ++k) v += ws[(long long)k * total + e];
+    const long long m = e / Ncol;
+    const int c = (int)(e - m * Ncol);
+    if (bias) v += bias[c];
+    v = (v > 0.f) ? v : v * slope;
+    y[m * ldy + c] = v * gain;
+  }
+}
+
+// FWD plan: tile + split-K count from a small cost model (measured rates of the lean tiles, 768 blocks = a full
+// chip, partial slabs priced at 4 TB/s).  Split-K only pays for small-M, deep-K GEMMs: the merged head layer
+// (M = 3N rows, K = 8192) and the last conv layers at small per-rank batches.
+struct FwdPlan { int bm, bn, splits, tps; };
+FwdPlan fwd_plan(const contrad_conv_desc* d) {
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  const bool vec = vec_ok(d, MODE_FWD);
+  const bool lean = vec && lean_ok(d, MODE_FWD, 0);
+  FwdPlan p{64, 64, 1, 0};
+  pick_tile(M, d->K, vec, lean, 1, &p.bm, &p.bn);
+  const int t_total = d->KH * d->KW * d->C / BK;
+  p.tps = t_total;
+  static const bool splitk_on = []() { const char* e = getenv("CONTRAD_IGEMM_SPLITK"); return !(e && e[0] == '0'); }();
+  if (!lean || !splitk_on || p.bn == 32 || t_total < 32) return p;
+  static const int cand[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
+  static const double rate[4] = {135e12, 128e12, 128e12, 115e12};
+  static const int sp[8] = {1, 2, 3, 4, 6, 8, 12, 16};
+  const double flops = 2.0 * (double)M * d->K * d->C * d->KH * d->KW;
+  double best = 1e30;
+  for (int i = (d->K > 64 ? 0 : 2); i < 4; ++i)
+    for (int j = 0; j < 8; ++j) {
+      const int s_ = sp[j];
+      const int tps = cdiv(t_total, s_);
+      if (s_ > 1 && tps < 8) break;
+      const int splits = cdiv(t_total, tps);
+      const long long tm = cdivll(M, cand[i][0]), tn = cdivll(d->K, cand[i][1]);
+      const double blocks = (double)(tm * tn) * splits;
+      const double waste = (double)(tm * cand[i][0]) * (double)(tn * cand[i][1]) / ((double)M * d->K);
+      const double fill = blocks >= 768.0 ? 1.0 : blocks / 768.0;
+      double t = flops * waste / (rate[i] * fill);
+      if (splits > 1) t += (2.0 * splits + 1.0) * (double)M * d->K * 4.0 / 4e12 + 4e-6;   // slabs + one more launch
+      if (t < best) { best = t; p.bm = cand[i][0]; p.bn = cand[i][1]; p.splits = splits; p.tps = tps; }
+    }
+  return p;
+}
+
 }  // namespace
 
-extern "C" int contrad_abi_version(void) { return 1; }
+extern "C" int contrad_abi_version(void) { return 2; }
+
+extern "C" long long contrad_conv2d_fwd_workspace_bytes(const contrad_conv_desc* d) {
+  if (check_desc(d)) return -22;
+  const FwdPlan p = fwd_plan(d);
+  if (p.splits <= 1) return 0;
+  return (long long)p.splits * d->N * d->Ho * d->Wo * d->K * (long long)sizeof(float);
+}
 
 extern "C" int contrad_conv2d_fwd(const contrad_conv_desc* d, const float* x, const float* wp,
-                                  const float* bias, float* y, float slope, float gain,
-                                  contrad_stream_t stream) {
+                                  const float* bias, float* y, float slope, float gain, float* workspace,
+                                  long long workspace_bytes, contrad_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   CONTRAD_ARG(x && wp && y);
@@ -867,11 +927,23 @@ extern "C" int contrad_conv2d_fwd(const contrad_conv_desc* d, const float* x, co
   const long long M = (long long)d->N * d->Ho * d->Wo;
   CONTRAD_ARG(M < (1ll << 31));
   a.M = (int)M; a.Ncol = d->K; a.Kg = d->KH * d->KW * d->C;
-  int bm, bn;
   const bool vec = vec_ok(d, MODE_FWD);
-  pick_tile(M, d->K, vec, vec && lean_ok(d, MODE_FWD, 0), 1, &bm, &bn);
-  a.tiles_m = cdiv(a.M, bm); a.tiles_n = cdiv(a.Ncol, bn);
-  return dispatch<MODE_FWD>(a, bm, bn, vec, dim3(a.tiles_m * a.tiles_n), (hipStream_t)stream);
+  const FwdPlan p = fwd_plan(d);
+  a.tiles_m = cdiv(a.M, p.bm); a.tiles_n = cdiv(a.Ncol, p.bn);
+  a.ptiles_per_split = p.tps;
+  if (p.splits > 1) {
+    CONTRAD_ARG(workspace && workspace_bytes >= contrad_conv2d_fwd_workspace_bytes(d));
+    a.C = workspace;
+  }
+  rc = dispatch<MODE_FWD>(a, p.bm, p.bn, vec, dim3(a.tiles_m * a.tiles_n, p.splits), (hipStream_t)stream);
+  if (rc || p.splits <= 1) return rc;
+  const long long total = M * d->K;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(fwd_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, workspace, p.splits, M,
+                     d->K, bias, slope, gain, y, d->ldy);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int contrad_conv2d_dgrad(const contrad_conv_desc* d, const float* gy, const float* wp,
@@ -899,8 +971,8 @@ extern "C" int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm
   if (rc) return rc;
   CONTRAD_ARG(bm && bn && mode >= 0 && mode <= 2);
   if (mode == MODE_FWD) {
-    pick_tile((long long)d->N * d->Ho * d->Wo, d->K, vec_ok(d, MODE_FWD), vec_ok(d, MODE_FWD) && lean_ok(d, MODE_FWD, 0),
-              1, bm, bn);
+    const FwdPlan p = fwd_plan(d);
+    *bm = p.bm; *bn = p.bn;
   } else if (mode == MODE_DGRAD) {
     pick_tile((long long)d->N * cdiv(d->H, d->stride) * cdiv(d->W, d->stride), d->C, vec_ok(d, MODE_DGRAD),
               vec_ok(d, MODE_DGRAD) && lean_ok(d, MODE_DGRAD, 0), d->stride * d->stride, bm, bn);

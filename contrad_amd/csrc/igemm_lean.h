@@ -105,7 +105,16 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
   int gw = 1, gh = 1, gn = 1, n_begin = 0;                                                    // WGRAD patch
 
   if constexpr (MODE == MODE_FWD) {
-    T = p.Kg / BK;
+    // split-K (p.ny > 1, small-M GEMMs such as the merged head layer): this block contracts K-tiles
+    // [t_begin, t_begin + T) and writes a raw partial slab; fwd_reduce_kernel sums the slabs and applies the epilogue
+    const int t_total = p.Kg / BK, t_begin = by * p.ptiles_per_split;
+    T = min(p.ptiles_per_split, t_total - t_begin);
+    if (T < 0) T = 0;
+    const int ntaps = d.KH * d.KW;
+    u_c0 = (t_begin / ntaps) * BK;          // taps-inner order: tile q = (chunk q / ntaps, tap q % ntaps)
+    u_tap = t_begin % ntaps;
+    u_a = u_tap / d.KW;
+    u_b = u_tap - u_a * d.KW;
     const int HoWo = d.Ho * d.Wo;
     const int n_first = m0 / HoWo;
     baseA = p.A + ((long long)n_first * d.H * d.W - (d.pad * d.W + d.pad)) * d.ldx;
@@ -448,10 +457,14 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
           if (c < Ncol) {
             float v = acc[i][j][r];
             if constexpr (MODE == MODE_FWD) {
-              if (p.bias) v += p.bias[c];
-              v = (v > 0.f) ? v : v * p.slope;
-              v *= p.gain;
-              p.C[(size_t)m * d.ldy + c] = v;
+              if (p.ny > 1) {   // uniform: split-K partial slab [split][M][Ncol] (p.C = workspace)
+                p.C[((size_t)by * M + m) * Ncol + c] = v;
+              } else {
+                if (p.bias) v += p.bias[c];
+                v = (v > 0.f) ? v : v * p.slope;
+                v *= p.gain;
+                p.C[(size_t)m * d.ldy + c] = v;
+              }
             } else {
               p.C[((size_t)by * M + m) * Ncol + c] = v;
             }

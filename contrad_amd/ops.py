@@ -118,8 +118,10 @@ def conv2d_fwd(x, wp, bias, K, KH, KW, stride, pad, slope=1.0, gain=1.0, out=Non
         out = torch.empty((N, Ho, Wo, K), device=x.device, dtype=torch.float32)
     _chk(out, 'out')
     d = make_desc(N, H, W, C, K, KH, KW, stride, pad, _ld(x), _ld(out), wp.stride(0))
+    nbytes = lib().raw('contrad_conv2d_fwd_workspace_bytes')(ctypes.byref(d))
+    ws = _workspace(nbytes, x.device) if nbytes > 0 else None
     _conv_call(0, d, 'contrad_conv2d_fwd', ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(out),
-               float(slope), float(gain), _stream())
+               float(slope), float(gain), _p(ws), nbytes, _stream())
     return out
 
 

@@ -47,7 +47,11 @@ typedef struct {
 /* y[n,ho,wo,k] = gain * lrelu_slope( sum_{kh,kw,c} x[n,ho*s-p+kh,wo*s-p+kw,c] * wp[(kh,kw,c),k] + bias[k] )
  * bias may be NULL; slope = 1 disables the activation. */
 int contrad_conv2d_fwd(const contrad_conv_desc* d, const float* x, const float* wp, const float* bias,
-                       float* y, float slope, float gain, contrad_stream_t stream);
+                       float* y, float slope, float gain, float* workspace, long long workspace_bytes,
+                       contrad_stream_t stream);
+/* Scratch for the split-K partial slabs of small-M / deep-K shapes (the merged head GEMM); 0 for most shapes, in
+ * which case workspace may be NULL. */
+long long contrad_conv2d_fwd_workspace_bytes(const contrad_conv_desc* d);
 
 /* dx[n,h,w,c] = act'(act_ref[n,h,w,c]) * sum_{kh,kw,k} gy[n,(h+p-kh)/s,(w+p-kw)/s,k] * wp[(kh,kw,c),k]
  * act_ref (may be NULL) is the OUTPUT of the leaky-relu that produced this conv's input (same layout

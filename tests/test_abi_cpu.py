@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_argument_errors_are_reported_without_gpu(built):
     # NULL descriptor -> -EINVAL, raised as RuntimeError by the host wrapper (TORCH_CHECK analogue)
     with pytest.raises(RuntimeError):
-        built.call('contrad_conv2d_fwd', None, None, None, None, None, 1.0, 1.0, None)
+        built.call('contrad_conv2d_fwd', None, None, None, None, None, 1.0, 1.0, None, 0, None)
     d = _lib.ConvDesc(1, 8, 8, 4, 4, 8, 8, 4, 4, 3, 3, 3, 1, 4)   # stride 3 unsupported
     assert built.raw('contrad_conv2d_wgrad_workspace_bytes')(ctypes.byref(d)) < 0
     d = _lib.ConvDesc(2, 8, 8, 4, 4, 8, 8, 8, 8, 3, 3, 1, 1, 8)
