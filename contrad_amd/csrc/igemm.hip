@@ -683,20 +683,31 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
                                     int ldw, int splits, const float* __restrict__ bias_ws,
                                     float* __restrict__ dbias) {
   const long long total = (long long)Kg * Ncol;
-  const long long ext = total + (dbias ? Ncol : 0);
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ext;
-       e += (long long)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    if (e < total) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ldw == Ncol && (total & 3) == 0) {   // dense packed rows: float4 streams, no index arithmetic
+    for (long long q = t0; q < total / 4; q += stride) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < splits; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(ws + (long long)k * total + q * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      *reinterpret_cast<float4*>(out + q * 4) = s;
+    }
+  } else {
+    for (long long e = t0; e < total; e += stride) {
+      float s = 0.f;
       for (int k = 0; k < splits; ++k) s += ws[(long long)k * total + e];
       const int i = (int)(e / Ncol), c = (int)(e - (long long)i * Ncol);
       out[(size_t)i * ldw + c] = s;
-    } else {
-      const int c = (int)(e - total);
+    }
+  }
+  if (dbias)
+    for (long long c = t0; c < Ncol; c += stride) {
+      float s = 0.f;
       for (int k = 0; k < splits; ++k) s += bias_ws[(long long)k * Ncol + c];
       dbias[c] = s;
     }
-  }
 }
 
 template <int BM, int BN>
@@ -1024,8 +1035,9 @@ extern "C" int contrad_conv2d_wgrad(const contrad_conv_desc* d, const float* x, 
                             (hipStream_t)stream);
   if (rc) return rc;
   const long long total = (long long)a.M * a.Ncol;
-  int blocks = (int)((total + 255) / 256);
+  int blocks = (int)((total / 4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, workspace, dwp,
                      a.M, a.Ncol, d->ldw, splits, a.bias_ws, fused_bias ? dbias : nullptr);
   CONTRAD_CHECK_LAUNCH();
