@@ -1,0 +1,151 @@
+"""Data-parallel equivalence on the HIP path with a REAL second rank: two processes share cuda:0 over a gloo process
+group (RCCL refuses two ranks on one device; gloo moves the same tensors) and each runs `engine.d_step` on its half
+of a global batch -- packed embedding all-gather + regrouping, GatherLayer-style local-slice backward, SyncBN
+statistics of G, the overlapped per-layer gradient exchange and Adam's 1/W.  The parent process runs the same global
+batch on one rank.  Expected relation (reference semantics, third_party/gather_layer.py:18-23 + DDP's mean):
+
+    sum_r grad_r / W  ==  grad(GAN loss, global mean)  +  grad(contrastive loss, global) / W
+
+(every rank evaluates the identical global contrastive loss but back-propagates only its own rows, and DDP divides
+by W).  Randomness (latents, augmentation parameters) is injected so both runs see the same samples.
+"""
+import argparse
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+NL, WORLD = 8, 2          # per-rank and world size: global batch 16
+
+
+def _setup(seed=0):
+    from contrad_amd import config
+    from contrad_amd.augment import get_augment
+    from contrad_amd.models.gan import get_architecture
+    from contrad_amd.training.gan import setup
+    config.clear_config()
+    config.parse_config_files_and_bindings([os.path.join(config.CONFIG_ROOT, 'defaults', 'gan.gin'),
+                                            os.path.join(config.CONFIG_ROOT, 'defaults', 'augment.gin'),
+                                            os.path.join(config.CONFIG_ROOT, 'gan', 'cifar10', 'c10_b512.gin')])
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(seed); np.random.seed(seed)
+    G, D = get_architecture('sndcgan', (32, 32, 3))
+    G, D = G.to(dev).train(), D.to(dev).train()
+    aug = get_augment(mode='simclr').to(dev)
+    return G, D, aug, setup, dev
+
+
+def _global_inputs(aug):
+    """Global batch: reals, latents, and the (3N, 12) augmentation parameter block in GLOBAL row order
+    [view 1 of all reals; view 2 of all reals; fakes]."""
+    N = NL * WORLD
+    g = torch.Generator().manual_seed(123)
+    images = torch.rand(N, 3, 32, 32, generator=g)
+    z = torch.empty(N, 128).uniform_(-1, 1, generator=g)
+    torch.manual_seed(7); np.random.seed(7)
+    P, contrast_first, sigma = aug.sample(3 * N, 32, 32)
+    return images, z, P, contrast_first, sigma
+
+
+def _inject(G, aug, z, P, contrast_first, sigma, dev):
+    G.sample_latent = lambda n: z.to(dev)
+    aug.sample = lambda B, a, b: (P, contrast_first, sigma)
+
+
+def _worker(rank, world, port, path):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from contrad_amd.engine import OverlappedGradReducer, d_step, set_grad
+        from contrad_amd.optim import FusedAdam
+        import contrad_amd.third_party.gather_layer as gl
+        import contrad_amd.training.gan.contrad as cd
+
+        def gather_rows(x):          # gloo has no all_gather_into_tensor for device tensors: list form, same result
+            outs = [torch.empty_like(x) for _ in range(world)]
+            dist.all_gather(outs, x.contiguous())
+            return torch.stack(outs, 0)
+        gl.all_gather_rows = gather_rows
+        cd.all_gather_rows = gather_rows
+
+        G, D, aug, setup, dev = _setup()
+        images, z, P, cf, sigma = _global_inputs(aug)
+        N = NL * world
+        sl = slice(rank * NL, (rank + 1) * NL)
+        rows = torch.cat([torch.arange(N)[sl], N + torch.arange(N)[sl], 2 * N + torch.arange(N)[sl]])
+        _inject(G, aug, z[sl], P[rows], cf, sigma, dev)
+        Pn = setup(argparse.Namespace(mode='contrad', aug='simclr', temp=0.1, lbd_a=1.0, distributed=True))
+        Pn.augment_fn = aug
+        opt = FusedAdam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+        D.enable_grad_overlap(OverlappedGradReducer())
+        set_grad(G, False); set_grad(D, True)
+        d_loss, aux = d_step(Pn, G, D, opt, {'loss': 'nonsat', 'batch_size': NL}, images[sl].to(dev), None)
+        torch.cuda.synchronize()
+        torch.save({'d_loss': d_loss.detach().cpu(), 'gan': aux['penalty'].detach().cpu(),
+                    'grads': [p.grad.detach().cpu().clone() for p in D.parameters()],
+                    'params': [p.detach().cpu().clone() for p in D.parameters()],
+                    'bn_mean': [m.running_mean.cpu().clone() for m in G.modules()
+                                if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d))]},
+                   '%s.rank%d' % (path, rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def rel(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def test_two_ranks_equal_one_rank_on_the_global_batch(tmp_path):
+    import torch.multiprocessing as mp
+    from contrad_amd.engine import set_grad
+    path = str(tmp_path / 'dp')
+    mp.spawn(_worker, args=(WORLD, 29533, path), nprocs=WORLD, join=True)
+    res = [torch.load('%s.rank%d' % (path, r)) for r in range(WORLD)]
+
+    # one rank, global batch, same samples
+    G, D0, aug, setup, dev = _setup()
+    images, z, P, cf, sigma = _global_inputs(aug)
+    _inject(G, aug, z, P, cf, sigma, dev)
+    Pn = setup(argparse.Namespace(mode='contrad', aug='simclr', temp=0.1, lbd_a=1.0, distributed=False))
+    Pn.augment_fn = aug
+    set_grad(G, False)
+    G0 = copy.deepcopy(G); _inject(G0, aug, z, P, cf, sigma, dev)
+    grads = []
+    losses = []
+    for which in ('con', 'gan'):          # two fresh copies: every forward advances the spectral-norm power iteration
+        D = copy.deepcopy(D0)
+        Gc = copy.deepcopy(G0); _inject(Gc, aug, z, P, cf, sigma, dev)
+        set_grad(D, True)
+        with torch.no_grad():
+            fakes = Gc(Gc.sample_latent(NL * WORLD))
+        d_loss, aux = Pn.train_fn["D"](Pn, D, {'loss': 'nonsat'}, images.to(dev), fakes)
+        (d_loss if which == 'con' else aux['penalty']).backward()
+        grads.append([p.grad.detach().cpu().clone() for p in D.parameters()])
+        losses.append((d_loss.item(), aux['penalty'].item()))
+        bn_mean = [m.running_mean.cpu().clone() for m in Gc.modules()
+                   if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d))]
+    g_con, g_gan = grads
+    con_ref, gan_ref = losses[0]
+
+    # losses: the contrastive loss is global on every rank; the GAN loss is a local mean
+    for r in res:
+        assert abs(r['d_loss'].item() - con_ref) < TOL * abs(con_ref)
+    assert abs(sum(r['gan'].item() for r in res) / WORLD - gan_ref) < TOL * abs(gan_ref)
+    # SyncBN: both ranks tracked the GLOBAL batch statistics
+    for a, b0, b1 in zip(bn_mean, res[0]['bn_mean'], res[1]['bn_mean']):
+        assert rel(b0, a) < TOL and torch.equal(b0, b1)
+    # gradients after the exchange are identical on both ranks and equal the single-rank decomposition
+    for i, (gc, gg) in enumerate(zip(g_con, g_gan)):
+        assert torch.equal(res[0]['grads'][i], res[1]['grads'][i])
+        want = gg + gc / WORLD
+        got = res[0]['grads'][i] / WORLD
+        assert rel(got, want) < 5 * TOL or (want.abs().max() < 1e-7 and got.abs().max() < 1e-7), i
+    # Adam with grad_scale 1/W on identical gradients -> identical weights on both ranks
+    for a, b in zip(res[0]['params'], res[1]['params']):
+        assert torch.equal(a, b)
