@@ -761,6 +761,7 @@ bool lean_ok(const contrad_conv_desc* d, int mode, long long pps) {
   if (d->KH * d->KW > 32) return false;
   if ((long long)d->KH * d->KW * d->C * d->ldw * 4 >= lim) return false;   // packed weight addressed with byte offsets
   const long long img_x = (long long)d->H * d->W * d->ldx * 4, img_y = (long long)d->Ho * d->Wo * d->ldy * 4;
+  if ((long long)d->ldy * 4 * 128 >= (1ll << 30) || (long long)d->K * 4 * 128 >= (1ll << 30)) return false;   // epilogue offsets
   if (mode == MODE_FWD) {
     if ((d->C & 15) || (d->ldx & 3) || (d->K & 3)) return false;
     const long long imgs = 128 / ((long long)d->Ho * d->Wo) + 2;            // images one 128-row M-tile can touch
@@ -769,7 +770,7 @@ bool lean_ok(const contrad_conv_desc* d, int mode, long long pps) {
   if (mode == MODE_DGRAD) {
     if ((d->K & 15) || (d->ldy & 3)) return false;
     const long long imgs = 128 / ((long long)cdiv(d->H, d->stride) * cdiv(d->W, d->stride)) + 2;
-    return imgs * img_y < lim;
+    return imgs * img_y < lim && imgs * img_x < (1ll << 30);   // (dx is addressed relative to the tile's first image)
   }
   if ((d->C & 3) || (d->ldx & 3) || (d->K & 3) || (d->ldy & 3)) return false;
   const long long P = (long long)d->N * d->Ho * d->Wo;

@@ -412,63 +412,85 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
 #endif
   }
 
-  // ---------------- epilogue (same as the general kernel) ----------------
+  // ---------------- epilogue ----------------
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+  // Stores go through a block-relative buffer descriptor too: voffset = (per-lane column part) + (row part), rows past
+  // M and columns past Ncol fall outside num_records and are dropped by the hardware -- one v_add per store instead of
+  // a 64-bit address, two compares and a branch (the 64 stores of a wave were ~2000 instructions; blocks of the
+  // shallow-K StyleGAN2 layers spent more time here than in their 18 K-tiles).
+  constexpr unsigned COL_OOB = 0x40000000u;    // > every valid block-relative offset, and 2 * COL_OOB does not wrap
+  unsigned colpart[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int c = n0 + wn * WN + j * 32 + l31;
+    colpart[j] = (c < Ncol) ? (unsigned)c * 4u : COL_OOB;
+  }
   if constexpr (MODE == MODE_DGRAD) {
-    long long* rowoff = reinterpret_cast<long long*>(smem);
+    // row -> byte offset of the dx pixel relative to the tile's first image (or out of range), staged in LDS
+    unsigned* rowoff = reinterpret_cast<unsigned*>(smem);
+    const int n_first = m0 / (Hc * Wc);
     if (tid < BM) {
       const int m = m0 + tid;
-      long long off = -1;
+      unsigned off = 2u * COL_OOB;
       if (m < M) {
         const int wq = m % Wc, t2 = m / Wc;
         const int hq = t2 % Hc, n = t2 / Hc;
-        off = ((long long)(n * d.H + hq * d.stride + ph) * d.W + (wq * d.stride + pw)) * d.ldx;
+        off = (unsigned)((((n - n_first) * d.H + hq * d.stride + ph) * d.W + (wq * d.stride + pw)) * d.ldx) * 4u;
       }
       rowoff[tid] = off;
     }
     __syncthreads();
+    const size_t img0 = (size_t)n_first * d.H * d.W * d.ldx;
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C + img0, 0, (int)COL_OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.act_ref ? p.act_ref + img0 : p.C + img0), 0,
+                                          p.act_ref ? (int)COL_OOB : 0, 0x00020000);
+    const float g1 = p.gain, g0 = p.gain * p.slope;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        const long long off = rowoff[row];
-        if (off < 0) continue;
+        const unsigned off = rowoff[wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const int c = n0 + wn * WN + j * 32 + l31;
-          if (c < Ncol) {
-            float v = acc[i][j][r];
-            if (p.act_ref) v *= (p.act_ref[off + c] > 0.f) ? p.gain : p.gain * p.slope;
-            p.C[off + c] = v;
+          const unsigned vo = off + colpart[j];
+          float v = acc[i][j][r];
+          if (p.act_ref) {   // uniform
+            const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)vo, 0, 0));
+            v *= (a > 0.f) ? g1 : g0;
           }
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)vo, 0, 0);
         }
       }
   } else {
+    const bool slab = (MODE == MODE_WGRAD) || p.ny > 1;              // split-K partial slab [split][M][Ncol]
+    const int pitch = slab ? Ncol : d.ldy;
+    float* outp = p.C + (slab ? (size_t)by * M * Ncol : (size_t)0) + (size_t)m0 * pitch;
+    const int rows_here = min(BM, M - m0);
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(outp, 0, rows_here * pitch * 4, 0x00020000);
+    const int wave_row = __builtin_amdgcn_readfirstlane(wm * WM);
+    unsigned lanepart[TN];
+    float bj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      lanepart[j] = colpart[j] + (unsigned)(4 * lhi * pitch) * 4u;
+      const int c = n0 + wn * WN + j * 32 + l31;
+      bj[j] = (MODE == MODE_FWD && !slab && p.bias && c < Ncol) ? p.bias[c] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (m >= M) continue;
+        const unsigned rowpart = (unsigned)((wave_row + i * 32 + (r & 3) + 8 * (r >> 2)) * pitch) * 4u;   // wave-uniform
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const int c = n0 + wn * WN + j * 32 + l31;
-          if (c < Ncol) {
-            float v = acc[i][j][r];
-            if constexpr (MODE == MODE_FWD) {
-              if (p.ny > 1) {   // uniform: split-K partial slab [split][M][Ncol] (p.C = workspace)
-                p.C[((size_t)by * M + m) * Ncol + c] = v;
-              } else {
-                if (p.bias) v += p.bias[c];
-                v = (v > 0.f) ? v : v * p.slope;
-                v *= p.gain;
-                p.C[(size_t)m * d.ldy + c] = v;
-              }
-            } else {
-              p.C[((size_t)by * M + m) * Ncol + c] = v;
-            }
+          float v = acc[i][j][r];
+          if (MODE == MODE_FWD && !slab) {
+            v += bj[j];
+            v = (v > 0.f) ? v : v * p.slope;
+            v *= p.gain;
           }
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)(lanepart[j] + rowpart), 0, 0);
         }
       }
     if constexpr (MODE == MODE_WGRAD) {
