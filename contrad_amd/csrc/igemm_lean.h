@@ -126,15 +126,12 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
       const int wo = mm % d.Wo, t = mm / d.Wo;
       const int ho = t % d.Ho, n = t / d.Ho;
       va[i] = (unsigned)(((((n - n_first) * d.H + ho * d.stride) * d.W + wo * d.stride) * d.ldx + kq * 4) * 4);
-      unsigned bits = 0;
-      int tap = 0;
+      // valid taps form a rectangle: a KW-bit column mask replicated into the valid kernel rows (KH + KW steps, not KH*KW)
+      unsigned wmask = 0, valid = 0;
+      for (int kw = 0; kw < d.KW; ++kw) wmask |= ((unsigned)(wo * d.stride - d.pad + kw) < (unsigned)d.W ? 1u : 0u) << kw;
       for (int kh = 0; kh < d.KH; ++kh)
-        for (int kw = 0; kw < d.KW; ++kw, ++tap) {
-          const int hi = ho * d.stride - d.pad + kh, wi = wo * d.stride - d.pad + kw;
-          const bool valid = ok && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
-          bits |= (valid ? 0u : 1u) << tap;
-        }
-      inv[i] = bits;
+        if ((unsigned)(ho * d.stride - d.pad + kh) < (unsigned)d.H) valid |= wmask << (kh * d.KW);
+      inv[i] = ok ? ~valid : 0xFFFFFFFFu;   // (bits past the last tap are never looked at)
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
@@ -170,14 +167,11 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
       const int n = t / Hc;
       const int ah = t % Hc + bh, aw = wq + bw;   // ho = ah - th, wo = aw - tw
       va[i] = (unsigned)(((((n - n_first) * d.Ho + ah) * d.Wo + aw) * d.ldy + kq * 4) * 4);
-      unsigned bits = 0;
-      int ti = 0;
+      unsigned wmask = 0, valid = 0;
+      for (int tw = 0; tw < ntw; ++tw) wmask |= ((unsigned)(aw - tw) < (unsigned)d.Wo ? 1u : 0u) << tw;
       for (int th = 0; th < nth; ++th)
-        for (int tw = 0; tw < ntw; ++tw, ++ti) {
-          const bool valid = ok && (unsigned)(ah - th) < (unsigned)d.Ho && (unsigned)(aw - tw) < (unsigned)d.Wo;
-          bits |= (valid ? 0u : 1u) << ti;
-        }
-      inv[i] = bits;
+        if ((unsigned)(ah - th) < (unsigned)d.Ho) valid |= wmask << (th * ntw);
+      inv[i] = ok ? ~valid : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
@@ -469,6 +463,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     const int rows_here = min(BM, M - m0);
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(outp, 0, rows_here * pitch * 4, 0x00020000);
     const int wave_row = __builtin_amdgcn_readfirstlane(wm * WM);
+    const float g1 = p.gain, g0 = p.gain * p.slope;
     unsigned lanepart[TN];
     float bj[TN];
 #pragma unroll
@@ -487,8 +482,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
           float v = acc[i][j][r];
           if (MODE == MODE_FWD && !slab) {
             v += bj[j];
-            v = (v > 0.f) ? v : v * p.slope;
-            v *= p.gain;
+            v *= (v > 0.f) ? g1 : g0;
           }
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)(lanepart[j] + rowpart), 0, 0);
         }
