@@ -17,6 +17,9 @@
 
 namespace {
 
+#ifndef RGB_MIN_WAVES
+#define RGB_MIN_WAVES 3   // 168 VGPRs, no spill -> 3 waves per SIMD (the weights of all 27 taps live in registers)
+#endif
 constexpr int MAX_TAPS = 9;  // k <= 3
 constexpr int MAX_CIN = 4;
 
@@ -43,7 +46,7 @@ __device__ __forceinline__ void stage_halo(float* lds, const RgbArgs& a, int n, 
 }
 
 template <int KSZ, int CIN>
-__global__ __launch_bounds__(256) void rgb_conv_fwd_kernel(RgbArgs a) {
+__global__ __launch_bounds__(256, RGB_MIN_WAVES) void rgb_conv_fwd_kernel(RgbArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TAPS = KSZ * KSZ;
   const int tpp = a.K >> 2;              // lanes per pixel
@@ -99,7 +102,7 @@ struct RgbWgradArgs {
 };
 
 template <int KSZ, int CIN>
-__global__ __launch_bounds__(256) void rgb_conv_wgrad_kernel(RgbWgradArgs a) {
+__global__ __launch_bounds__(256, RGB_MIN_WAVES) void rgb_conv_wgrad_kernel(RgbWgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TAPS = KSZ * KSZ;
   const int tpp = a.K >> 2;

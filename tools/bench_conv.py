@@ -10,6 +10,12 @@ LAYERS = [(32, 64, 128, 4, 2, 1), (16, 128, 128, 3, 1, 1), (16, 128, 256, 4, 2, 
           (8, 256, 512, 4, 2, 1), (4, 512, 512, 3, 1, 1), (1, 8192, 1536, 1, 1, 0)]
 
 
+# StyleGAN2 discriminator at 512x512 (3N = 48 images): conv1 of each ResBlock + the blurred stride-2 conv2
+LAYERS_SG2 = [(512, 32, 32, 3, 1, 1), (513, 32, 64, 3, 2, 0), (256, 64, 64, 3, 1, 1), (257, 64, 128, 3, 2, 0),
+              (128, 128, 128, 3, 1, 1), (64, 256, 256, 3, 1, 1), (32, 512, 512, 3, 1, 1)]
+if os.environ.get('CONV_SET') == 'sg2':
+    LAYERS = LAYERS_SG2
+
 ITERS = int(os.environ.get('CONV_ITERS', '10'))
 WARM = int(os.environ.get('CONV_WARM', '3'))
 
