@@ -207,8 +207,9 @@ def main():
         traffic, traffic_src = None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_bench_n1_pmc.json')))
-            if pmc.get('kernel') == name and world == 1:
-                traffic, traffic_src = pmc['traffic_bytes_per_launch'], 'profiles/r01_bench_n1_pmc.json'
+            ent = pmc.get('kernels', {}).get(name) or (pmc if pmc.get('kernel') == name else None)
+            if ent is not None and world == 1:
+                traffic, traffic_src = ent['traffic_bytes_per_launch'], 'profiles/r01_bench_n1_pmc.json'
         except (OSError, ValueError, KeyError):
             pass
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA,

@@ -40,24 +40,32 @@ def main(d, kernel):
         txt.append(t.rstrip())
         parsed[p] = parse(t)
     open(os.path.join(ROOT, 'profiles', 'r01_bench_n1_pmc.txt'), 'w').write('\n'.join(txt) + '\n')
-    f, w, sq, m = (parsed[p][kernel] for p in ('fetch', 'write', 'sq', 'misc'))
-    dur_us = sq['avg_dur_us']
-    cyc = m['GRBM_GUI_ACTIVE'] / 8.0                       # summed over the 8 XCDs
+    def entry(kernel):
+        f, w, sq, m = (parsed[p][kernel] for p in ('fetch', 'write', 'sq', 'misc'))
+        cyc = m['GRBM_GUI_ACTIVE'] / 8.0                       # summed over the 8 XCDs
+        return {
+            "kernel": kernel, "dispatches": f['dispatches'],
+            "FETCH_SIZE_KiB_per_launch": f['FETCH_SIZE'], "WRITE_SIZE_KiB_per_launch": w['WRITE_SIZE'],
+            "traffic_bytes_per_launch": (2 * f['FETCH_SIZE'] + w['WRITE_SIZE']) * 1024,
+            "SQ_VALU_MFMA_BUSY_CYCLES": sq['SQ_VALU_MFMA_BUSY_CYCLES'],
+            "GRBM_GUI_ACTIVE_sum_over_8_xcd": m['GRBM_GUI_ACTIVE'],
+            "avg_dur_us": sq['avg_dur_us'], "avg_dur_us_misc_pass": m['avg_dur_us'],
+            "mfma_busy_fraction": sq['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / cyc,   # 1024 SIMDs
+            "effective_clock_GHz": cyc / m['avg_dur_us'] * 1e-3,
+            "lds_bank_conflict_fraction": m['SQ_LDS_BANK_CONFLICT'] / max(m['SQ_LDS_IDX_ACTIVE'], 1.0),
+        }
+    names = [k for k in parsed['fetch'] if all(k in parsed[p] for p in ('write', 'sq', 'misc')) and
+             parsed['fetch'][k]['avg_dur_us'] > 100.0]
     js = {
         "command": "python bench.py --steps 3 --warmup 2 --no-cpu-baseline (under rocprofv3 --kernel-trace --pmc <counter>, one pass per counter set)",
-        "kernel": kernel, "dispatches": f['dispatches'],
-        "FETCH_SIZE_KiB_per_launch": f['FETCH_SIZE'], "WRITE_SIZE_KiB_per_launch": w['WRITE_SIZE'],
         "correction": "gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM): bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
-        "traffic_bytes_per_launch": (2 * f['FETCH_SIZE'] + w['WRITE_SIZE']) * 1024,
-        "SQ_VALU_MFMA_BUSY_CYCLES": sq['SQ_VALU_MFMA_BUSY_CYCLES'],
-        "GRBM_GUI_ACTIVE_sum_over_8_xcd": m['GRBM_GUI_ACTIVE'],
-        "avg_dur_us": dur_us, "avg_dur_us_misc_pass": m['avg_dur_us'],
-        "mfma_busy_fraction": sq['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / cyc,   # 1024 SIMDs
-        "effective_clock_GHz": cyc / m['avg_dur_us'] * 1e-3,
-        "lds_bank_conflict_fraction": m['SQ_LDS_BANK_CONFLICT'] / max(m['SQ_LDS_IDX_ACTIVE'], 1.0),
+        "kernel": kernel,
+        "kernels": {k: entry(k) for k in names},
     }
+    js.update(entry(kernel))
     json.dump(js, open(os.path.join(ROOT, 'profiles', 'r01_bench_n1_pmc.json'), 'w'), indent=1)
-    print(json.dumps(js, indent=1))
+    print(json.dumps({k: (round(v['traffic_bytes_per_launch'] / 1e6, 1), round(v['mfma_busy_fraction'], 3),
+                          round(v['effective_clock_GHz'], 2)) for k, v in js['kernels'].items()}, indent=1))
 
 
 if __name__ == '__main__':
