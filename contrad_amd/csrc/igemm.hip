@@ -10,14 +10,14 @@
 //          |  class / grid.y) |      |                         |                        |
 //   WGRAD  | (kh,kw,c)        | Cout | n,ho,wo (split, grid.y) | x  (c-contiguous rows) | gy[p][cout]
 //
-// Block = 256 threads = 4 wave64 in a 2x2 arrangement; block tile BM x BN x 32, each wave owns
-// (BM/2)x(BN/2) as 32x32 MFMA tiles.  Operands are staged global -> registers -> LDS (double-buffered LDS,
-// one barrier per K-tile, next tile's global loads in flight during the MFMA phase).  LDS tiles are stored
-// K-major ([k][row]) so the MFMA operand fetch is a conflict-free ds_read_b32 (lane -> consecutive row);
-// operands that are K-contiguous in memory are transposed on the LDS write with leading dimension BM+1
-// (conflict-free scatter), row-contiguous ones are written as 16-byte rows with leading dimension BM+4.
-// fp32 MFMA issues once per 64 cycles per SIMD, so LDS traffic is far from the bottleneck; the design goal
-// is simply "never starve the matrix pipe": >= 2 waves per SIMD, loads issued a full tile ahead.
+// Two kernels share this file's host side (plans, tile choice, C ABI):
+//   * igemm_lean_kernel (igemm_lean.h): the fast path for every shape whose K-tiles sit inside one filter tap
+//     (channel counts % 16) -- buffer loads with hardware zero fill, scalar tap walk, quad LDS layout; see that file.
+//   * igemm_kernel (below): the general path (Cin = 3, Cout = 1, 513 channels, odd WGRAD grids ...).  Block = 256
+//     threads = 4 wave64 in a 2x2 arrangement, block tile BM x BN x 16; operands are staged global -> registers -> LDS
+//     (double-buffered, one barrier per K-tile) with per-element predicate masks; LDS tiles are K-major ([k][row]):
+//     K-contiguous operands are transposed on the LDS write (leading dimension BM+1), row-contiguous ones are written as
+//     16-byte rows (leading dimension BM+4).  VEC = float4-addressable operands, !VEC = per-element gathers (64x64 only).
 //
 // blockIdx.x is remapped XCD-aware (common.h) with the N-tile index fastest, so the blocks that share an
 // activation tile run on the same XCD/L2.

@@ -134,6 +134,35 @@ def test_channel_sliced_views():
     assert outbuf[..., :16].abs().max().item() == 0 and outbuf[..., 64:].abs().max().item() == 0
 
 
+def test_channel_sliced_views_dgrad_wgrad():
+    """Leading dimensions on the backward kernels: gy read from a channel slice, dx written into a slice of a wider
+    buffer (its neighbours untouched), act_ref with the same leading dimension, x read from a slice for wgrad."""
+    N, H, W, C, K = 3, 8, 8, 32, 48
+    g = torch.Generator().manual_seed(6)
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.1
+    gy_big = torch.randn(N, H, W, 80, generator=g)
+    x_big = torch.randn(N, H, W, 96, generator=g)
+    dev = torch.device('cuda')
+    wp = ops.pack_weight(w).to(dev)
+    gy_s = gy_big.to(dev)[..., 16:64]                 # (N,H,W,48) view, ld 80
+    x_s = x_big.to(dev)[..., 32:64]                   # (N,H,W,32) view, ld 96
+    dxbuf = torch.full((N, H, W, 96), 7.0, device=dev)
+    ops.conv2d_dgrad(gy_s, wp, (N, H, W, C), 3, 3, 1, 1, act_ref=x_s, slope=0.2, gain=1.5, out=dxbuf[..., 32:64])
+    xr = x_big[..., 32:64].permute(0, 3, 1, 2)
+    ref = F.conv_transpose2d(gy_big[..., 16:64].permute(0, 3, 1, 2), w, None, stride=1, padding=1)
+    ref = ref * torch.where(xr > 0, torch.tensor(1.5), torch.tensor(1.5 * 0.2))
+    assert rel(dxbuf[..., 32:64].permute(0, 3, 1, 2).cpu(), ref) < TOL
+    assert torch.all(dxbuf[..., :32] == 7.0) and torch.all(dxbuf[..., 64:] == 7.0)
+    db = torch.zeros(K, device=dev)
+    dwp = ops.conv2d_wgrad(x_s, gy_s, 3, 3, 1, 1, dbias=db)
+    xg = x_big[..., 32:64].permute(0, 3, 1, 2).clone().requires_grad_()
+    wr = w.clone().requires_grad_()
+    y = F.conv2d(xg, wr, None, stride=1, padding=1)
+    gw_ref, = torch.autograd.grad(y, wr, gy_big[..., 16:64].permute(0, 3, 1, 2))
+    assert rel(ops.unpack_weight(dwp.cpu(), K, C, 3, 3), gw_ref) < TOL
+    assert rel(db.cpu(), gy_big[..., 16:64].sum((0, 1, 2))) < TOL
+
+
 def test_wgrad_is_deterministic_and_linear():
     N, H, W, C, K = 64, 16, 16, 128, 128
     dev = torch.device('cuda')
