@@ -3,7 +3,7 @@ import os, sys
 import numpy as np
 import torch
 import torch.nn.functional as F
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import contrad_oracle as O
 from contrad_amd import ops
 from contrad_amd.models.gan import get_architecture

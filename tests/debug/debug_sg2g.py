@@ -1,6 +1,6 @@
 import os, sys, math
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import stylegan2_oracle as S
 from contrad_amd.models.gan.stylegan2.generator import Generator
 from contrad_amd import ops

@@ -29,7 +29,7 @@ def grad_close(got, ref, tol):
 # Gradients vs the REFERENCE-generated goldens are compared at FLIP_TOL, not 1e-3: leaky_relu's derivative is
 # discontinuous at 0, and with ~2M activations per step a pre-activation of ~1e-8 (fp32 summation-order noise)
 # lands on the other side of 0 than in the reference's BLAS in roughly every other step, changing that unit's slope
-# 1 <-> 0.1 (tools/debug_dstep.py pin-points the single flipped unit of this fixture).  That is a property of the
+# 1 <-> 0.1 (tests/debug/debug_dstep.py pin-points the single flipped unit of this fixture).  That is a property of the
 # maths, not of a kernel: any two fp32 conv implementations disagree the same way.  The strict 1e-3 element-wise
 # check is test_full_step_on_the_same_linear_region below, where the oracle is evaluated with the activation
 # sign pattern of the run under test; forward quantities, gradient NORMS and the u/v/Adam state are 1e-3 here.
