@@ -218,3 +218,50 @@ def test_overlapped_gradient_exchange_single_rank_rccl():
     finally:
         if own:
             dist.destroy_process_group()
+
+
+def test_full_size_step_is_bitwise_deterministic():
+    """BASELINE size (global batch 512 -> 1536 images through D): every reduction on the path (split-K slabs, bias /
+    BatchNorm column sums, spectral-norm partials, contrastive column splits) has a fixed order, so two runs from the
+    same state and the same samples give bit-identical losses, gradients, power-iteration vectors and Adam updates --
+    and the step has the properties the loss promises (finite, GAN loss of an untrained D = 2 log 2)."""
+    import argparse
+    import copy
+    from contrad_amd.augment import get_augment
+    from contrad_amd.engine import d_step, set_grad
+    from contrad_amd.training.gan import setup
+    import os
+    from contrad_amd import config
+    config.clear_config()
+    config.parse_config_files_and_bindings([os.path.join(config.CONFIG_ROOT, 'defaults', 'gan.gin'),
+                                            os.path.join(config.CONFIG_ROOT, 'defaults', 'augment.gin'),
+                                            os.path.join(config.CONFIG_ROOT, 'gan', 'cifar10', 'c10_b512.gin')])
+    N = 512
+    G0, D0 = build()
+    aug = get_augment(mode='simclr').to(DEV)
+    torch.manual_seed(3); np.random.seed(3)
+    images = torch.rand(N, 3, 32, 32, device=DEV)
+    z = torch.empty(N, 128).uniform_(-1, 1)
+    params = aug.sample(3 * N, 32, 32)
+    outs = []
+    for _ in range(2):
+        G, D = copy.deepcopy(G0), copy.deepcopy(D0)
+        G.sample_latent = lambda n: z.to(DEV)
+        a = copy.deepcopy(aug)
+        a.sample = lambda B, h, w: params
+        P = setup(argparse.Namespace(mode='contrad', aug='simclr', temp=0.1, lbd_a=1.0, distributed=False))
+        P.augment_fn = a
+        opt = FusedAdam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+        set_grad(G, False); set_grad(D, True)
+        d_loss, aux = d_step(P, G, D, opt, {'loss': 'nonsat', 'batch_size': N}, images, None)
+        torch.cuda.synchronize()
+        outs.append((d_loss.detach().clone(), aux['penalty'].detach().clone(),
+                     [p.grad.detach().clone() for p in D.parameters()],
+                     [p.detach().clone() for p in D.parameters()],
+                     [b.detach().clone() for b in D.buffers()]))
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in (2, 3, 4):
+        assert len(a[k]) == len(b[k]) and all(torch.equal(x, y) for x, y in zip(a[k], b[k]))
+    assert torch.isfinite(a[0]).item() and all(torch.isfinite(g).all().item() for g in a[2])
+    assert abs(a[1].item() - 2 * np.log(2)) < 0.05        # sigmoid(0) on both sides: softplus(0) * 2
