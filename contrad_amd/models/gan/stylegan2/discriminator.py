@@ -173,8 +173,11 @@ class ResidualDiscriminatorP(BaseDiscriminator):
             if rec is not None:
                 rec.append(o)
             p0, p1 = blk.skip[0].pad
-            s = A.UpFirDn2dFn.apply(x, blk.skip[0].kernel, 1, 1, (p0, p1, p0, p1))
-            s = A.Conv2dFn.apply(s, wp[idx[(bi, 'skip')]], (co, 1, 1, 2, 0))
+            # skip = Blur -> 1x1 stride-2 conv (discriminator.py:60-63 of the reference).  A 1x1 stride-2 conv only ever
+            # reads the even pixels of its input, so the blur is evaluated at those pixels only (down = 2: a quarter of
+            # the outputs, a quarter of the bytes written and re-read) and the conv runs at stride 1 -- the same sums.
+            s = A.UpFirDn2dFn.apply(x, blk.skip[0].kernel, 1, 2, (p0, p1, p0, p1))
+            s = A.Conv2dFn.apply(s, wp[idx[(bi, 'skip')]], (co, 1, 1, 1, 0))
             x = A.LinCombFn.apply(o, s, inv, inv)
         x = minibatch_stddev_nhwc(x)
         x = A.ConvBiasActFn.apply(x, wp[idx['last']], self.last_conv[1].bias,
