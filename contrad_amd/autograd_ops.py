@@ -318,7 +318,8 @@ class LinCombFn(Function):
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.cfg
-        return g * a, g * b, None, None
+        ga = g * a
+        return ga, (ga if b == a else g * b), None, None    # the ResBlock merge has a == b: one scaled copy feeds both
 
 
 # ----------------------------------------------------------------------------------------------------------
