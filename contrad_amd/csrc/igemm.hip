@@ -824,6 +824,12 @@ int dispatch(const IgemmArgs& a, int bm, int bn, bool vec, dim3 grid, hipStream_
   return launch<MODE, 64, 64, true>(a, grid, s);
 }
 
+// The float4 / buffer-load paths need 16-byte aligned operands (torch allocations and channel slices at multiples of
+// 4 floats are); anything else is a caller error, not a silent slow path.
+bool aligned16(const void* a, const void* b, const void* c) {
+  return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0;
+}
+
 int check_desc(const contrad_conv_desc* d) {
   CONTRAD_ARG(d != nullptr);
   CONTRAD_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0);
@@ -934,6 +940,7 @@ extern "C" int contrad_conv2d_fwd(const contrad_conv_desc* d, const float* x, co
   int rc = check_desc(d);
   if (rc) return rc;
   CONTRAD_ARG(x && wp && y);
+  if (vec_ok(d, MODE_FWD)) CONTRAD_ARG(aligned16(x, wp, y));
   IgemmArgs a{};
   a.A = x; a.B = wp; a.C = y; a.bias = bias; a.d = *d; a.slope = slope; a.gain = gain;
   const long long M = (long long)d->N * d->Ho * d->Wo;
@@ -964,6 +971,7 @@ extern "C" int contrad_conv2d_dgrad(const contrad_conv_desc* d, const float* gy,
   int rc = check_desc(d);
   if (rc) return rc;
   CONTRAD_ARG(gy && wp && dx);
+  if (vec_ok(d, MODE_DGRAD)) CONTRAD_ARG(aligned16(gy, wp, dx) && aligned16(act_ref, nullptr, nullptr));
   // every input pixel must be covered by at least one tap of its parity class, otherwise the class
   // (whose gradient is exactly zero) still writes zeros: handled by Kg == 0 -> T == 0 -> acc = 0.
   IgemmArgs a{};
@@ -1020,6 +1028,7 @@ extern "C" int contrad_conv2d_wgrad(const contrad_conv_desc* d, const float* x, 
   int rc = check_desc(d);
   if (rc) return rc;
   CONTRAD_ARG(x && gy && dwp && workspace);
+  if (vec_ok(d, MODE_WGRAD)) CONTRAD_ARG(aligned16(x, gy, workspace));
   CONTRAD_ARG(workspace_bytes >= contrad_conv2d_wgrad_workspace_bytes(d));
   int bm, bn, splits, pps;
   IgemmArgs a{};

@@ -44,7 +44,10 @@ typedef struct {
   int ldw;          /* floats between rows of the packed weight [KH*KW*C][ldw] (>= K)  */
 } contrad_conv_desc;
 
-/* y[n,ho,wo,k] = gain * lrelu_slope( sum_{kh,kw,c} x[n,ho*s-p+kh,wo*s-p+kw,c] * wp[(kh,kw,c),k] + bias[k] )
+/* Alignment: when the channel counts / leading dimensions are multiples of 4 the kernels use 16-byte accesses, and
+ * x, wp, y, gy, dx, act_ref and the workspaces must then be 16-byte aligned (-EINVAL otherwise).
+ *
+ * y[n,ho,wo,k] = gain * lrelu_slope( sum_{kh,kw,c} x[n,ho*s-p+kh,wo*s-p+kw,c] * wp[(kh,kw,c),k] + bias[k] )
  * bias may be NULL; slope = 1 disables the activation. */
 int contrad_conv2d_fwd(const contrad_conv_desc* d, const float* x, const float* wp, const float* bias,
                        float* y, float slope, float gain, float* workspace, long long workspace_bytes,
