@@ -96,8 +96,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     multi = world > 1 or args.force_dist
+    # RCCL writes its banner and warnings to STDOUT, unterminated, possibly in the middle of our line: keep stdout to the
+    # one JSON line by sending them to stderr (and never ask for the version banner)
     if os.environ.get('NCCL_DEBUG', '').upper() == 'VERSION':
-        os.environ['NCCL_DEBUG'] = 'WARN'     # the RCCL version banner goes to STDOUT; keep it to the one JSON line
+        os.environ['NCCL_DEBUG'] = 'WARN'
+    os.environ.setdefault('NCCL_DEBUG_FILE', '/dev/stderr')
     if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29566')
@@ -237,9 +240,11 @@ def main():
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
     if multi:
-        dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()             # before the JSON line: nothing RCCL prints can follow or split it
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':
