@@ -39,3 +39,42 @@ def test_argument_errors_are_reported_without_gpu(built):
     assert built.raw('contrad_conv2d_wgrad_workspace_bytes')(ctypes.byref(d)) < 0
     d = _lib.ConvDesc(2, 8, 8, 4, 4, 8, 8, 8, 8, 3, 3, 1, 1, 8)
     assert built.raw('contrad_conv2d_wgrad_workspace_bytes')(ctypes.byref(d)) >= 3 * 3 * 4 * 8 * 4
+
+
+def _desc(N, H, C, K, k, s, p):
+    Ho = (H + 2 * p - k) // s + 1
+    return _lib.ConvDesc(N, H, H, C, C, Ho, Ho, K, K, k, k, s, p, (K + 3) // 4 * 4)
+
+
+# SNDCGAN discriminator trunk at the BASELINE batch (3N = 1536 images): (H, Cin, Cout, k, stride, pad)
+_SNDCGAN = [(32, 64, 128, 4, 2, 1), (16, 128, 128, 3, 1, 1), (16, 128, 256, 4, 2, 1), (8, 256, 256, 3, 1, 1),
+            (8, 256, 512, 4, 2, 1), (4, 512, 512, 3, 1, 1)]
+
+
+def test_launch_plans_are_host_logic(built):
+    """Kernel family, tile and split-K decisions are pure host code behind the C ABI: every igemm layer of the headline
+    configuration must land on the lean loop at the big tile, odd shapes on the general kernel, and the merged head GEMM
+    of a small per-rank batch on the split-K forward (with a workspace to match)."""
+    path, tile = built.raw('contrad_conv2d_path'), built.raw('contrad_conv2d_tile')
+    bm, bn = ctypes.c_int(0), ctypes.c_int(0)
+    for (H, C, K, k, s, p) in _SNDCGAN:
+        d = _desc(1536, H, C, K, k, s, p)
+        for mode in (0, 1, 2):
+            assert path(ctypes.byref(d), mode) == 2, (H, C, K, mode)
+            assert tile(ctypes.byref(d), mode, ctypes.byref(bm), ctypes.byref(bn)) == 0
+            want_bn = 64 if (mode == 1 and C == 64) else 128        # dgrad's columns are the input channels
+            assert (bm.value, bn.value) == (128, want_bn), (H, C, K, mode, bm.value, bn.value)
+        assert built.raw('contrad_conv2d_fwd_workspace_bytes')(ctypes.byref(d)) == 0
+    # Cin = 3 / Cout = 1 / 513 channels: general kernel, scalar or float4 gathers
+    assert path(ctypes.byref(_desc(8, 32, 3, 64, 3, 1, 1)), 0) == 0
+    assert path(ctypes.byref(_desc(8, 1, 512, 1, 1, 1, 0)), 0) == 0
+    assert path(ctypes.byref(_desc(8, 4, 516, 512, 3, 1, 1)), 0) == 1
+    # 32-column GEMM (StyleGAN2 at 512x512): the 128x32 tile
+    d = _desc(48, 64, 32, 32, 3, 1, 1)
+    assert tile(ctypes.byref(d), 0, ctypes.byref(bm), ctypes.byref(bn)) == 0 and (bm.value, bn.value) == (128, 32)
+    # merged head layer at 3N = 192 rows: split-K forward with partial slabs of M x N floats each
+    d = _desc(192, 1, 8192, 1536, 1, 1, 0)
+    nbytes = built.raw('contrad_conv2d_fwd_workspace_bytes')(ctypes.byref(d))
+    assert nbytes > 0 and nbytes % (192 * 1536 * 4) == 0 and 2 <= nbytes // (192 * 1536 * 4) <= 16
+    # contrastive column splits: ~256 blocks
+    assert built.raw('contrad_contrast_workspace_bytes')(1024, 128) == 16 * 1024 * 128 * 4
