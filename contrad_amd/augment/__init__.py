@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..hostio import upload
 from ..config import configurable, get_bindings
 
 __all__ = ['get_augment', 'SimCLRAugment', 'simclr', 'simclr_hq']
@@ -128,7 +129,7 @@ class SimCLRAugment(nn.Module):
 
     def apply(self, inputs, P, contrast_first, sigma=None):
         """Deterministic device part."""
-        Pd = P.to(inputs.device)      # (B,12) parameter block; synchronous pageable upload (see G.sample_latent)
+        Pd = upload(P, inputs.device)      # (B,12) parameter block (asynchronous pinned upload, contrad_amd/hostio.py)
         if inputs.requires_grad and torch.is_grad_enabled():
             if sigma is not None:
                 raise NotImplementedError('backward through simclr_hq (large images / blur) is scope row N2')

@@ -316,6 +316,13 @@ __global__ void axpby_kernel(float* __restrict__ y, const float* __restrict__ x,
     y[i] = a * y[i] + bcoef * x[i];
 }
 
+// dst[i] = src[i]; src may be PINNED HOST memory (device-mapped): the per-step random draws are pulled over PCIe by
+// this kernel instead of a runtime H2D copy (see contrad_amd/hostio.py for why)
+__global__ void pull_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
 int colstats_plan(long long M, int* rows_per_block, int* nblocks) {
   long long nb = (M + 31) / 32;    // >= 32 rows per block (a 512-row BatchNorm1d still spreads over 16 row blocks)
   if (nb > 512) nb = 512;
@@ -463,6 +470,15 @@ extern "C" int contrad_axpby(float* y, const float* x, long long n, float a, flo
   long long grid = (n + 255) / 256;
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(axpby_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, y, x, n, a, b);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int contrad_pull_host(const float* host_pinned, float* dst, long long n, contrad_stream_t stream) {
+  CONTRAD_ARG(host_pinned && dst && n > 0);
+  long long grid = (n + 255) / 256;
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(pull_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, host_pinned, dst, n);
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }

@@ -10,6 +10,8 @@ so the exchange is two large collectives over xGMI instead of DDP's 25 MB bucket
 import torch
 import torch.distributed as dist
 
+from .hostio import THROTTLE
+
 
 # Test hook: run every collective code path on a 1-rank process group (set by bench.py --force-dist / tests).
 FORCE_DIST = False
@@ -103,6 +105,7 @@ def set_grad(model, flag=True):
 def d_step(P, G, D, opt_D, options, images, reducer=None):
     """One discriminator step, exactly train_gan.py:153-163 (minus the four logging .item() syncs): fakes under
     no_grad -> loss_D_fn -> zero_grad -> backward -> [gradient all-reduce] -> Adam.  Returns (d_loss, aux)."""
+    THROTTLE.begin()                          # host stays at most one step ahead of the GPU (hostio.py)
     gen_images = sample_generator(G, images.size(0), enable_grad=False)
     d_loss, aux = P.train_fn["D"](P, D, options, images, gen_images)
     loss = d_loss + aux['penalty']
@@ -117,6 +120,7 @@ def d_step(P, G, D, opt_D, options, images, reducer=None):
         opt_D.step(grad_scale=1.0 / world)
     else:
         opt_D.step()
+    THROTTLE.end()
     return d_loss, aux
 
 

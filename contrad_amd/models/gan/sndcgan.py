@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.distributed as dist
 
 from ... import ops
+from ...hostio import upload
 from ... import autograd_ops as A
 from .base import BaseDiscriminator, SNParams, TinyHead, _Act, make_projection
 
@@ -378,12 +379,9 @@ class G_SNDCGAN(nn.Module):
         self._packed_key = None
 
     def sample_latent(self, n_samples):
-        # U(-1,1) from the CPU generator, as the reference (sndcgan.py:50-52).  The pageable upload is synchronous
-        # on purpose: it bounds the host's run-ahead to one step.  (Asynchronous pinned uploads let the host queue
-        # >= 3 steps ahead, at which point the ROCm 7.2 runtime stalls and drains the whole queue every third step:
-        # measured 31.4 vs 22.8 ms/step at N = 512, tools/dbg_runahead.py.)
+        # U(-1,1) from the CPU generator, as the reference (sndcgan.py:50-52); handed over by contrad_amd/hostio.py
         _device = next(self.parameters()).device
-        return torch.empty(n_samples, self.nz).uniform_(-1, 1).to(_device)
+        return upload(torch.empty(n_samples, self.nz).uniform_(-1, 1), _device)
 
     def _weights(self):
         ws = [self.linear.weight] + [self.main[3 * j].weight for j in range(4)]

@@ -215,6 +215,9 @@ int contrad_adam_step(const contrad_adam_batch* b, int step, float lr, float bet
                       float grad_scale, contrad_stream_t stream);
 /* y = a*y + b*x (G EMA `accumulate`, utils.py:130-143) */
 int contrad_axpby(float* y, const float* x, long long n, float a, float b, contrad_stream_t stream);
+/* dst[0..n) (device) = host_pinned[0..n): a kernel reads device-mapped pinned host memory (hipHostMalloc) directly --
+ * the stream-ordered hand-over of the per-step host-side random draws (latents, augmentation parameters). */
+int contrad_pull_host(const float* host_pinned, float* dst, long long n, contrad_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SimCLR augmentation, fused (augment/__init__.py:106-122 `simclr()` / `simclr_hq()`):

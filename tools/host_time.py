@@ -36,6 +36,10 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print('batch %d: host enqueue %.2f ms/step, synchronised total %.2f ms/step' % (B, (t1 - t0) / K * 1e3, (t2 - t0) / K * 1e3))
+ms = torch.cuda.memory_stats()
+print('allocator: segments allocated %d freed %d, retries %d, reserved %.2f GB, peak allocated %.2f GB' % (
+    ms.get('segment.all.allocated', -1), ms.get('segment.all.freed', -1), ms.get('num_alloc_retries', -1),
+    ms.get('reserved_bytes.all.current', 0) / 2**30, ms.get('allocated_bytes.all.peak', 0) / 2**30))
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(K):
