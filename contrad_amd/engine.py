@@ -140,6 +140,7 @@ def r1_loss(D, images, augment_fn):
 def d_step_stylegan2(P, G, D, opt_D, options, images, step, reducer=None, style_mix=0.9):
     """D-step of train_stylegan2.py:199-212 (BASELINE config 4): single 3N-image D call via loss_D_fn, plus the
     R1 penalty every ``P.d_reg_every`` steps weighted (0.5*lbd_r1)*r1*d_reg_every (``--no_lazy`` => every step)."""
+    THROTTLE.begin()
     with torch.no_grad():
         gen_images = G(G.sample_latent(images.size(0)), style_mix=style_mix)
     d_loss, aux = P.train_fn["D"](P, D, options, images, gen_images)
@@ -152,6 +153,7 @@ def d_step_stylegan2(P, G, D, opt_D, options, images, step, reducer=None, style_
     loss.backward()
     world = reducer() if reducer is not None else 1
     opt_D.step(grad_scale=1.0 / world) if world > 1 else opt_D.step()
+    THROTTLE.end()
     return d_loss, aux
 
 
@@ -161,6 +163,7 @@ def d_step_stylegan2_contrad(P, G, D, opt_D, options, images, step, reducer=None
     (_loss_D_fn, :95-109); lazy R1 on its own D call."""
     from .training.gan.contrad import _ContraDContrastive, _GanDLoss
     N = images.size(0)
+    THROTTLE.begin()
     with torch.no_grad():
         gen_images = G(G.sample_latent(N), style_mix=style_mix)
     d_gen, aux_g = D(P.augment_fn(gen_images), sg_linear=True, projection=True, projection2=True)
@@ -181,4 +184,5 @@ def d_step_stylegan2_contrad(P, G, D, opt_D, options, images, step, reducer=None
     loss.backward()
     world = reducer() if reducer is not None else 1
     opt_D.step(grad_scale=1.0 / world) if world > 1 else opt_D.step()
+    THROTTLE.end()
     return simclr + P.lbd_a * sup, aux
