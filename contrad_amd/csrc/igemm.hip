@@ -853,13 +853,16 @@ int wgrad_plan(const contrad_conv_desc* d, int* bm, int* bn, int* tiles_m, int* 
   const long long P = (long long)d->N * d->Ho * d->Wo;
   *bn = (d->K > 64) ? 128 : 64;
   *bm = (Kg > 64) ? 128 : 64;
+  static const int forced = []() { const char* e = getenv("CONTRAD_WGRAD_TILE"); return e ? atoi(e) : 0; }();  // dev
+  if (forced) { *bm = forced / 1000; *bn = forced % 1000; }
+  static const int target = []() { const char* e = getenv("CONTRAD_WGRAD_BLOCKS"); return e ? atoi(e) : 1024; }();  // dev
   if (!vec_ok(d, MODE_WGRAD)) { *bm = 64; *bn = 64; }
   *tiles_m = cdiv(Kg, *bm);
   *tiles_n = cdiv(d->K, *bn);
   const long long ptiles = cdivll(P, BK);
   // 2 blocks are resident per CU (LDS): aim at <= 1024 blocks = two full rounds of the 256 CUs, never a ragged
   // third one (9 x 114 = 1026 blocks cost +30 % on the 3x3 layers before this was a floor)
-  long long want = 1024 / ((long long)(*tiles_m) * (*tiles_n));
+  long long want = target / ((long long)(*tiles_m) * (*tiles_n));
   if (want < 1) want = 1;
   long long pps = cdivll(ptiles, want);
   if (pps < 4) pps = 4;  // at least 128 positions per split
