@@ -419,6 +419,7 @@ def adam_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, beta2, eps=
 
 def axpby_(y, x, a, b):
     lib().call('contrad_axpby', _p(y), _p(x), ctypes.c_longlong(y.numel()), float(a), float(b), _stream())
+    torch.autograd.graph.increment_version(y)          # raw-pointer write: keep ``_version``-keyed caches honest
     return y
 
 
@@ -535,11 +536,15 @@ def bn_relu_bwd(dy2d, x2d, stats, count, gamma, beta, eps, reduce_fn=None):
     ws = _workspace(nbytes, x2d.device)
     lib().call('contrad_bn_relu_bwd_stats', _p(dy2d), _p(x2d), ctypes.c_longlong(M), K, ld, _p(stats), float(count),
                _p(gamma), _p(beta), float(eps), _p(out), _p(ws), ctypes.c_longlong(ws.numel() * 4), _stream())
+    # SyncBN: dx needs the GLOBAL {sum dy, sum dy*xhat}; dgamma / dbeta stay this rank's LOCAL sums (as
+    # torch.nn.SyncBatchNorm returns them) -- the gradient exchange averages them like every other parameter
+    local = out
     if reduce_fn is not None:
+        local = out.clone()
         reduce_fn(out)
     dx = torch.empty_like(x2d)
     if _ld(dx) != ld:
         raise RuntimeError('contrad_hip: bn backward expects dense rows')
     lib().call('contrad_bn_relu_bwd_apply', _p(dy2d), _p(x2d), _p(dx), ctypes.c_longlong(M), K, ld, _p(stats),
                float(count), _p(gamma), _p(beta), float(eps), _p(out), _stream())
-    return dx, out[1], out[0]
+    return dx, local[1], local[0]

@@ -33,4 +33,8 @@ class FusedAdam(torch.optim.Optimizer):
                 ops.adam_step([p.data for p in ps], [p.grad.data for p in ps],
                               [self.state[p]['exp_avg'] for p in ps], [self.state[p]['exp_avg_sq'] for p in ps],
                               step, group['lr'], beta1, beta2, group['eps'], grad_scale)
+                # the kernel writes through raw pointers: tell autograd's version counters, so that everything keyed
+                # on ``p._version`` (the generators' packed-weight caches) sees the update
+                for p in ps:
+                    torch.autograd.graph.increment_version(p)
         return loss

@@ -21,6 +21,7 @@ import torch.distributed as dist
 from . import config
 from .augment import get_augment
 from .engine import GradAllReducer, OverlappedGradReducer, sample_generator, set_grad
+from .hostio import THROTTLE
 from .models.gan import get_architecture
 from .optim import FusedAdam
 from .training.gan import setup
@@ -98,8 +99,11 @@ def _dataset_loader(name, batch, rank, world, workers):
         sampler.set_epoch(epoch)
 
 
-def train_step(P, opt, G, D, opt_G, opt_D, images, step, reducers):
-    """One iteration of train_gan.py:141-179.  Returns the loss tensors (no host sync)."""
+def train_step(P, opt, G, D, opt_G, opt_D, loader, step, reducers):
+    """One iteration of train_gan.py:141-179.  ``loader`` yields (images, labels); a fresh real batch is drawn for
+    every critic iteration (train_gan.py:153-155) and the last one feeds the G-step.  Returns the loss tensors (no
+    host sync)."""
+    THROTTLE.begin()                          # host stays at most one step ahead of the GPU (hostio.py)
     G.train(); D.train()
     if P.use_warmup:
         _update_warmup(opt_G, step, opt["warmup"], opt["lr"])
@@ -107,6 +111,7 @@ def train_step(P, opt, G, D, opt_G, opt_D, images, step, reducers):
     red_G, red_D = reducers
     set_grad(G, False); set_grad(D, True)
     for _ in range(opt['n_critic']):
+        images, _labels = next(loader)
         gen_images = sample_generator(G, images.size(0), enable_grad=False)
         d_loss, aux = P.train_fn["D"](P, D, opt, images, gen_images)
         loss = d_loss + aux['penalty']
@@ -122,6 +127,7 @@ def train_step(P, opt, G, D, opt_G, opt_D, images, step, reducers):
     g_loss.backward()
     world = red_G() if red_G is not None else 1
     opt_G.step(grad_scale=1.0 / world) if world > 1 else opt_G.step()
+    THROTTLE.end()
     return {'G_loss': g_loss, 'D_loss': d_loss, 'D_penalty': aux['penalty'], 'D_real': aux['d_real'],
             'D_gen': aux['d_gen']}
 
@@ -150,7 +156,10 @@ def main(argv=None):
     if P.max_steps is not None:
         options['max_steps'] = P.max_steps
     options['batch_size'] = options['batch_size'] // world                  # train_gan.py:247
-    image_size = IMAGE_SIZES.get(options['dataset'], (32, 32, 3))
+    if options['dataset'] not in IMAGE_SIZES:
+        raise NotImplementedError("dataset '%s' (train_gan.py drives %s; the StyleGAN2 high-resolution configs run "
+                                  "through train_stylegan2_contraD.py)" % (options['dataset'], sorted(IMAGE_SIZES)))
+    image_size = IMAGE_SIZES[options['dataset']]
 
     torch.manual_seed(P.seed); np.random.seed(P.seed)                       # identical initial weights on all ranks
     G, D = get_architecture(P.architecture, image_size, P=P)
@@ -204,8 +213,7 @@ def main(argv=None):
 
     t0 = time.time()
     for step in range(starting_step, options['max_steps'] + 1):
-        images, _ = next(loader)
-        losses = train_step(P, options, G, D, opt_G, opt_D, images, step, reducers)
+        losses = train_step(P, options, G, D, opt_G, opt_D, loader, step, reducers)
         if step % P.print_every == 0:
             vals = {k: float(v.detach()) for k, v in losses.items()}              # the only host sync of the loop
             log('[Steps %7d] [G %.3f] [D %.3f] [pen %.3f] [%.1f img/s]' %

@@ -90,8 +90,7 @@ def _worker(rank, world, port, path):
         torch.save({'d_loss': d_loss.detach().cpu(), 'gan': aux['penalty'].detach().cpu(),
                     'grads': [p.grad.detach().cpu().clone() for p in D.parameters()],
                     'params': [p.detach().cpu().clone() for p in D.parameters()],
-                    'bn_mean': [m.running_mean.cpu().clone() for m in G.modules()
-                                if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d))]},
+                    'bn_mean': [m.running_mean.cpu().clone() for m in G.modules() if hasattr(m, 'running_mean')]},
                    '%s.rank%d' % (path, rank))
     finally:
         dist.destroy_process_group()
@@ -128,8 +127,7 @@ def test_two_ranks_equal_one_rank_on_the_global_batch(tmp_path):
         (d_loss if which == 'con' else aux['penalty']).backward()
         grads.append([p.grad.detach().cpu().clone() for p in D.parameters()])
         losses.append((d_loss.item(), aux['penalty'].item()))
-        bn_mean = [m.running_mean.cpu().clone() for m in Gc.modules()
-                   if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d))]
+        bn_mean = [m.running_mean.cpu().clone() for m in Gc.modules() if hasattr(m, 'running_mean')]
     g_con, g_gan = grads
     con_ref, gan_ref = losses[0]
 
@@ -138,6 +136,7 @@ def test_two_ranks_equal_one_rank_on_the_global_batch(tmp_path):
         assert abs(r['d_loss'].item() - con_ref) < TOL * abs(con_ref)
     assert abs(sum(r['gan'].item() for r in res) / WORLD - gan_ref) < TOL * abs(gan_ref)
     # SyncBN: both ranks tracked the GLOBAL batch statistics
+    assert len(bn_mean) == 4 and len(res[0]['bn_mean']) == 4 and len(res[1]['bn_mean']) == 4
     for a, b0, b1 in zip(bn_mean, res[0]['bn_mean'], res[1]['bn_mean']):
         assert rel(b0, a) < TOL and torch.equal(b0, b1)
     # gradients after the exchange are identical on both ranks and equal the single-rank decomposition
@@ -149,3 +148,61 @@ def test_two_ranks_equal_one_rank_on_the_global_batch(tmp_path):
     # Adam with grad_scale 1/W on identical gradients -> identical weights on both ranks
     for a, b in zip(res[0]['params'], res[1]['params']):
         assert torch.equal(a, b)
+
+
+def _gstep_worker(rank, world, port, path):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from contrad_amd.engine import GradAllReducer, set_grad
+        G, D, aug, setup, dev = _setup()
+        images, z, P, cf, sigma = _global_inputs(aug)
+        sl = slice(rank * NL, (rank + 1) * NL)
+        _inject(G, aug, z[sl], P[sl], cf, sigma, dev)
+        Pn = setup(argparse.Namespace(mode='contrad', aug='simclr', temp=0.1, lbd_a=1.0, distributed=True))
+        Pn.augment_fn = aug
+        set_grad(G, True); set_grad(D, False)
+        g_loss = Pn.train_fn["G"](Pn, D, {'loss': 'nonsat'}, None, G(G.sample_latent(NL)))
+        g_loss.backward()
+        local = [p.grad.detach().cpu().clone() for p in G.parameters()]
+        world_n = GradAllReducer(G.parameters())()
+        torch.cuda.synchronize()
+        torch.save({'g_loss': g_loss.detach().cpu(), 'world': world_n, 'local': local,
+                    'grads': [p.grad.detach().cpu().clone() for p in G.parameters()]}, '%s.rank%d' % (path, rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_generator_step_equals_one_rank_on_the_global_batch(tmp_path):
+    """SyncBN backward.  dx uses the GLOBAL batch sums, dgamma / dbeta stay LOCAL and are averaged
+    by the gradient exchange like every other parameter:  sum_r grad_r / W == grad(global-mean G loss)."""
+    import torch.multiprocessing as mp
+    from contrad_amd.engine import set_grad
+    path = str(tmp_path / 'dpg')
+    mp.spawn(_gstep_worker, args=(WORLD, 29537, path), nprocs=WORLD, join=True)
+    res = [torch.load('%s.rank%d' % (path, r)) for r in range(WORLD)]
+    G, D, aug, setup, dev = _setup()
+    images, z, P, cf, sigma = _global_inputs(aug)
+    N = NL * WORLD
+    _inject(G, aug, z, P[:N], cf, sigma, dev)
+    Pn = setup(argparse.Namespace(mode='contrad', aug='simclr', temp=0.1, lbd_a=1.0, distributed=False))
+    Pn.augment_fn = aug
+    set_grad(G, True); set_grad(D, False)
+    g_loss = Pn.train_fn["G"](Pn, D, {'loss': 'nonsat'}, None, G(G.sample_latent(N)))
+    g_loss.backward()
+    assert res[0]['world'] == WORLD
+    assert abs(sum(r['g_loss'].item() for r in res) / WORLD - g_loss.item()) < TOL * abs(g_loss.item())
+    names = [k for k, _ in G.named_parameters()]
+    for i, p in enumerate(G.parameters()):
+        want = p.grad.detach().cpu()
+        assert torch.equal(res[0]['grads'][i], res[1]['grads'][i])
+        got = res[0]['grads'][i] / WORLD
+        if want.abs().max() < 1e-7:
+            assert got.abs().max() < 1e-5, names[i]
+        else:
+            assert rel(got, want) < 5 * TOL, (names[i], rel(got, want))
+        # the BatchNorm affine gradients are rank-LOCAL sums before the exchange (not already global)
+        if names[i].endswith(('norm_init.weight', 'main.1.weight', 'main.4.weight', 'main.7.weight')):
+            assert not torch.equal(res[0]['local'][i], res[1]['local'][i]), names[i]

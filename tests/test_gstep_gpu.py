@@ -143,3 +143,31 @@ def test_generator_step_on_the_same_linear_region():
         if ref.norm().item() < 1e-7:
             continue
         assert l2(prm.grad, ref) < 5e-3, (k, l2(prm.grad, ref))
+
+
+def test_no_grad_forward_sees_the_optimizer_update():
+    """the packed-weight cache of G is keyed on ``_version``; the fused Adam writes through raw
+    pointers, so it must bump the counters -- the D-step's fakes have to come from the UPDATED generator."""
+    import copy
+    from contrad_amd.optim import FusedAdam
+    N = 8
+    G, D = build()
+    set_grad(G, False)
+    z = (torch.rand(N, 128, generator=torch.Generator().manual_seed(5)) * 2 - 1).to(DEV)
+    with torch.no_grad():
+        before = G(z).clone()                      # fills the cache
+    set_grad(G, True); set_grad(D, False)
+    P = _P()
+    P.augment_fn = SimCLRAugment(scale=(0.2, 1.0))
+    opt_G = FusedAdam(G.parameters(), lr=1e-2, betas=(0.5, 0.999))
+    torch.manual_seed(3); np.random.seed(3)
+    hip_contrad.loss_G_fn(P, D, {'loss': 'nonsat'}, None, G(z)).backward()
+    opt_G.step()
+    set_grad(G, False)
+    with torch.no_grad():
+        after = G(z)
+        fresh = copy.deepcopy(G)                  # a fresh module packs from the live parameters
+        fresh._packed = fresh._packed_key = None
+        want = fresh(z)
+    assert rel(after, want) < 1e-6
+    assert (after - before).abs().max().item() > 1e-3      # and the update is visible at all
