@@ -1,17 +1,30 @@
 #!/usr/bin/env python
-"""Headline benchmark: discriminator-step images/sec (ContraD, SimCLR aug), SNDCGAN on CIFAR-10-shaped synthetic
-data, global batch 512 (BASELINE.json configs[1]; configs[2] = the same global batch over N GPUs).
+"""Headline benchmark: discriminator-step images/sec (ContraD, SimCLR aug) on synthetic batches, random-init weights.
 
-    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W] [--config c10_b512|sg2_32|sg2_512|all]
+
+``--gpus N`` (N > 1) spawns one process per GPU itself (re-exec under ``torch.distributed.run`` on 127.0.0.1, as the
+reference's ``mp.spawn`` does, train_gan.py:331) unless it already runs inside such a launch (WORLD_SIZE set).
+
+Workloads (BASELINE.json configs):
+  c10_b512  SNDCGAN + ContraD, CIFAR-10 32x32, GLOBAL batch 512, simclr aug (configs[1]; [2] = the same over N GPUs)
+            -- the configuration the metric is quoted on: the top-level fields of the JSON line.  "strong" scaling.
+  sg2_32    StyleGAN2 small32 + ContraD, 32x32, batch 64 per GPU, R1 every step (train_stylegan2.py --no_lazy) (configs[3])
+  sg2_512   StyleGAN2_512 + ContraD, 512x512, batch 16 per GPU, simclr_hq aug, lazy R1 every 16th step
+            (train_stylegan2_contraD.py semantics: separate N and 2N discriminator calls) (configs[4])
+With ``--config all`` (the default) the two StyleGAN2 workloads run after the headline one and are reported under
+``"other_configs"`` of the same single JSON line, each with its own ``roofline`` (and ``cpu_baseline`` at N=1).
 
 One "step" = one full D-step of the reference loop (train_gan.py:153-163): no-grad G forward for N fakes ->
-SimCLR-augment 3N images -> D forward -> NT-Xent + SupCon + non-saturating GAN loss -> backward -> [embedding
-all-gather / gradient all-reduce over RCCL] -> Adam on D.  Inputs are resident in HBM before the timed region;
-weights are random-init.  Prints ONE JSON line on rank 0.
+SimCLR-augment 3N images -> D forward -> NT-Xent + SupCon + non-saturating GAN loss [+ R1] -> backward -> [embedding
+all-gather / gradient all-reduce over RCCL] -> Adam on D.  Inputs are resident in HBM before the timed region.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,21 +35,56 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-GLOBAL_BATCH = 512
-FLOP_PER_IMAGE = 4.28e9        # algorithmic FLOPs of one SNDCGAN D-step per real image
 PEAK_FP32_MFMA = 157.3         # TFLOP/s, MI355X_MICROARCH.md chip table (v_mfma_f32_32x32x2_f32)
 
+# flop_per_image: SURVEY.md 8(d) -- algorithmic FLOPs of one D-step per real image (FlopCounterMode on the reference
+# path), R1 amortised over its period.
+CONFIGS = {
+    'c10_b512': dict(arch='sndcgan', size=32, batch=512, batch_is_global=True, aug='simclr',
+                     gin=('gan', 'cifar10', 'c10_b512.gin'), flop_per_image=4.28e9, d_reg_every=0, lbd_r1=0.0,
+                     steps=20, warmup=5,
+                     workload="SNDCGAN + ContraD D-step, CIFAR-10 32x32, global batch %d, simclr aug, nonsat loss, "
+                              "Adam(2e-4,(0.5,0.999)), random-init weights"),
+    'sg2_32': dict(arch='stylegan2', size=32, batch=64, batch_is_global=False, aug='simclr',
+                   gin=('gan', 'stylegan2', 'c10_style64.gin'), flop_per_image=14.29e9 + 8.6e9, d_reg_every=1,
+                   lbd_r1=0.1, steps=10, warmup=3,
+                   workload="StyleGAN2(small32) + ContraD D-step, 32x32, batch %d per GPU, simclr aug, R1 every step "
+                            "(--no_lazy, lbd_r1 0.1), single 3N discriminator call (train_stylegan2.py), "
+                            "Adam(2e-3,(0,0.99)), random-init weights"),
+    'sg2_512': dict(arch='stylegan2_512', size=512, batch=16, batch_is_global=False, aug='simclr_hq',
+                    gin=('gan', 'stylegan2', 'afhq_dog_style64.gin'), flop_per_image=388.7e9 + 235e9 / 16,
+                    d_reg_every=16, lbd_r1=0.5, steps=16, warmup=2,
+                    workload="StyleGAN2_512 (channel multiplier 1) + ContraD D-step, AFHQ-shaped 512x512, batch %d per "
+                             "GPU, simclr_hq aug (crop 0.08-1, jitter 0.8/0.8/0.8/0.2, gaussian blur k=51), lazy R1 every "
+                             "16th step (lbd_r1 0.5), separate N and 2N discriminator calls "
+                             "(train_stylegan2_contraD.py), Adam(2.5e-3,(0,0.99)), random-init weights"),
+}
 
-def cpu_baseline(n=64, steps=5):
-    """BASELINE.json configs[0] on the host cores: the oracle's (= reference algorithm's) PyTorch-CPU D-step."""
-    from oracle import contrad_oracle as O
-    torch.manual_seed(0); np.random.seed(0)
+
+def _threads():
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    threads = max(1, min(avail, 32))      # the 32x32 convs stop scaling (and oversubscribe) beyond that
-    torch.set_num_threads(threads)
+    return max(1, min(avail, 32))      # the small convs stop scaling (and oversubscribe) beyond that
+
+
+def _time_cpu(step, budget_s=20.0, max_steps=5):
+    t0 = time.perf_counter()
+    step(1)
+    warm = time.perf_counter() - t0
+    steps = max(1, min(max_steps, int(budget_s / max(warm, 1e-3))))      # bound the sample to ~20 s of CPU work
+    t0 = time.perf_counter()
+    for t in range(steps):
+        step(t + 2)
+    return (time.perf_counter() - t0) / steps, steps
+
+
+def cpu_baseline_c10(n=64):
+    """BASELINE.json configs[0] on the host cores: the oracle's (= reference algorithm's) PyTorch-CPU D-step."""
+    from oracle import contrad_oracle as O
+    torch.manual_seed(0); np.random.seed(0)
+    torch.set_num_threads(_threads())
     sd = O.det_fill(O.sndcgan_d_param_shapes(), seed=1)
     gsd = O.det_fill(O.sndcgan_g_param_shapes(), seed=2)
     params = [k for k in sd if k.endswith('weight_orig') or k.endswith('bias')]
@@ -59,40 +107,266 @@ def cpu_baseline(n=64, steps=5):
             for k in params:
                 O.adam_step(sd[k], sd[k].grad, m[k], v[k], t, 2e-4, 0.5, 0.999)
 
-    t0 = time.perf_counter()
-    step(1)
-    warm = time.perf_counter() - t0
-    steps = max(1, min(steps, int(20.0 / max(warm, 1e-3))))      # bound the sample to ~20 s of CPU work
-    t0 = time.perf_counter()
-    for t in range(steps):
-        step(t + 2)
-    dt = (time.perf_counter() - t0) / steps
+    dt, steps = _time_cpu(step)
     return {"value": n / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "SNDCGAN ContraD D-step, 32x32, batch %d, %d timed steps after 1 warm-up "
                       "(oracle = PyTorch-CPU restatement of the reference path, %.3f s/step)" % (n, steps, dt)}
 
 
+def cpu_baseline_sg2(name, n):
+    """The oracle's StyleGAN2 discriminator step on the host cores (D forward/backward + losses + R1 + Adam on a fixed
+    synthetic fake batch: the generator forward, ~9 % of the FLOPs, is left out of the CPU sample and said so)."""
+    from oracle import contrad_oracle as O
+    from oracle import stylegan2_oracle as S
+    cfg = CONFIGS[name]
+    size = cfg['size']
+    small32 = cfg['arch'] == 'stylegan2'
+    cm = 2 if small32 else 1
+    torch.manual_seed(0); np.random.seed(0)
+    torch.set_num_threads(_threads())
+    sd = S.det_fill_d(S.d_param_shapes(size, small32, cm))
+    params = [k for k in sd if not k.endswith('kernel')]
+    for k in params:
+        sd[k].requires_grad_()
+    m = {k: torch.zeros_like(sd[k]) for k in params}
+    v = {k: torch.zeros_like(sd[k]) for k in params}
+    x = torch.rand(n, 3, size, size)
+    fake = torch.rand(n, 3, size, size)
+    aug_cfg = O.SIMCLR_CIFAR if name == 'sg2_32' else O.SIMCLR_HQ_AFHQ
+    lr = 2e-3 if small32 else 2.5e-3
+    every = cfg['d_reg_every']
+
+    def step(t):
+        p = O.sample_simclr_params(3 * n, size, size, aug_cfg)
+        aug = O.simclr_apply(torch.cat([x, x, fake]), p)
+        closs, gloss, _, _ = O.contrad_loss_d(lambda z: S.d_forward(sd, z, size, sg_linear=True)[:3], aug, n)
+        loss = closs + gloss
+        if t % every == 0 or name == 'sg2_32':
+            pr = O.sample_simclr_params(n, size, size, aug_cfg)
+            r1 = S.r1_penalty(lambda z: S.d_forward(sd, z, size)[0], O.simclr_apply(x, pr).detach())
+            loss = loss + 0.5 * cfg['lbd_r1'] * r1 * every
+        for k in params:
+            sd[k].grad = None
+        loss.backward()
+        with torch.no_grad():
+            for k in params:
+                O.adam_step(sd[k], sd[k].grad, m[k], v[k], t, lr, 0.0, 0.99)
+
+    dt, steps = _time_cpu(step, max_steps=3)
+    return {"value": n / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%s ContraD D-step (augment + D fwd/bwd + losses%s + Adam; fakes synthetic, G forward not "
+                      "included), %dx%d, batch %d, %d timed steps after 1 warm-up (oracle = PyTorch-CPU restatement, "
+                      "%.3f s/step)" % (cfg['arch'], ' + R1 every step' if name == 'sg2_32' else ', no R1 step in the sample',
+                                        size, size, n, steps, dt)}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _pmc_traffic(config, kernel):
+    """HBM traffic per launch of ``kernel`` from the newest committed rocprofv3 --pmc summary of this config
+    (profiles/rNN_<config>_n1_pmc.json; separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)."""
+    prof = os.path.join(ROOT, 'profiles')
+    cands = []
+    for f in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
+        if f.endswith('_pmc.json') and (('_%s_' % config) in f or (config == 'c10_b512' and '_bench_n1_' in f)):
+            cands.append(f)
+    for f in reversed(cands):
+        try:
+            pmc = json.load(open(os.path.join(prof, f)))
+            ent = pmc.get('kernels', {}).get(kernel)
+            if ent is not None:
+                return ent['traffic_bytes_per_launch'], 'profiles/' + f
+        except (OSError, ValueError, KeyError):
+            pass
+    return None, None
+
+
+def run_config(name, args, world, rank, dev, multi):
+    from contrad_amd import config, ops
+    from contrad_amd.augment import get_augment
+    from contrad_amd.engine import (GradAllReducer, OverlappedGradReducer, d_step, d_step_stylegan2,
+                                    d_step_stylegan2_contrad, set_grad)
+    from contrad_amd.models.gan import get_architecture
+    from contrad_amd.optim import FusedAdam
+    from contrad_amd.training.gan import setup
+
+    cfg = CONFIGS[name]
+    steps = args.steps if args.steps is not None else cfg['steps']
+    warmup = args.warmup if args.warmup is not None else cfg['warmup']
+    batch = args.dev_local_batch or cfg['batch']
+    if cfg['batch_is_global']:
+        assert batch % world == 0
+        n_local, global_batch, scaling = batch // world, batch, 'strong'          # train_gan.py:247
+    else:
+        n_local, global_batch, scaling = batch, batch * world, 'weak'
+    size = cfg['size']
+
+    config.clear_config()
+    config.parse_config_files_and_bindings([os.path.join(config.CONFIG_ROOT, 'defaults', 'gan.gin'),
+                                            os.path.join(config.CONFIG_ROOT, 'defaults', 'augment.gin'),
+                                            os.path.join(config.CONFIG_ROOT, *cfg['gin'])])
+    opt = config.get_bindings('options')
+    torch.manual_seed(0); np.random.seed(0)                   # identical weights on every rank (DDP's broadcast)
+    G, D = get_architecture(cfg['arch'], (size, size, 3))
+    torch.manual_seed(0 + rank); np.random.seed(0 + rank)
+    G, D = G.to(dev).train(), D.to(dev).train()
+    P = argparse.Namespace(mode='contrad', aug=cfg['aug'], temp=0.1, lbd_a=1.0, distributed=multi,
+                           lbd_r1=cfg['lbd_r1'], d_reg_every=max(cfg['d_reg_every'], 1))
+    P = setup(P)
+    P.augment_fn = get_augment(mode=P.aug).to(dev)
+    options = {'loss': opt['loss'], 'batch_size': n_local}
+    opt_D = FusedAdam(D.parameters(), lr=opt['lr'], betas=tuple(opt['beta']))
+    reducer = None
+    if multi:
+        if os.environ.get('CONTRAD_NO_OVERLAP') or not hasattr(D, 'enable_grad_overlap'):
+            reducer = GradAllReducer(D.parameters())          # flat collectives after the backward
+        else:
+            D.enable_grad_overlap(OverlappedGradReducer())      # per-layer collectives hidden behind the backward
+    set_grad(G, False); set_grad(D, True)
+    images = torch.rand(n_local, 3, size, size, device=dev)     # synthetic batch, resident in HBM
+
+    counter = [0]
+    if name == 'c10_b512':
+        def one_step():
+            return d_step(P, G, D, opt_D, options, images, reducer)
+    else:
+        fn = d_step_stylegan2 if name == 'sg2_32' else d_step_stylegan2_contrad
+
+        def one_step():
+            counter[0] += 1
+            return fn(P, G, D, opt_D, options, images, counter[0], reducer)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # Warm-up: every conv-engine launch is bracketed by HIP events (on the launch stream) -> per-kernel table and the
+    # choice of the dominant kernel.  Timed region: only the dominant kernel is bracketed -- an event pair costs
+    # ~10 us of stream time and ~60 of them per step would take 6 % off the number being measured.
+    ops.PROFILE = []
+    marks = [0]
+    for _ in range(warmup):
+        one_step()
+        marks.append(len(ops.PROFILE))
+    torch.cuda.synchronize()
+    warm_prof = ops.PROFILE
+    ops.PROFILE = []
+    wsteps = max(1, warmup // 2)                                     # the later half of the warm-up (clocks ramped)
+    wagg = {}
+    for kname, flops, e0, e1 in warm_prof[marks[max(0, warmup - wsteps)]:]:
+        a = wagg.setdefault(kname, [0.0, 0.0, 0])
+        a[0] += e0.elapsed_time(e1) * 1e-3
+        a[1] += flops
+        a[2] += 1
+    del warm_prof
+    ops.PROFILE_ONLY = max(wagg.items(), key=lambda kv: kv[1][0])[0] if wagg else None
+    # the lazy-R1 schedule: start the timed window right after an R1 step so that K steps contain exactly K // period
+    if cfg['d_reg_every'] > 1:
+        counter[0] = 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        d_loss, aux = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    dom_name, ops.PROFILE_ONLY = ops.PROFILE_ONLY, None
+    if multi:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms = dt / steps * 1e3
+    value = global_batch * steps / dt
+    finite = bool(torch.isfinite(d_loss).item() and torch.isfinite(aux['penalty']).item())
+    peak_mem = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    out = None
+    if rank == 0:
+        # dominant kernel = the conv-engine instance with the largest summed device time (chosen on the warm-up
+        # steps); its launches in the timed region are the `achieved` figure
+        if dom_name is None:                                        # --warmup 0: everything was bracketed
+            tagg = {}
+            for n_, f_, e0, e1 in prof:
+                a = tagg.setdefault(n_, [0.0, 0.0, 0])
+                a[0] += e0.elapsed_time(e1) * 1e-3; a[1] += f_; a[2] += 1
+            dom_name = max(tagg.items(), key=lambda kv: kv[1][0])[0]
+            wagg, wsteps = tagg, steps
+            prof = [q for q in prof if q[0] == dom_name]
+        tsum = sum(e0.elapsed_time(e1) for _, _, e0, e1 in prof) * 1e-3
+        fsum = sum(f for _, f, _, _ in prof)
+        cnt = max(len(prof), 1)
+        achieved = fsum / max(tsum, 1e-12) / 1e12
+        conv_time_per_step = sum(a[0] for a in wagg.values()) / wsteps
+        traffic, traffic_src = _pmc_traffic(name, dom_name) if world == 1 else (None, None)
+        fpi = cfg['flop_per_image']
+        roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic,
+                    "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                    "launches_per_step": cnt / steps, "avg_launch_ms": round(tsum / cnt * 1e3, 4),
+                    "algorithmic_gflop_per_launch": round(fsum / cnt / 1e9, 2),
+                    "bracket": "HIP events around the C-ABI call on its stream" +
+                               (" (igemm WGRAD kernel + its wgrad_reduce_kernel)" if "<2," in dom_name else ""),
+                    "conv_engine_share_of_step": round(conv_time_per_step / (dt / steps), 3),
+                    "all_kernels_warmup": {k: {"tflops": round(v[1] / v[0] / 1e12, 1),
+                                               "ms_per_step": round(v[0] / wsteps * 1e3, 3)}
+                                           for k, v in sorted(wagg.items())},
+                    "step_level": {"achieved": round(value / world * fpi / 1e12, 2),
+                                   "frac": round(value / world * fpi / 1e12 / PEAK_FP32_MFMA, 4),
+                                   "flop_per_image": fpi}}
+        out = {"metric": "discriminator-step images/sec (ContraD, SimCLR aug)", "value": round(value, 1),
+               "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
+               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": cfg['workload'] % batch, "name": name,
+                          "global_batch": global_batch, "per_gpu_batch": n_local,
+                          "parallelism": "dp%d" % world, "losses_finite": finite,
+                          "rccl_ranks": dist.get_world_size() if multi else 1,
+                          "peak_hbm_gib": round(peak_mem, 2)},
+               "roofline": roofline}
+        if cfg['d_reg_every'] > 1:
+            out["config"]["r1_steps_in_window"] = steps // cfg['d_reg_every']
+    # release this workload's memory before the next one
+    del G, D, opt_D, images, P
+    ops._ws_cache.clear()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(dev)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=None, help='timed steps (default: 20 / 10 / 16 for c10_b512 / sg2_32 / sg2_512)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed warm-up steps (default: 5 / 3 / 2)')
+    ap.add_argument('--config', default='all', choices=sorted(CONFIGS) + ['all'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-dist', action='store_true',
                     help='dev: run all collective code paths on a 1-rank RCCL group (single GPU)')
     ap.add_argument('--dev-local-batch', type=int, default=0,
                     help='dev: single-GPU run at this batch (what one rank of an N-GPU job sees); not the headline config')
     args = ap.parse_args()
-    global GLOBAL_BATCH
-    if args.dev_local_batch:
-        GLOBAL_BATCH = args.dev_local_batch
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # self-launch: one process per GPU over RCCL, rendezvous on 127.0.0.1 (the container hostname may not resolve)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('OMP_NUM_THREADS', '4')
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
-                         % (args.gpus, args.gpus))
+        raise SystemExit('bench.py --gpus %d inside a launch of WORLD_SIZE=%d' % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     multi = world > 1 or args.force_dist
@@ -111,139 +385,27 @@ def main():
             import contrad_amd.engine as _eng
             _eng.FORCE_DIST = True
 
-    from contrad_amd import config, ops
-    from contrad_amd.augment import get_augment
-    from contrad_amd.engine import GradAllReducer, OverlappedGradReducer, d_step, set_grad
-    from contrad_amd.models.gan import get_architecture
-    from contrad_amd.optim import FusedAdam
-    from contrad_amd.training.gan import setup
-
-    config.clear_config()
-    config.parse_config_files_and_bindings([os.path.join(config.CONFIG_ROOT, 'defaults', 'gan.gin'),
-                                            os.path.join(config.CONFIG_ROOT, 'defaults', 'augment.gin'),
-                                            os.path.join(config.CONFIG_ROOT, 'gan', 'cifar10', 'c10_b512.gin')])
-    opt = config.get_bindings('options')
-    assert (opt['batch_size'] == GLOBAL_BATCH or args.dev_local_batch) and GLOBAL_BATCH % world == 0
-    n_local = GLOBAL_BATCH // world                          # train_gan.py:247
-
-    torch.manual_seed(0 + rank); np.random.seed(0 + rank)
-    G, D = get_architecture('sndcgan', (32, 32, 3))
-    if world > 1:                                            # identical weights on every rank (DDP's broadcast)
-        torch.manual_seed(0)
-        G, D = get_architecture('sndcgan', (32, 32, 3))
-        torch.manual_seed(0 + rank)
-    G, D = G.to(dev).train(), D.to(dev).train()
-    P = argparse.Namespace(mode='contrad', aug='simclr', temp=0.1, lbd_a=1.0, distributed=multi)
-    P = setup(P)
-    P.augment_fn = get_augment(mode=P.aug).to(dev)
-    options = {'loss': opt['loss'], 'batch_size': n_local}
-    opt_D = FusedAdam(D.parameters(), lr=opt['lr'], betas=tuple(opt['beta']))
-    reducer = None
-    if multi:
-        if os.environ.get('CONTRAD_NO_OVERLAP'):
-            reducer = GradAllReducer(D.parameters())          # two flat collectives after the backward
-        else:
-            D.enable_grad_overlap(OverlappedGradReducer())      # per-layer collectives hidden behind the backward
-    set_grad(G, False); set_grad(D, True)
-    images = torch.rand(n_local, 3, 32, 32, device=dev)      # synthetic CIFAR-shaped batch, resident in HBM
-
-    def barrier():
-        torch.cuda.synchronize()
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # Warm-up: every conv-engine launch is bracketed by HIP events (on the launch stream) -> per-kernel table and the
-    # choice of the dominant kernel.  Timed region: only the dominant kernel is bracketed -- an event pair costs
-    # ~10 us of stream time and ~60 of them per step would take 6 % off the number being measured.
-    ops.PROFILE = []
-    marks = [0]
-    for _ in range(args.warmup):
-        d_step(P, G, D, opt_D, options, images, reducer)
-        marks.append(len(ops.PROFILE))
-    torch.cuda.synchronize()
-    warm_prof = ops.PROFILE
-    ops.PROFILE = []
-    wsteps = max(1, args.warmup // 2)                                # the later half of the warm-up (clocks ramped)
-    wagg = {}
-    for name, flops, e0, e1 in warm_prof[marks[max(0, args.warmup - wsteps)]:]:
-        a = wagg.setdefault(name, [0.0, 0.0, 0])
-        a[0] += e0.elapsed_time(e1) * 1e-3
-        a[1] += flops
-        a[2] += 1
-    ops.PROFILE_ONLY = max(wagg.items(), key=lambda kv: kv[1][0])[0] if wagg else None
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        d_loss, aux = d_step(P, G, D, opt_D, options, images, reducer)
-    barrier()
-    dt = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
-    dom_name, ops.PROFILE_ONLY = ops.PROFILE_ONLY, None
-    if multi:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    ms = dt / args.steps * 1e3
-    value = GLOBAL_BATCH * args.steps / dt
-    finite = bool(torch.isfinite(d_loss).item() and torch.isfinite(aux['penalty']).item())
-
-    if rank == 0:
-        # dominant kernel = the conv-engine instance with the largest summed device time (chosen on the warm-up
-        # steps); its launches in the timed region are the `achieved` figure
-        if dom_name is None:                                        # --warmup 0: everything was bracketed
-            tagg = {}
-            for n_, f_, e0, e1 in prof:
-                a = tagg.setdefault(n_, [0.0, 0.0, 0])
-                a[0] += e0.elapsed_time(e1) * 1e-3; a[1] += f_; a[2] += 1
-            dom_name = max(tagg.items(), key=lambda kv: kv[1][0])[0]
-            wagg, wsteps = tagg, args.steps
-            prof = [q for q in prof if q[0] == dom_name]
-        tsum = sum(e0.elapsed_time(e1) for _, _, e0, e1 in prof) * 1e-3
-        fsum = sum(f for _, f, _, _ in prof)
-        cnt = len(prof)
-        name = dom_name
-        achieved = fsum / tsum / 1e12
-        conv_time_per_step = sum(a[0] for a in wagg.values()) / wsteps
-        # HBM traffic per launch of the dominant kernel: from the committed rocprofv3 --pmc passes of this same
-        # command (profiles/r01_bench_n1_pmc.*; separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)
-        traffic, traffic_src = None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_bench_n1_pmc.json')))
-            ent = pmc.get('kernels', {}).get(name) or (pmc if pmc.get('kernel') == name else None)
-            if ent is not None and world == 1:
-                traffic, traffic_src = ent['traffic_bytes_per_launch'], 'profiles/r01_bench_n1_pmc.json'
-        except (OSError, ValueError, KeyError):
-            pass
-        roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic,
-                    "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                    "launches_per_step": cnt / args.steps, "avg_launch_ms": round(tsum / cnt * 1e3, 4),
-                    "algorithmic_gflop_per_launch": round(fsum / cnt / 1e9, 2),
-                    "bracket": "HIP events around the C-ABI call on its stream" +
-                               (" (igemm WGRAD kernel + its wgrad_reduce_kernel)" if "<2," in name else ""),
-                    "conv_engine_share_of_step": round(conv_time_per_step / (dt / args.steps), 3),
-                    "all_kernels_warmup": {k: {"tflops": round(v[1] / v[0] / 1e12, 1),
-                                               "ms_per_step": round(v[0] / wsteps * 1e3, 3)}
-                                           for k, v in sorted(wagg.items())},
-                    "step_level": {"achieved": round(value / world * FLOP_PER_IMAGE / 1e12, 2),
-                                   "frac": round(value / world * FLOP_PER_IMAGE / 1e12 / PEAK_FP32_MFMA, 4),
-                                   "flop_per_image": FLOP_PER_IMAGE}}
-        out = {"metric": "discriminator-step images/sec (ContraD, SimCLR aug)", "value": round(value, 1),
-               "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "SNDCGAN + ContraD D-step, CIFAR-10 32x32, global batch %d, simclr aug, "
-                                      "nonsat loss, Adam(2e-4,(0.5,0.999)), random-init weights" % GLOBAL_BATCH,
-                          "global_batch": GLOBAL_BATCH, "per_gpu_batch": n_local,
-                          "parallelism": "dp%d" % world, "losses_finite": finite},
-               "roofline": roofline}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+    names = ['c10_b512', 'sg2_32', 'sg2_512'] if args.config == 'all' else [args.config]
+    if args.dev_local_batch:
+        names = names[:1]
+    results = {}
+    for name in names:
+        results[name] = run_config(name, args, world, rank, dev, multi)
     if multi:
         dist.barrier()
         dist.destroy_process_group()             # before the JSON line: nothing RCCL prints can follow or split it
     if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            for name in names:
+                if name == 'c10_b512':
+                    results[name]["cpu_baseline"] = cpu_baseline_c10()
+                elif name == 'sg2_32':
+                    results[name]["cpu_baseline"] = cpu_baseline_sg2(name, 16)
+                else:
+                    results[name]["cpu_baseline"] = cpu_baseline_sg2(name, 2)
+        out = results[names[0]]
+        if len(names) > 1:
+            out["other_configs"] = {n: results[n] for n in names[1:]}
         print(json.dumps(out), flush=True)
 
 

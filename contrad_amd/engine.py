@@ -157,16 +157,13 @@ def d_step_stylegan2(P, G, D, opt_D, options, images, step, reducer=None, style_
     return d_loss, aux
 
 
-def d_step_stylegan2_contrad(P, G, D, opt_D, options, images, step, reducer=None, style_mix=0.9):
-    """D-step of train_stylegan2_contraD.py:148-164,218-226 (BASELINE config 5): the fakes (N) and the two real
-    views (2N) are augmented SEPARATELY and go through D in two calls; losses on the concatenated embeddings
-    (_loss_D_fn, :95-109); lazy R1 on its own D call."""
+def loss_D_fn_separate(P, D, options, images, gen_images):
+    """ContraD discriminator loss with the call structure of train_stylegan2_contraD.py (G_D.forward :138-164 and
+    _loss_D_fn :95-109): the fakes (N) and the two real views (2N) are augmented SEPARATELY and go through D in two
+    calls; the losses act on the concatenated embeddings.  Same return contract as contrad.loss_D_fn."""
     from .training.gan.contrad import _ContraDContrastive, _GanDLoss
     N = images.size(0)
-    THROTTLE.begin()
-    with torch.no_grad():
-        gen_images = G(G.sample_latent(N), style_mix=style_mix)
-    d_gen, aux_g = D(P.augment_fn(gen_images), sg_linear=True, projection=True, projection2=True)
+    d_gen, aux_g = D(P.augment_fn(gen_images.detach()), sg_linear=True, projection=True, projection2=True)
     d_real2, aux_r = D(P.augment_fn(torch.cat([images, images], dim=0)), sg_linear=True, projection=True,
                        projection2=True)
     proj = torch.cat([aux_r['projection'], aux_g['projection']], dim=0)
@@ -174,8 +171,18 @@ def d_step_stylegan2_contrad(P, G, D, opt_D, options, images, step, reducer=None
     d_all = torch.cat([d_real2, d_gen], dim=0)
     simclr, sup = _ContraDContrastive.apply(proj, proj2, N, P.temp, bool(P.distributed))
     gan, d_real_m, d_gen_m = _GanDLoss.apply(d_all, N, options['loss'])
-    loss = simclr + P.lbd_a * sup + gan
-    aux = {'penalty': gan, 'd_real': d_real_m, 'd_gen': d_gen_m}
+    return simclr + P.lbd_a * sup, {'penalty': gan, 'd_real': d_real_m, 'd_gen': d_gen_m}
+
+
+def d_step_stylegan2_contrad(P, G, D, opt_D, options, images, step, reducer=None, style_mix=0.9):
+    """D-step of train_stylegan2_contraD.py:148-164,218-226 (BASELINE config 5): loss_D_fn_separate + lazy R1 on
+    its own D call."""
+    N = images.size(0)
+    THROTTLE.begin()
+    with torch.no_grad():
+        gen_images = G(G.sample_latent(N), style_mix=style_mix)
+    d_loss, aux = loss_D_fn_separate(P, D, options, images, gen_images)
+    loss = d_loss + aux['penalty']
     if (step % P.d_reg_every == 0) and P.lbd_r1 > 0:
         r1 = r1_loss(D, images, P.augment_fn)
         loss = loss + (0.5 * P.lbd_r1) * r1 * P.d_reg_every
@@ -185,4 +192,4 @@ def d_step_stylegan2_contrad(P, G, D, opt_D, options, images, step, reducer=None
     world = reducer() if reducer is not None else 1
     opt_D.step(grad_scale=1.0 / world) if world > 1 else opt_D.step()
     THROTTLE.end()
-    return simclr + P.lbd_a * sup, aux
+    return d_loss, aux

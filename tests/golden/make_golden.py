@@ -507,8 +507,132 @@ def gen_stylegan2_g():
     save('stylegan2_g', **out)
 
 
+# ------------------------------------------------------------------------------------------------
+def seeded_rand(shape, seed):
+    """Inputs too large to commit are regenerated from a CPU-generator seed on both sides (torch's CPU mt19937
+    stream is machine-independent); a float64 checksum travels with the fixture."""
+    return torch.rand(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def seeded_images(n, size, seed):
+    """Distinct smooth synthetic 'photos' in [0,1]: a per-sample random 6x6 colour field, bilinearly upsampled, plus
+    10 % pixel noise (i.i.d. uniform noise alone gives every image the same statistics -> collapsed embeddings, a
+    parity test that could not see most bugs).  Same rule in tests/ (sg2_inputs.py)."""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.rand(n, 3, 6, 6, generator=g)
+    img = F.interpolate(base, size=(size, size), mode='bilinear', align_corners=False)
+    return (0.9 * img + 0.1 * torch.rand(n, 3, size, size, generator=g)).clamp_(0, 1)
+
+
+def gen_stylegan2_512():
+    """BASELINE config 5 at full resolution: ResidualDiscriminatorP(512, channel_multiplier=1) driven with the call
+    sequence of train_stylegan2_contraD.py:129-164 (G_D.forward: fakes (N) and the two real views (2N) in SEPARATE
+    D calls, _loss_D_fn :95-109, lazy R1 :129-136,222-226), N = 2; and Generator(512) forward with explicit noise."""
+    from oracle import stylegan2_oracle as S
+    from models.gan import get_architecture
+    from training.criterion import nt_xent
+    from training.gan.contrad import supcon_fake
+    torch.manual_seed(0)
+    G, D = get_architecture('stylegan2_512', (512, 512, 3))
+    D.train(); G.train()
+    shapes = S.d_param_shapes(512, False, 1.0)
+    assert {k: tuple(v.shape) for k, v in D.state_dict().items()} == shapes
+    assert list(D.state_dict()) == list(shapes)
+    sd = S.det_fill_d(shapes, seed=512)
+    D.load_state_dict({k: v.clone() for k, v in sd.items()})
+    N, T, lbd_a, lbd_r1, every = 2, 0.1, 1.0, 0.5, 16
+    aug_f = seeded_images(N, 512, 9001)         # stands for augment(G(z))
+    aug_r = seeded_images(2 * N, 512, 9002)     # stands for augment(cat[x, x])
+    aug_r1 = seeded_images(N, 512, 9003)        # stands for augment(x) inside the R1 branch
+
+    def contrad_512(dfwd, r1fn):
+        d_gen, pf, p2f = dfwd(aug_f)
+        d_rs, pr, p2r = dfwd(aug_r)
+        views_r, reals = F.normalize(pr), F.normalize(p2r)
+        others, fakes = F.normalize(pf), F.normalize(p2f)
+        simclr = nt_xent(views_r[:N], views_r[N:], temperature=T)
+        sup = supcon_fake(reals[:N], reals[N:], fakes, temperature=T)
+        d_real = d_rs[:N]
+        gan = F.softplus(d_gen).mean() + F.softplus(-d_real).mean()
+        r1 = r1fn()
+        return simclr, sup, gan, r1, (d_gen, d_rs, pf, p2f, pr, p2r)
+
+    def ref_fwd(t):
+        o, a = D(t, sg_linear=True, projection=True, projection2=True)
+        return o, a['projection'], a['projection2']
+
+    keep = {}
+
+    def ref_r1():
+        xa = aug_r1.detach().clone().requires_grad_()
+        d_real = D(xa)
+        grad_real, = torch.autograd.grad(outputs=d_real.sum(), inputs=xa, create_graph=True, retain_graph=True)
+        keep['d_r1'], keep['grad_real'] = d_real.detach(), grad_real.detach()
+        return grad_real.pow(2).reshape(N, -1).sum(1).mean()
+
+    D.zero_grad()
+    simclr, sup, gan, r1, outs = contrad_512(ref_fwd, ref_r1)
+    loss = simclr + lbd_a * sup + gan + (0.5 * lbd_r1) * r1 * every
+    loss.backward()
+    ref_grads = {k: v.grad.clone() for k, v in D.named_parameters()}
+    print('  sg2-512 reference: simclr %.5f sup %.5f gan %.5f r1 %.5e' % (simclr.item(), sup.item(), gan.item(), r1.item()))
+
+    osd = {k: v.clone() for k, v in sd.items()}
+    for k in osd:
+        if not k.endswith('kernel'):
+            osd[k].requires_grad_()
+    o_simclr, o_sup, o_gan, o_r1, _ = contrad_512(lambda t: S.d_forward(osd, t, 512, sg_linear=True)[:3],
+                                                  lambda: S.r1_penalty(lambda t: S.d_forward(osd, t, 512)[0], aug_r1))
+    (o_simclr + lbd_a * o_sup + o_gan + (0.5 * lbd_r1) * o_r1 * every).backward()
+    check(o_simclr, simclr, 1e-6, '512 simclr'); check(o_sup, sup, 1e-6, '512 sup')
+    check(o_gan, gan, 1e-6, '512 gan'); check(o_r1, r1, 1e-5, '512 r1')
+    gerr = 0.0
+    for k, gref in ref_grads.items():
+        gerr = max(gerr, check(osd[k].grad, gref, 5e-5, '512 grad ' + k))
+    print('  stylegan2-512 D: max grad err oracle vs reference %.2e' % gerr)
+    d_gen, d_rs, pf, p2f, pr, p2r = [t.detach() for t in outs]
+    out = {'N': N, 'seed_f': 9001, 'seed_r': 9002, 'seed_r1': 9003, 'wseed': 512,
+           'sum_f': aug_f.double().sum(), 'sum_r': aug_r.double().sum(), 'sum_r1': aug_r1.double().sum(),
+           'd_gen': d_gen, 'd_rs': d_rs, 'proj_f': pf, 'proj2_f': p2f, 'proj_r': pr, 'proj2_r': p2r,
+           'simclr': simclr, 'sup': sup, 'gan': gan, 'r1': r1, 'd_r1_logits': keep['d_r1'],
+           'grad_real_norm': keep['grad_real'].norm(), 'grad_real_head': keep['grad_real'].reshape(N, -1)[:, :256]}
+    for k, gref in ref_grads.items():
+        out['gradnorm/' + k] = gref.norm()
+        out['gradhead/' + k] = gref.reshape(-1)[:256]
+    save('stylegan2_512_d', **out)
+
+    # ---- Generator(512, channel_multiplier=1) forward, explicit noise, with and without style mixing ----
+    gshapes = {k: tuple(v.shape) for k, v in G.state_dict().items()}
+    assert gshapes == S.g_param_shapes(512, False, 1.0) and list(gshapes) == list(S.g_param_shapes(512, False, 1.0))
+    gsd = S.fill_kernels(S.det_fill_g(gshapes, seed=778), gshapes)
+    G.load_state_dict({k: v.clone() for k, v in gsd.items()})
+    B = 2
+    g = torch.Generator().manual_seed(43)
+    z = torch.randn(B, 512, generator=g)
+    nseed = 9100
+    noise = [torch.randn(B, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), generator=torch.Generator().manual_seed(nseed + i))
+             for i in range(G.num_layers)]
+    with torch.no_grad():
+        img0 = G(z, style_mix=0.0, noise=noise)
+        check(S.g_forward(gsd, z, 512, noise), img0, 1e-5, 'G512 forward')
+        # style mixing: reproduce the reference's CPU draws (randn, rand, randint in that order, generator.py:252-259)
+        for mseed in range(100):           # a seed whose draws mix one sample and leave the other alone
+            torch.manual_seed(mseed)
+            z_mix = torch.randn(B, 512)
+            nomix = torch.rand(B) >= 0.9
+            mix_layer = torch.randint(G.n_latent, (B,)).masked_fill(nomix, G.n_latent)
+            if nomix.sum().item() == 1:
+                break
+        torch.manual_seed(mseed)
+        img1 = G(z, style_mix=0.9, noise=noise)
+        check(S.g_forward(gsd, z, 512, noise, mix=(z_mix, mix_layer)), img1, 1e-5, 'G512 forward (mixing)')
+    save('stylegan2_512_g', z=z, z_mix=z_mix, mix_layer=mix_layer, nseed=nseed, wseed=778,
+         img0_sub=img0[:, :, ::32, ::32], img1_sub=img1[:, :, ::32, ::32],
+         img0_rowsum=img0.double().sum(3), img1_rowsum=img1.double().sum(3), img0_patch=img0[:, :, 200:232, 300:332])
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['losses', 'augment', 'sndcgan', 'sndcgan_gstep', 'adam', 'stylegan2', 'stylegan2_g']
+    which = sys.argv[1:] or ['losses', 'augment', 'sndcgan', 'sndcgan_gstep', 'adam', 'stylegan2', 'stylegan2_g', 'stylegan2_512']
     for w in which:
         globals()['gen_' + w]()
     print('golden vectors OK')

@@ -1,0 +1,209 @@
+"""BASELINE config 5 (StyleGAN2_512 + ContraD, 512x512) and full-size config 4 on the device: reference-generated
+goldens at N = 2 (tests/golden/make_golden.py::gen_stylegan2_512 -- ResidualDiscriminatorP(512, channel_multiplier=1)
+driven with train_stylegan2_contraD.py's call sequence, and Generator(512) with explicit noise), plus size-independent
+properties at the BASELINE sizes (N = 16 at 512^2, N = 64 + R1 every step at 32^2): finite, bitwise deterministic,
+adjoint identities of the 512^2 layer shapes."""
+import argparse
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from contrad_amd import autograd_ops as A
+from contrad_amd import ops
+from contrad_amd.engine import (d_step_stylegan2, d_step_stylegan2_contrad, loss_D_fn_separate, r1_loss, set_grad)
+from contrad_amd.models.gan import get_architecture
+from contrad_amd.optim import FusedAdam
+from oracle import stylegan2_oracle as S
+from sg2_inputs import seeded_images
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+DEV = 'cuda'
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def l2(a, b):
+    a, b = torch.as_tensor(a).double().cpu().reshape(-1), torch.as_tensor(b).double().cpu().reshape(-1)
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+class _P(object):
+    temp, lbd_a, distributed = 0.1, 1.0, False
+
+
+def test_discriminator_512_contrad_step_against_reference(golden):
+    g = golden('stylegan2_512_d')
+    N = int(g['N'])
+    G, D = get_architecture('stylegan2_512', (512, 512, 3))
+    shapes = S.d_param_shapes(512, False, 1.0)
+    assert {k: tuple(v.shape) for k, v in D.state_dict().items()} == shapes and list(D.state_dict()) == list(shapes)
+    D.load_state_dict(S.det_fill_d(shapes, seed=int(g['wseed'])))
+    D = D.to(DEV).train()
+    aug_f = seeded_images(N, 512, int(g['seed_f']))
+    aug_r = seeded_images(2 * N, 512, int(g['seed_r']))
+    aug_r1 = seeded_images(N, 512, int(g['seed_r1']))
+    for t, key in ((aug_f, 'sum_f'), (aug_r, 'sum_r'), (aug_r1, 'sum_r1')):      # same inputs as the generator run
+        assert abs(t.double().sum().item() - float(g[key])) < 1e-6 * float(g[key])
+    aug_f, aug_r, aug_r1 = aug_f.to(DEV), aug_r.to(DEV), aug_r1.to(DEV)
+
+    # forward values of the two separate calls
+    with torch.no_grad():
+        d_gen, af = D(aug_f, sg_linear=True, projection=True, projection2=True)
+        d_rs, ar = D(aug_r, sg_linear=True, projection=True, projection2=True)
+    assert rel(d_gen, g['d_gen']) < TOL and rel(d_rs, g['d_rs']) < TOL
+    assert rel(af['projection'], g['proj_f']) < TOL and rel(af['projection2'], g['proj2_f']) < TOL
+    assert rel(ar['projection'], g['proj_r']) < TOL and rel(ar['projection2'], g['proj2_r']) < TOL
+
+    # the step: train_stylegan2_contraD.py semantics with the augmentation outputs injected
+    P = _P()
+    calls = []
+
+    def augment_fn(t):
+        calls.append(t.shape[0])
+        if t.shape[0] == 2 * N:
+            return aug_r
+        return aug_f if len([c for c in calls if c == N]) == 1 else aug_r1
+    P.augment_fn = augment_fn
+    P.lbd_r1, P.d_reg_every = 0.5, 16
+    x = torch.rand(N, 3, 512, 512, device=DEV)
+    d_loss, aux = loss_D_fn_separate(P, D, {'loss': 'nonsat'}, x, torch.rand(N, 3, 512, 512, device=DEV))
+    r1 = r1_loss(D, x, P.augment_fn)
+    assert calls == [N, 2 * N, N]
+    loss = d_loss + aux['penalty'] + (0.5 * P.lbd_r1) * r1 * P.d_reg_every
+    D.zero_grad()
+    loss.backward()
+    want = float(g['simclr']) + float(g['sup'])
+    assert abs(d_loss.item() - want) < TOL * abs(want)
+    assert abs(aux['penalty'].item() - float(g['gan'])) < TOL * float(g['gan'])
+    assert abs(r1.item() - float(g['r1'])) < 5e-3 * float(g['r1'])
+    grads = {k: p.grad for k, p in D.named_parameters()}
+    worst = 0.0
+    for k in g.files:
+        if k.startswith('gradnorm/'):
+            name = k[len('gradnorm/'):]
+            ref = float(g[k])
+            e = abs(grads[name].norm().item() - ref) / max(ref, 1e-30)
+            worst = max(worst, e)
+            assert e < 5e-3, (name, e)
+        elif k.startswith('gradhead/'):
+            name = k[len('gradhead/'):]
+            ref = torch.from_numpy(g[k])
+            got = grads[name].reshape(-1)[:ref.numel()].cpu()
+            scale = float(g['gradnorm/' + name]) / np.sqrt(grads[name].numel())      # rms of the full gradient
+            assert (got - ref).abs().max().item() < 3e-2 * max(ref.abs().max().item(), scale), name
+
+
+def test_generator_512_forward_against_reference(golden):
+    g = golden('stylegan2_512_g')
+    G, _ = get_architecture('stylegan2_512', (512, 512, 3))
+    shapes = S.g_param_shapes(512, False, 1.0)
+    assert {k: tuple(v.shape) for k, v in G.state_dict().items()} == shapes
+    G.load_state_dict(S.fill_kernels(S.det_fill_g(shapes, seed=int(g['wseed'])), shapes))
+    G = G.to(DEV).train()
+    z = torch.from_numpy(g['z']).to(DEV)
+    B = z.shape[0]
+    nseed = int(g['nseed'])
+    noise = [torch.randn(B, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2),
+                         generator=torch.Generator().manual_seed(nseed + i)).to(DEV) for i in range(G.num_layers)]
+    with torch.no_grad():
+        img0 = G(z, style_mix=0.0, noise=noise)
+        img1 = G(z, style_mix=0.9, noise=noise, _mix=(torch.from_numpy(g['z_mix']).to(DEV),
+                                                      torch.from_numpy(g['mix_layer'])))
+    assert img0.shape == (B, 3, 512, 512)
+    assert rel(img0[:, :, ::32, ::32], g['img0_sub']) < TOL and rel(img1[:, :, ::32, ::32], g['img1_sub']) < TOL
+    assert rel(img0[:, :, 200:232, 300:332], g['img0_patch']) < TOL
+    assert rel(img0.double().sum(3), g['img0_rowsum']) < TOL and rel(img1.double().sum(3), g['img1_rowsum']) < TOL
+
+
+def _setup(arch, size, N, aug_kwargs, lbd_r1, every, lr):
+    from contrad_amd.augment import SimCLRAugment
+    from contrad_amd.training.gan import setup
+    torch.manual_seed(0); np.random.seed(0)
+    G, D = get_architecture(arch, (size, size, 3))
+    G, D = G.to(DEV).train(), D.to(DEV).train()
+    P = setup(argparse.Namespace(mode='contrad', aug='x', temp=0.1, lbd_a=1.0, distributed=False, lbd_r1=lbd_r1,
+                                 d_reg_every=every))
+    P.augment_fn = SimCLRAugment(**aug_kwargs)
+    set_grad(G, False)
+    x = seeded_images(N, size, 5).to(DEV)
+    return G, D, P, x, lr
+
+
+def _two_identical_runs(fn, G, D, P, x, lr, step):
+    outs = []
+    for _ in range(2):
+        Dc = copy.deepcopy(D)
+        opt = FusedAdam(Dc.parameters(), lr=lr, betas=(0.0, 0.99))
+        torch.manual_seed(123); np.random.seed(123)
+        torch.cuda.manual_seed(123)
+        d_loss, aux = fn(P, G, Dc, opt, {'loss': 'nonsat'}, x, step)
+        torch.cuda.synchronize()
+        outs.append((d_loss.detach().clone(), aux, [p.grad.clone() for p in Dc.parameters()],
+                     [p.detach().clone() for p in Dc.parameters()]))
+    return outs
+
+
+def test_config5_full_size_step_is_finite_and_deterministic():
+    """StyleGAN2_512, N = 16, simclr_hq, one plain step and one lazy-R1 step (step 16)."""
+    hq = dict(scale=(0.08, 1.0), brightness=0.8, contrast=0.8, saturation=0.8, hue=0.2, p_blur=0.5,
+              sigma_range=(0.1, 2.0))
+    G, D, P, x, lr = _setup('stylegan2_512', 512, 16, hq, 0.5, 16, 2.5e-3)
+    for step in (1, 16):
+        a, b = _two_identical_runs(d_step_stylegan2_contrad, G, D, P, x, lr, step)
+        assert torch.isfinite(a[0]) and torch.isfinite(a[1]['penalty'])
+        assert ('r1' in a[1]) == (step == 16)
+        if step == 16:
+            assert torch.isfinite(a[1]['r1']) and a[1]['r1'].item() > 0
+        assert torch.equal(a[0], b[0])
+        for ga, gb in zip(a[2], b[2]):
+            assert torch.isfinite(ga).all() and torch.equal(ga, gb)
+        for pa, pb, p0 in zip(a[3], b[3], D.parameters()):
+            assert torch.equal(pa, pb)
+        assert any(not torch.equal(pa, p0) for pa, p0 in zip(a[3], D.parameters()))
+    assert torch.cuda.max_memory_allocated() < 80 * 2 ** 30
+
+
+def test_config4_full_size_step_is_finite_and_deterministic():
+    """StyleGAN2 small32, N = 64, simclr, R1 every step (--no_lazy)."""
+    G, D, P, x, lr = _setup('stylegan2', 32, 64, dict(scale=(0.2, 1.0)), 0.1, 1, 2e-3)
+    a, b = _two_identical_runs(d_step_stylegan2, G, D, P, x, lr, 1)
+    assert torch.isfinite(a[0]) and torch.isfinite(a[1]['penalty']) and torch.isfinite(a[1]['r1'])
+    assert torch.equal(a[0], b[0])
+    for ga, gb in zip(a[2], b[2]):
+        assert torch.isfinite(ga).all() and torch.equal(ga, gb)
+    for pa, pb in zip(a[3], b[3]):
+        assert torch.equal(pa, pb)
+
+
+@pytest.mark.parametrize('shape', [
+    # (N, H, W, Cin, Cout, k, stride, pad): layer shapes of ResidualDiscriminatorP(512, channel_multiplier=1)
+    (4, 512, 512, 32, 32, 3, 1, 1),       # conv1 at 512^2 (128x32 tile)
+    (4, 515, 515, 32, 64, 3, 2, 0),       # conv2 on the blurred (pad 2,2) map: odd size, stride 2
+    (4, 256, 256, 32, 64, 1, 1, 0),       # skip 1x1 on the blurred + decimated map
+    (4, 259, 259, 64, 128, 3, 2, 0),
+    (8, 67, 67, 256, 512, 3, 2, 0),
+    (16, 4, 4, 516, 512, 3, 1, 1),        # last_conv (513 channels padded to 516)
+])
+def test_adjoint_identities_of_the_512_layer_shapes(shape):
+    """<conv(x), g> == <x, dgrad(g)> == <W, wgrad(x, g)> on the kernels the 512^2 model selects."""
+    N, H, W, C, K, k, s, p = shape
+    gen = torch.Generator(device=DEV).manual_seed(C * 7 + H)
+    x = torch.randn(N, H, W, C, device=DEV, generator=gen)
+    w = torch.randn(K, C, k, k, device=DEV, generator=gen) / np.sqrt(C * k * k)
+    wp = ops.pack_weight(w.cpu()).to(DEV)
+    y = ops.conv2d_fwd(x, wp, None, K, k, k, s, p)
+    gy = torch.randn(y.shape, device=DEV, generator=gen)
+    dx = ops.conv2d_dgrad(gy, wp, tuple(x.shape), k, k, s, p)
+    dw = ops.conv2d_wgrad(x, gy, k, k, s, p, ldw=wp.shape[1])
+    a = (y.double() * gy.double()).sum().item()
+    b = (x.double() * dx.double()).sum().item()
+    c = (wp.double() * dw.double()).sum().item()
+    # |a| ~ sqrt(#terms) * rms(y) * rms(gy); fp32 accumulation noise is ~1e-6 of that, a wrong tap / stride is O(1) of it
+    tol = 1e-4 * abs(a) + 2e-5 * np.sqrt(y.numel()) * y.double().pow(2).mean().sqrt().item()
+    assert abs(a - b) < tol and abs(a - c) < tol, (a, b, c, tol)
