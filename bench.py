@@ -73,6 +73,8 @@ def _time_cpu(step, budget_s=20.0, max_steps=5):
     t0 = time.perf_counter()
     step(1)
     warm = time.perf_counter() - t0
+    if warm > budget_s:                    # one step already exceeds the sample budget: it IS the sample
+        return warm, 1
     steps = max(1, min(max_steps, int(budget_s / max(warm, 1e-3))))      # bound the sample to ~20 s of CPU work
     t0 = time.perf_counter()
     for t in range(steps):
@@ -136,10 +138,23 @@ def cpu_baseline_sg2(name, n):
     lr = 2e-3 if small32 else 2.5e-3
     every = cfg['d_reg_every']
 
+    def d3(z):
+        if name == 'sg2_32':                   # train_stylegan2.py: one 3N call
+            return S.d_forward(sd, z, size, sg_linear=True)[:3]
+        # train_stylegan2_contraD.py: the two real views (2N) and the fakes (N) in separate calls (the minibatch-stddev
+        # groups then live inside each call); outputs re-assembled in [view1, view2, fakes] order
+        r = S.d_forward(sd, z[:2 * n], size, sg_linear=True)[:3]
+        f = S.d_forward(sd, z[2 * n:], size, sg_linear=True)[:3]
+        return tuple(torch.cat([a, b]) for a, b in zip(r, f))
+
     def step(t):
-        p = O.sample_simclr_params(3 * n, size, size, aug_cfg)
-        aug = O.simclr_apply(torch.cat([x, x, fake]), p)
-        closs, gloss, _, _ = O.contrad_loss_d(lambda z: S.d_forward(sd, z, size, sg_linear=True)[:3], aug, n)
+        if name == 'sg2_32':
+            aug = O.simclr_apply(torch.cat([x, x, fake]), O.sample_simclr_params(3 * n, size, size, aug_cfg))
+        else:
+            aug_f = O.simclr_apply(fake, O.sample_simclr_params(n, size, size, aug_cfg))
+            aug_r = O.simclr_apply(torch.cat([x, x]), O.sample_simclr_params(2 * n, size, size, aug_cfg))
+            aug = torch.cat([aug_r, aug_f])
+        closs, gloss, _, _ = O.contrad_loss_d(d3, aug, n)
         loss = closs + gloss
         if t % every == 0 or name == 'sg2_32':
             pr = O.sample_simclr_params(n, size, size, aug_cfg)

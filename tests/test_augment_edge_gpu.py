@@ -38,8 +38,10 @@ def test_flip_and_identity_crop_are_bit_exact(size):
     for i in range(B):
         want = x[i] if sign[i] > 0 else x[i].flip(-1)
         assert torch.equal(out[i], want), (size, i)
-    # the oracle's two grid_samples agree bit for bit as well (the permutation is exact on both sides)
-    assert torch.equal(out, O.hflip(O.resized_crop(x, torch.eye(2, 3).repeat(B, 1, 1)), sign))
+    # the oracle's two grid_samples: bit for bit at the CIFAR size (SURVEY.md 8a row A2's probe), round-off elsewhere
+    # (ATen builds its base grid with linspace; the kernel's closed form stays exact at every power-of-two size)
+    ref = O.hflip(O.resized_crop(x, torch.eye(2, 3).repeat(B, 1, 1)), sign)
+    assert torch.equal(out, ref) if size == 32 else (out - ref).abs().max().item() < 1e-4 * size / 32
 
 
 @pytest.mark.parametrize('tag', ['c10a', 'c10b'])
@@ -96,7 +98,8 @@ def test_contrast_and_gray_fixtures_through_the_kernel(golden, rep):
     one, zero = torch.ones(B), torch.zeros(B)
     want = O.adjust_hsv(con, zero, one, one)                      # pinned to the reference by hsv_roundtrip / hsv_adjusted
     assert (out - want).abs().max().item() < 1e-5
-    assert (out - con).abs().max().item() < 1e-4                    # and the round trip itself is ~identity
+    # (the atan2 "circular" hue is not the hexagonal one: the round trip moves values by up to ~2e-2, as in the reference)
+    assert (want - con).abs().max().item() > 1e-3 and (out - con).abs().max().item() < 5e-2
     # RandomColorGrayLayer
     out = _run(x, _params(B, gray=torch.ones(B)))
     assert (out - gray).abs().max().item() < 1e-6
