@@ -33,20 +33,32 @@ def _jitter_range(value, center=1.0, clip_first_on_zero=True):
 
 class _SimCLRFn(torch.autograd.Function):
     """Differentiable (w.r.t. the images) fused augmentation for the generator step: gradient flows through the
-    bilinear crop/flip gather, the contrast stage and -- as an identity, like RandomHSVFunction.backward
-    (augment/color_jitter.py:97-104) -- through the HSV jitter."""
+    bilinear crop/flip gather, the contrast stage, -- as an identity, like RandomHSVFunction.backward
+    (augment/color_jitter.py:97-104) -- through the HSV jitter, and through the masked Gaussian blur of simclr_hq
+    (its reflect-padding transpose)."""
 
     @staticmethod
-    def forward(ctx, x, Pd, contrast_first, has_contrast):
-        ctx.save_for_backward(x, Pd)
-        ctx.cfg = (contrast_first, has_contrast)
-        return ops.simclr_augment(x, Pd, contrast_first, has_contrast)
+    def forward(ctx, x, Pd, contrast_first, has_contrast, blur):
+        out = ops.simclr_augment(x, Pd, contrast_first, has_contrast)
+        if blur is not None:
+            radius, g = blur
+            out = ops.gaussian_blur_masked(out, Pd, g, radius)
+            ctx.save_for_backward(x, Pd, g)
+        else:
+            ctx.save_for_backward(x, Pd)
+        ctx.cfg = (contrast_first, has_contrast, None if blur is None else blur[0])
+        return out
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g):
-        x, Pd = ctx.saved_tensors
-        cf, hc = ctx.cfg
-        return ops.simclr_augment_bwd(x, Pd, g, cf, hc), None, None, None
+        cf, hc, radius = ctx.cfg
+        if radius is not None:
+            x, Pd, gk = ctx.saved_tensors
+            g = ops.gaussian_blur_masked_bwd(g, Pd, gk, radius)
+        else:
+            x, Pd = ctx.saved_tensors
+        return ops.simclr_augment_bwd(x, Pd, g, cf, hc), None, None, None, None
 
 
 class SimCLRAugment(nn.Module):
@@ -131,9 +143,12 @@ class SimCLRAugment(nn.Module):
         """Deterministic device part."""
         Pd = upload(P, inputs.device)      # (B,12) parameter block (asynchronous pinned upload, contrad_amd/hostio.py)
         if inputs.requires_grad and torch.is_grad_enabled():
+            blur = None
             if sigma is not None:
-                raise NotImplementedError('backward through simclr_hq (large images / blur) is scope row N2')
-            return _SimCLRFn.apply(inputs.contiguous().float(), Pd, contrast_first, self.r_c is not None)
+                radius, g = self.blur_kernel(inputs.shape[2], sigma)
+                if radius > 0:
+                    blur = (radius, g.to(inputs.device))
+            return _SimCLRFn.apply(inputs.contiguous().float(), Pd, contrast_first, self.r_c is not None, blur)
         x = inputs.detach().contiguous().float()
         out = ops.simclr_augment(x, Pd, contrast_first, self.r_c is not None)
         if sigma is not None:

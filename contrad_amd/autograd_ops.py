@@ -390,6 +390,53 @@ class UnpackWeightsFn(Function):
         return (None, None) + tuple(outs)
 
 
+# ----------------------------------------------------------------------------------------------------------
+# modulated-convolution pieces of the StyleGAN2 generator (first-order backward: the generator step never needs
+# a double backward -- R1 differentiates the discriminator w.r.t. its input images only)
+# ----------------------------------------------------------------------------------------------------------
+class NhwcScaleFn(Function):
+    """y[n,h,w,c] = x[n,h,w,c] * s[n,c]  (weight modulation moved onto the activations, generator.py:52-60)."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        x, s = _cont(x), _cont(s)
+        ctx.save_for_backward(x, s)
+        return ops.nhwc_scale(x, s)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, s = ctx.saved_tensors
+        g = _cont(g)
+        gx = ops.nhwc_scale(g, s) if ctx.needs_input_grad[0] else None
+        gs = ops.nhwc_dot(g, x) if ctx.needs_input_grad[1] else None
+        return gx, gs
+
+
+class ModconvEpilogueFn(Function):
+    """out = sqrt2 * lrelu_0.2(y * demod[n,k] + noise_w * noise[n,h,w] + bias[k]): demodulation (generator.py:62-64),
+    NoiseInjection (:85-94) and FusedLeakyReLU (:113-118) in one pass; the backward returns the gradients of the conv
+    output, the demodulation factors, the noise strength and the bias."""
+
+    @staticmethod
+    def forward(ctx, y, demod, noise, noise_w, bias):
+        y, demod, noise = _cont(y), _cont(demod), _cont(noise)
+        out = ops.modconv_epilogue_(y, demod, noise, noise_w, bias, out=torch.empty_like(y))
+        ctx.save_for_backward(y, demod, noise, out)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        y, demod, noise, out = ctx.saved_tensors
+        g_pre = ops.fused_bias_act(_cont(g), None, out, 3, 1, 0.2, SQRT2)
+        gy = ops.nhwc_scale(g_pre, demod) if ctx.needs_input_grad[0] else None
+        gdemod = ops.nhwc_dot(g_pre, y) if ctx.needs_input_grad[1] else None
+        gnw = ops.nhwc_dot(g_pre, noise, per_channel=False).sum().reshape(1) if ctx.needs_input_grad[3] else None
+        gb = ops.colstats(g_pre.view(-1, g_pre.shape[-1]))[0] if ctx.needs_input_grad[4] else None
+        return gy, gdemod, None, gnw, gb
+
+
 def make_blur_kernel(k=(1, 3, 3, 1)):
     """make_kernel (stylegan2/layers.py:24-32)."""
     k = torch.tensor(k, dtype=torch.float32)

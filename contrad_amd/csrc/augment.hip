@@ -386,6 +386,182 @@ __global__ __launch_bounds__(256) void blur_v_kernel(const float* __restrict__ t
   }
 }
 
+// ---------------- backward of the large-image pipeline (generator step at AFHQ size) ----------------
+// Same mathematics as simclr_small_bwd_kernel, spread over four launches because nothing fits LDS:
+//   (stats pass of the forward: channel means of the contrast input)
+//   gm pass      : recompute the forward per pixel, gray backward, clamp mask -> GM, partial channel sums of GM
+//   gather^T (x) : T[i][x]  = sum_j  G'[i][j] Wx[j][x],   G' = fc*GM + (1-fc)*mean(GM)  (contrast backward)
+//   gather^T (y) : dX[y][x] = sum_i  Wy[i][y] T[i][x]
+// The crop+flip gather is an axis-aligned affine grid, so Wx / Wy have <= 2 entries per row and the rows that touch a
+// given source column form a short contiguous run: each thread inverts the affine map for its run (deterministic,
+// no atomics).
+struct Axis { int p0, p1; float w0, w1; bool v0, v1; };
+__device__ __forceinline__ Axis axis_sample(float scale, float bias, int idx, int size) {
+  const float n = (2.f * idx + 1.f) / (float)size - 1.f;
+  const float g = scale * n + bias;
+  float c = ((g + 1.f) * (float)size - 1.f) * 0.5f;
+  c = reflect_coord(c, size);
+  Axis a;
+  const float f = floorf(c);
+  a.p0 = (int)f; a.p1 = a.p0 + 1;
+  a.w1 = c - f; a.w0 = 1.f - a.w1;
+  a.v0 = (unsigned)a.p0 < (unsigned)size; a.v1 = (unsigned)a.p1 < (unsigned)size;
+  return a;
+}
+// candidate output indices whose (unclamped) source coordinate lies within (src-1, src+1), widened by 2
+__device__ __forceinline__ void axis_inverse_range(float scale, float bias, int src, int size, int& lo, int& hi) {
+  if (!(scale > 1e-6f)) { lo = 0; hi = size - 1; return; }
+  const float c0 = scale * 0.5f + (float)size * (bias + 1.f - scale) * 0.5f - 0.5f;
+  lo = (int)floorf(((float)src - 1.f - c0) / scale) - 2;
+  hi = (int)ceilf(((float)src + 1.f - c0) / scale) + 2;
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > size - 1 ? size - 1 : hi;
+}
+
+__global__ __launch_bounds__(256) void simclr_bwd_gm_kernel(AugArgs a, const float* __restrict__ gout,
+                                                            const float* __restrict__ partial, int nparts,
+                                                            float* __restrict__ GM, float* __restrict__ partial2) {
+  __shared__ float mean[3];
+  __shared__ float red[16];
+  const int n = blockIdx.x;
+  const int HW = a.H * a.W;
+  const float* pr = a.params + (size_t)n * NPARAM;
+  const bool jitter = pr[5] != 0.f, gray = pr[10] != 0.f;
+  if (threadIdx.x < 3) {
+    float s = 0.f;
+    for (int q = 0; q < nparts; ++q) s += partial[((size_t)n * nparts + q) * 3 + threadIdx.x];
+    mean[threadIdx.x] = s / (float)HW;
+  }
+  __syncthreads();
+  const float* src = a.x + (size_t)n * 3 * HW;
+  const float* go = gout + (size_t)n * 3 * HW;
+  float* gm = GM + (size_t)n * 3 * HW;
+  const float fc = pr[6];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int p = blockIdx.y * blockDim.x + threadIdx.x; p < HW; p += gridDim.y * blockDim.x) {
+    float g0 = go[p], g1 = go[HW + p], g2 = go[2 * HW + p];
+    if (gray) {
+      const float sum = g0 + g1 + g2;
+      g0 = 0.299f * sum; g1 = 0.587f * sum; g2 = 0.114f * sum;
+    }
+    if (jitter) {
+      const int i = p / a.W, j = p - i * a.W;
+      const Sampler s = make_sampler(pr, i, j, a.H, a.W);
+      float r = sample_plane(src, s, a.W), g = sample_plane(src + HW, s, a.W), b = sample_plane(src + 2 * HW, s, a.W);
+      if (!a.contrast_first) hsv_jitter(r, g, b, pr[7], pr[8], pr[9]);
+      if (a.has_contrast) {
+        r = (r - mean[0]) * fc + mean[0]; g = (g - mean[1]) * fc + mean[1]; b = (b - mean[2]) * fc + mean[2];
+      }
+      if (!(r >= 0.f && r <= 1.f)) g0 = 0.f;        // torch.clamp backward
+      if (!(g >= 0.f && g <= 1.f)) g1 = 0.f;
+      if (!(b >= 0.f && b <= 1.f)) g2 = 0.f;
+      s0 += g0; s1 += g1; s2 += g2;
+    }
+    gm[p] = g0; gm[HW + p] = g1; gm[2 * HW + p] = g2;
+  }
+  s0 = block_sum(s0, red); s1 = block_sum(s1, red); s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    float* o = partial2 + ((size_t)n * gridDim.y + blockIdx.y) * 3;
+    o[0] = s0; o[1] = s1; o[2] = s2;
+  }
+}
+
+// T[n,c,i,x] = sum_j G'[n,c,i,j] Wx[j][x]
+__global__ __launch_bounds__(256) void simclr_bwd_gather_x_kernel(AugArgs a, const float* __restrict__ GM,
+                                                                  const float* __restrict__ partial2, int nparts,
+                                                                  float* __restrict__ T) {
+  __shared__ float gmean[3];
+  const int n = blockIdx.x;
+  const int H = a.H, W = a.W, HW = H * W;
+  const float* pr = a.params + (size_t)n * NPARAM;
+  const bool contrast = pr[5] != 0.f && a.has_contrast;
+  if (threadIdx.x < 3) {
+    float s = 0.f;
+    if (contrast)
+      for (int q = 0; q < nparts; ++q) s += partial2[((size_t)n * nparts + q) * 3 + threadIdx.x];
+    gmean[threadIdx.x] = s / (float)HW;
+  }
+  __syncthreads();
+  const float fc = contrast ? pr[6] : 1.f;
+  const bool flip = pr[4] < 0.f;
+  for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < 3 * HW; e += gridDim.y * blockDim.x) {
+    const int c = e / HW, rem = e - c * HW, i = rem / W, x = rem - i * W;
+    int lo, hi;
+    axis_inverse_range(pr[0], pr[2], x, W, lo, hi);
+    const float* grow = GM + ((size_t)n * 3 + c) * HW + (size_t)i * W;
+    const float add = (1.f - fc) * gmean[c];
+    float acc = 0.f;
+    for (int jj = lo; jj <= hi; ++jj) {
+      const Axis ax = axis_sample(pr[0], pr[2], jj, W);
+      float w = 0.f;
+      if (ax.v0 && ax.p0 == x) w += ax.w0;
+      if (ax.v1 && ax.p1 == x) w += ax.w1;
+      if (w != 0.f) acc = fmaf(fc * grow[flip ? (W - 1 - jj) : jj] + add, w, acc);
+    }
+    T[((size_t)n * 3 + c) * HW + rem] = acc;
+  }
+}
+
+// dX[n,c,y,x] = sum_i Wy[i][y] T[n,c,i,x]
+__global__ __launch_bounds__(256) void simclr_bwd_gather_y_kernel(AugArgs a, const float* __restrict__ T,
+                                                                  float* __restrict__ gin) {
+  const int n = blockIdx.x;
+  const int H = a.H, W = a.W, HW = H * W;
+  const float* pr = a.params + (size_t)n * NPARAM;
+  for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < 3 * HW; e += gridDim.y * blockDim.x) {
+    const int c = e / HW, rem = e - c * HW, y = rem / W, x = rem - y * W;
+    int lo, hi;
+    axis_inverse_range(pr[1], pr[3], y, H, lo, hi);
+    const float* tcol = T + ((size_t)n * 3 + c) * HW + x;
+    float acc = 0.f;
+    for (int i = lo; i <= hi; ++i) {
+      const Axis ay = axis_sample(pr[1], pr[3], i, H);
+      float w = 0.f;
+      if (ay.v0 && ay.p0 == y) w += ay.w0;
+      if (ay.v1 && ay.p1 == y) w += ay.w1;
+      if (w != 0.f) acc = fmaf(tcol[(size_t)i * W], w, acc);
+    }
+    gin[((size_t)n * 3 + c) * HW + rem] = acc;
+  }
+}
+
+// ---------------- adjoint of the masked separable Gaussian blur (reflect padding) ----------------
+// forward (one axis): out[i] = sum_t g[t] in[reflect(i + t - R)].  Adjoint: din[y] = sum over the pre-images p of y
+// under the reflection (p = y, p = -y for 1 <= y <= R, p = 2(n-1) - y for n-1-R <= y <= n-2) of the zero-padded
+// correlation  F(p) = sum_{i in [0,n), |i-p| <= R} g[p - i + R] dout[i].  Applied along y first (the forward ran x
+// then y), then along x.  Un-masked samples pass the gradient through.
+__device__ __forceinline__ float blur_adj_at(const float* __restrict__ v, long long stride, int n, int p, int R,
+                                             const float* g) {
+  int i0 = p - R, i1 = p + R;
+  i0 = i0 < 0 ? 0 : i0;
+  i1 = i1 > n - 1 ? n - 1 : i1;
+  float s = 0.f;
+  for (int i = i0; i <= i1; ++i) s = fmaf(g[p - i + R], v[(long long)i * stride], s);
+  return s;
+}
+__global__ __launch_bounds__(256) void blur_adj_kernel(const float* __restrict__ gin_, float* __restrict__ gout_,
+                                                       const float* __restrict__ params, int H, int W, int R,
+                                                       const float* __restrict__ gk, int vertical) {
+  __shared__ float g[BLUR_MAXK];
+  const int plane = blockIdx.y, n = plane / 3;
+  const bool masked = params[(size_t)n * NPARAM + 11] != 0.f;
+  for (int t = threadIdx.x; t < 2 * R + 1; t += blockDim.x) g[t] = gk[t];
+  __syncthreads();
+  const size_t pbase = (size_t)plane * H * W;
+  const int HW = H * W;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < HW; e += gridDim.x * blockDim.x) {
+    if (!masked) { gout_[pbase + e] = gin_[pbase + e]; continue; }
+    const int y = e / W, x = e - y * W;
+    const int len = vertical ? H : W, pos = vertical ? y : x;
+    const float* base = vertical ? (gin_ + pbase + x) : (gin_ + pbase + (size_t)y * W);
+    const long long stride = vertical ? W : 1;
+    float s = blur_adj_at(base, stride, len, pos, R, g);
+    if (pos >= 1 && pos <= R) s += blur_adj_at(base, stride, len, -pos, R, g);
+    if (pos >= len - 1 - R && pos <= len - 2) s += blur_adj_at(base, stride, len, 2 * (len - 1) - pos, R, g);
+    gout_[pbase + e] = s;
+  }
+}
+
 }  // namespace
 
 extern "C" long long contrad_simclr_workspace_bytes(int B, int H, int W) {
@@ -415,14 +591,54 @@ extern "C" int contrad_simclr_augment(const float* x, float* y, const float* par
   return 0;
 }
 
+extern "C" long long contrad_simclr_augment_bwd_workspace_bytes(int B, int H, int W) {
+  const size_t smem = (size_t)(7 * H * W + H * H + W * W) * sizeof(float);
+  if (smem <= 64 * 1024) return 16;
+  const int nparts = cdiv(H * W, 256 * 16);
+  return ((long long)B * nparts * 3 * 2 + (long long)B * 3 * H * W * 2) * (long long)sizeof(float);
+}
+
 extern "C" int contrad_simclr_augment_bwd(const float* x, const float* params, const float* grad_out,
                                           float* grad_in, int B, int H, int W, int contrast_first,
-                                          int has_contrast, contrad_stream_t stream) {
+                                          int has_contrast, float* workspace, long long workspace_bytes,
+                                          contrad_stream_t stream) {
   CONTRAD_ARG(x && params && grad_out && grad_in && B > 0 && H > 1 && W > 1);
+  hipStream_t s = (hipStream_t)stream;
   const size_t smem = (size_t)(7 * H * W + H * H + W * W) * sizeof(float);
-  CONTRAD_ARG(smem <= 64 * 1024);   // small-image path (<= 44x44); larger images: not built (scope row N2)
   AugArgs a{x, nullptr, params, B, H, W, contrast_first, has_contrast};
-  hipLaunchKernelGGL(simclr_small_bwd_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, a, grad_out, grad_in);
+  if (smem <= 64 * 1024) {   // small-image path (<= 44x44): one block per image, everything in LDS
+    hipLaunchKernelGGL(simclr_small_bwd_kernel, dim3(B), dim3(256), smem, s, a, grad_out, grad_in);
+    CONTRAD_CHECK_LAUNCH();
+    return 0;
+  }
+  CONTRAD_ARG(workspace && workspace_bytes >= contrad_simclr_augment_bwd_workspace_bytes(B, H, W));
+  const int nparts = cdiv(H * W, 256 * 16);
+  float* partial = workspace;
+  float* partial2 = partial + (size_t)B * nparts * 3;
+  float* GM = partial2 + (size_t)B * nparts * 3;
+  float* T = GM + (size_t)B * 3 * H * W;
+  hipLaunchKernelGGL(simclr_stats_kernel, dim3(B, nparts), dim3(256), 0, s, a, partial);
+  CONTRAD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(simclr_bwd_gm_kernel, dim3(B, nparts), dim3(256), 0, s, a, grad_out, partial, nparts, GM, partial2);
+  CONTRAD_CHECK_LAUNCH();
+  const int gy = cdiv(3 * H * W, 256 * 4);
+  hipLaunchKernelGGL(simclr_bwd_gather_x_kernel, dim3(B, gy), dim3(256), 0, s, a, GM, partial2, nparts, T);
+  CONTRAD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(simclr_bwd_gather_y_kernel, dim3(B, gy), dim3(256), 0, s, a, T, grad_in);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int contrad_gaussian_blur_masked_bwd(const float* grad_out, float* tmp, float* grad_in, const float* params,
+                                                const float* kernel1d, int B, int H, int W, int radius,
+                                                contrad_stream_t stream) {
+  CONTRAD_ARG(grad_out && tmp && grad_in && params && kernel1d && B > 0 && H > 0 && W > 0);
+  CONTRAD_ARG(radius >= 0 && 2 * radius + 1 <= BLUR_MAXK && radius < H && radius < W);
+  hipStream_t s = (hipStream_t)stream;
+  const int gx = cdiv(H * W, 256 * 2);
+  hipLaunchKernelGGL(blur_adj_kernel, dim3(gx, B * 3), dim3(256), 0, s, grad_out, tmp, params, H, W, radius, kernel1d, 1);
+  CONTRAD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(blur_adj_kernel, dim3(gx, B * 3), dim3(256), 0, s, tmp, grad_in, params, H, W, radius, kernel1d, 0);
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }

@@ -213,6 +213,55 @@ __global__ void modconv_epilogue_kernel(const float* __restrict__ x, const float
   }
 }
 
+// out[n][c] = sum_hw a[n,hw,c] * b[n,hw,c]  (bcs = 1)  or  sum_hw a[n,hw,c] * b[n,hw]  (bcs = 0, b broadcast over c):
+// the style / demodulation / noise-strength gradients of the modulated convolution (generator step).  Deterministic
+// two-stage reduction: partial[n][s][c] over S row segments, then a fixed-order sum over s.
+__global__ __launch_bounds__(256) void nhwc_dot_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                               float* __restrict__ partial, long long HW, int C,
+                                                               int bcs, int S, int lanes_c) {
+  __shared__ float4 red[256];
+  const int s = blockIdx.x, n = blockIdx.y;
+  const int c4n = C >> 2;
+  const int lc = threadIdx.x % lanes_c, lr = threadIdx.x / lanes_c, R = 256 / lanes_c;
+  const long long chunk = (HW + S - 1) / S;
+  const long long r0 = (long long)s * chunk, r1 = (r0 + chunk < HW) ? r0 + chunk : HW;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (lc < c4n) {
+    const float* an = a + (size_t)n * HW * C;
+    for (long long r = r0 + lr; r < r1; r += R) {
+      const float4 u = *reinterpret_cast<const float4*>(an + (size_t)r * C + lc * 4);
+      if (bcs) {
+        const float4 v = *reinterpret_cast<const float4*>(b + ((size_t)n * HW + r) * C + lc * 4);
+        acc.x = fmaf(u.x, v.x, acc.x); acc.y = fmaf(u.y, v.y, acc.y);
+        acc.z = fmaf(u.z, v.z, acc.z); acc.w = fmaf(u.w, v.w, acc.w);
+      } else {
+        const float v = b[(size_t)n * HW + r];
+        acc.x = fmaf(u.x, v, acc.x); acc.y = fmaf(u.y, v, acc.y);
+        acc.z = fmaf(u.z, v, acc.z); acc.w = fmaf(u.w, v, acc.w);
+      }
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (lr == 0 && lc < c4n) {
+    float4 t = red[lc];
+    for (int q = 1; q < R; ++q) {
+      const float4 u = red[q * lanes_c + lc];
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    *reinterpret_cast<float4*>(partial + ((size_t)n * S + s) * C + lc * 4) = t;
+  }
+}
+
+__global__ void nhwc_dot_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int N, int C, int S) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * C) return;
+  const int n = e / C, c = e - n * C;
+  float t = 0.f;
+  for (int s = 0; s < S; ++s) t += partial[((size_t)n * S + s) * C + c];
+  out[e] = t;
+}
+
 }  // namespace
 
 extern "C" int contrad_pixelnorm(const float* x, float* y, int M, int K, contrad_stream_t stream) {
@@ -228,6 +277,36 @@ extern "C" int contrad_nhwc_scale(const float* x, const float* s, float* y, int 
   long long grid = ((long long)N * HW * (C / 4) + 255) / 256;
   if (grid > 16384) grid = 16384;
   hipLaunchKernelGGL(nhwc_scale_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, x, s, y, N, HW, C);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+
+static int nhwc_dot_segments(int N, long long HW) {
+  long long S = (HW + 63) / 64;
+  const long long cap = (2048 + N - 1) / N;
+  if (S > cap) S = cap;
+  return (int)(S < 1 ? 1 : S);
+}
+
+extern "C" long long contrad_nhwc_dot_workspace_bytes(int N, long long HW, int C) {
+  if (N <= 0 || HW <= 0 || C <= 0) return -22;
+  return (long long)N * nhwc_dot_segments(N, HW) * C * (long long)sizeof(float);
+}
+
+extern "C" int contrad_nhwc_dot(const float* a, const float* b, float* out, int N, long long HW, int C,
+                                int b_per_channel, float* workspace, long long workspace_bytes,
+                                contrad_stream_t stream) {
+  CONTRAD_ARG(a && b && out && N > 0 && HW > 0 && C > 0 && (C & 3) == 0 && C <= 1024);
+  CONTRAD_ARG(workspace && workspace_bytes >= contrad_nhwc_dot_workspace_bytes(N, HW, C));
+  const int S = nhwc_dot_segments(N, HW);
+  int lanes_c = 1;
+  while (lanes_c < C / 4) lanes_c <<= 1;
+  hipLaunchKernelGGL(nhwc_dot_partial_kernel, dim3(S, N), dim3(256), 0, (hipStream_t)stream, a, b, workspace, HW, C,
+                     b_per_channel ? 1 : 0, S, lanes_c);
+  CONTRAD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(nhwc_dot_final_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, workspace, out,
+                     N, C, S);
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }

@@ -1,6 +1,8 @@
 """StyleGAN2 generator forward on the HIP library -- counterpart of models/gan/stylegan2/generator.py:146-291.
 
-Used under no_grad inside the discriminator step (the fake batch).  Same state-dict names as the reference.
+Under no_grad (the discriminator step's fake batch) it runs on fused forward-only launches; with gradients enabled
+(the generator step, train_stylegan2.py:184-194 / train_stylegan2_contraD.py:138-146,207) the same network is composed
+from the differentiable HIP nodes of contrad_amd.autograd_ops.  Same state-dict names as the reference.
 Design (NHWC feature maps):
   * mapping network: PixelNorm kernel + 8 EqualLinear(lr_mul 0.01)+fused-lrelu as GEMMs with bias/activation in the
     epilogue;
@@ -156,11 +158,14 @@ class Generator(nn.Module):
             out.append(t.conv)
         return out
 
-    def _prepared(self):
-        params = list(self.parameters())
-        key = tuple((p.data_ptr(), p._version) for p in params)
-        if key == self._cache_key:
-            return self._cache
+    def _prepared(self, differentiable=False):
+        """Packed weights / biases / Wsq tables.  Forward-only: built under no_grad and cached on the parameters'
+        version counters.  ``differentiable``: rebuilt inside the autograd graph on every call."""
+        if not differentiable:
+            params = list(self.parameters())
+            key = tuple((p.data_ptr(), p._version) for p in params)
+            if key == self._cache_key:
+                return self._cache
         dev = self.device
         ws, entries, groups = [], [], []
 
@@ -170,8 +175,8 @@ class Generator(nn.Module):
             entries.append((K, C, T, scale, len(groups) - 1, 0))
             return len(groups) - 1
 
-        c = {'style': [], 'mod': {}, 'conv': {}, 'wsq': {}}
-        with torch.no_grad():
+        c = {'style': [], 'mod': {}, 'conv': {}, 'wsq': {}, 'differentiable': differentiable}
+        with torch.set_grad_enabled(differentiable):
             for m in list(self.style)[1:]:
                 c['style'].append((add(m.weight, m.weight.shape[0], m.weight.shape[1], 1, m.scale),
                                    (m.bias * m.lr_mul).contiguous()))
@@ -190,23 +195,65 @@ class Generator(nn.Module):
                     c['wsq'][mc] = ((w * mc.scale).pow(2).sum((2, 3)).t().contiguous())
             packed = A.PackWeightsFn.apply(A.PackMeta(entries, groups), *ws)
         c['packed'] = packed
-        self._cache_key, self._cache = key, c
+        if not differentiable:
+            self._cache_key, self._cache = key, c
         return c
 
     # ---- pieces ----------------------------------------------------------------------------------------------
     def _mapping(self, z, c):
-        x = ops.pixelnorm(z.contiguous().float())
+        x = ops.pixelnorm(z.contiguous().float())          # z is a sample, not a parameter: no gradient needed
         B = x.shape[0]
         for gi, bias in c['style']:
-            x = ops.conv2d_fwd(x.view(B, 1, 1, -1), c['packed'][gi], bias, self.style_dim, 1, 1, 1, 0, 0.2,
-                               math.sqrt(2.0)).view(B, -1)
+            if c['differentiable']:
+                x = A.ConvBiasActFn.apply(x.view(B, 1, 1, -1), c['packed'][gi], bias, (self.style_dim, 1, 1, 1, 0),
+                                          0.2, math.sqrt(2.0)).view(B, -1)
+            else:
+                x = ops.conv2d_fwd(x.view(B, 1, 1, -1), c['packed'][gi], bias, self.style_dim, 1, 1, 1, 0, 0.2,
+                                   math.sqrt(2.0)).view(B, -1)
         return x
 
     def _style(self, mc, w_lat, c):
         gi, bias = c['mod'][mc]
         B = w_lat.shape[0]
+        if c['differentiable']:
+            return A.ConvBiasActFn.apply(w_lat.contiguous().view(B, 1, 1, -1), c['packed'][gi], bias,
+                                         (mc.in_channel, 1, 1, 1, 0), 1.0, 1.0).view(B, mc.in_channel)
         return ops.conv2d_fwd(w_lat.contiguous().view(B, 1, 1, -1), c['packed'][gi], bias, mc.in_channel, 1, 1, 1,
                               0).view(B, mc.in_channel)
+
+    def _styled_conv_grad(self, layer, x, w_lat, noise, c):
+        """StyledConv (generator.py:97-118) out of differentiable nodes: style -> demodulation factors -> modulate the
+        input -> shared-weight conv (or transposed conv + blur) -> demod + noise + bias + activation."""
+        mc = layer.conv
+        B, H, W, _ = x.shape
+        s = self._style(mc, w_lat, c)
+        d = A.Conv2dFn.apply((s * s).view(B, 1, 1, -1), c['wsq'][mc], (mc.out_channel, 1, 1, 1, 0)).view(B, -1)
+        demod = torch.rsqrt(d + 1e-8)
+        xm = A.NhwcScaleFn.apply(x, s)
+        wp = c['packed'][c['conv'][mc]]
+        if mc.upsample:
+            y = A.ConvDgradFn.apply(xm, wp, (B, 2 * H + 1, 2 * W + 1, mc.out_channel), (mc.in_channel, 3, 3, 2, 0))
+            p0, p1 = mc.blur.pad
+            y = A.UpFirDn2dFn.apply(y, mc.blur.kernel, 1, 1, (p0, p1, p0, p1))
+        else:
+            y = A.Conv2dFn.apply(xm, wp, (mc.out_channel, 3, 3, 1, 1))
+        if noise is None:
+            noise = torch.empty(B, 1, y.shape[1], y.shape[2], device=y.device).normal_()
+        noise = noise.expand(B, 1, y.shape[1], y.shape[2]).contiguous()
+        return A.ModconvEpilogueFn.apply(y, demod, noise, layer.noise.weight, layer.activate.bias)
+
+    def _to_rgb_grad(self, trgb, x, w_lat, skip, c):
+        """ToRGB (generator.py:121-143): 1x1 modulated conv without demodulation + bias + upsampled skip."""
+        mc = trgb.conv
+        s = self._style(mc, w_lat, c)
+        xm = A.NhwcScaleFn.apply(x, s)
+        out = A.RgbDgradFn.apply(xm, c['packed'][c['conv'][mc]], 3, (1, 1.0)) + trgb.bias
+        if skip is not None:
+            B, C, H, W = skip.shape
+            p0, p1 = trgb.upsample.pad
+            up = A.UpFirDn2dFn.apply(skip.reshape(B * C, H, W, 1), trgb.upsample.kernel, 2, 1, (p0, p1, p0, p1))
+            out = out + up.view(B, C, 2 * H, 2 * W)
+        return out
 
     def _styled_conv(self, layer, x, w_lat, noise, c):
         mc = layer.conv
@@ -244,11 +291,10 @@ class Generator(nn.Module):
                                   mod=s, residual=res)
 
     def forward(self, input, return_latents=False, style_mix=0.9, input_is_latent=False, noise=None, _mix=None):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError('generator backward (G-step) is scope row N1/N2 -- call under no_grad')
         if not input.is_cuda:
             raise RuntimeError('contrad_amd StyleGAN2 generator runs on the MI355X HIP path only (no CPU fallback)')
-        c = self._prepared()
+        grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        c = self._prepared(differentiable=grad)
         latent = self._mapping(input, c) if not input_is_latent else input
         if noise is None:
             noise = [None] * self.num_layers
@@ -267,6 +313,19 @@ class Generator(nn.Module):
             latents = latents * mask + latent_mix.unsqueeze(1) * (1 - mask)
         B = latents.shape[0]
         x = self.input.const.permute(0, 2, 3, 1).expand(B, -1, -1, -1).contiguous()        # NHWC const input
+        if grad:
+            x = self._styled_conv_grad(self.conv1, x, latents[:, 0], noise[0], c)
+            skip = self._to_rgb_grad(self.to_rgb1, x, latents[:, 1], None, c)
+            idx = 1
+            for j in range(len(self.to_rgbs)):
+                x = self._styled_conv_grad(self.layers[2 * j], x, latents[:, idx], noise[1 + 2 * j], c)
+                x = self._styled_conv_grad(self.layers[2 * j + 1], x, latents[:, idx + 1], noise[2 + 2 * j], c)
+                skip = self._to_rgb_grad(self.to_rgbs[j], x, latents[:, idx + 2], skip, c)
+                idx += 2
+            image = 0.5 * skip + 0.5                                                        # generator.py:283
+            if return_latents:
+                return image, latents
+            return image
         x = self._styled_conv(self.conv1, x, latents[:, 0], noise[0], c)
         last = len(self.to_rgbs) == 0
         skip = self._to_rgb(self.to_rgb1, x, latents[:, 1], None, c, final=last)

@@ -509,20 +509,46 @@ def nhwc_scale(x, s):
     return y
 
 
-def modconv_epilogue_(x, demod, noise, noise_w, bias):
-    """In place on x (N,H,W,K): sqrt2 * lrelu_0.2(x * demod + noise_w * noise + bias)."""
+def modconv_epilogue_(x, demod, noise, noise_w, bias, out=None):
+    """sqrt2 * lrelu_0.2(x * demod + noise_w * noise + bias) on x (N,H,W,K); in place unless ``out`` is given."""
     N, H, W, K = x.shape
-    lib().call('contrad_modconv_epilogue', _p(x), _p(demod), _p(noise), _p(noise_w), _p(bias), _p(x), N,
+    out = x if out is None else out
+    lib().call('contrad_modconv_epilogue', _p(x), _p(demod), _p(noise), _p(noise_w), _p(bias), _p(out), N,
                ctypes.c_longlong(H * W), K, _stream())
-    return x
+    return out
 
 
 def simclr_augment_bwd(x, params, grad_out, contrast_first, has_contrast):
     B, C, H, W = x.shape
     gin = torch.empty_like(x)
+    nbytes = lib().raw('contrad_simclr_augment_bwd_workspace_bytes')(B, H, W)
+    ws = _workspace(nbytes, x.device)
     lib().call('contrad_simclr_augment_bwd', _p(x), _p(params), _p(grad_out.contiguous()), _p(gin), B, H, W,
-               int(contrast_first), int(has_contrast), _stream())
+               int(contrast_first), int(has_contrast), _p(ws), ctypes.c_longlong(ws.numel() * 4), _stream())
     return gin
+
+
+def gaussian_blur_masked_bwd(grad_out, params, kernel1d, radius):
+    B, C, H, W = grad_out.shape
+    tmp = torch.empty_like(grad_out)
+    gin = torch.empty_like(grad_out)
+    lib().call('contrad_gaussian_blur_masked_bwd', _p(grad_out.contiguous()), _p(tmp), _p(gin), _p(params),
+               _p(kernel1d), B, H, W, int(radius), _stream())
+    return gin
+
+
+def nhwc_dot(a, b, per_channel=True):
+    """a (N,H,W,C) contiguous; b (N,H,W,C) [per_channel] or (N,H,W) / (N,1,H,W) -> (N,C) sums over the pixels."""
+    _chk(a, 'a'); _chk(b, 'b')
+    N, H, W, C = a.shape
+    if not (a.is_contiguous() and b.is_contiguous()) or b.numel() != (a.numel() if per_channel else N * H * W):
+        raise RuntimeError('contrad_hip: nhwc_dot needs contiguous (N,H,W,C) / (N,H,W) operands')
+    out = torch.empty((N, C), device=a.device, dtype=torch.float32)
+    nbytes = lib().raw('contrad_nhwc_dot_workspace_bytes')(N, ctypes.c_longlong(H * W), C)
+    ws = _workspace(nbytes, a.device)
+    lib().call('contrad_nhwc_dot', _p(a), _p(b), _p(out), N, ctypes.c_longlong(H * W), C, int(per_channel), _p(ws),
+               ctypes.c_longlong(ws.numel() * 4), _stream())
+    return out
 
 
 def bn_relu_bwd(dy2d, x2d, stats, count, gamma, beta, eps, reduce_fn=None):

@@ -233,17 +233,24 @@ int contrad_simclr_augment(const float* x, float* y, const float* params, int B,
                            int contrast_first, int has_contrast, float* workspace,
                            long long workspace_bytes, contrad_stream_t stream);
 /* Backward of contrad_simclr_augment for the generator step (gradient flows through the augmentation into G,
- * training/gan/contrad.py:73-82): grad_in = d loss / d x given grad_out = d loss / d y.  Bilinear gather
- * transpose, contrast backward, straight-through HSV (augment/color_jitter.py:97-104), gray backward.
- * Small images only (7*H*W + H*H + W*W floats of LDS <= 64 KiB, i.e. CIFAR). */
+ * training/gan/contrad.py:73-82, train_stylegan2_contraD.py:138-146): grad_in = d loss / d x given grad_out =
+ * d loss / d y.  Bilinear gather transpose, contrast backward, straight-through HSV (augment/color_jitter.py:97-104),
+ * gray backward.  Small images (7*H*W + H*H + W*W floats of LDS <= 64 KiB, i.e. CIFAR) run in one block per image and
+ * need no workspace; larger images (AFHQ 512x512) take four launches and the workspace sized by the query. */
+long long contrad_simclr_augment_bwd_workspace_bytes(int B, int H, int W);
 int contrad_simclr_augment_bwd(const float* x, const float* params, const float* grad_out, float* grad_in,
-                               int B, int H, int W, int contrast_first, int has_contrast,
-                               contrad_stream_t stream);
+                               int B, int H, int W, int contrast_first, int has_contrast, float* workspace,
+                               long long workspace_bytes, contrad_stream_t stream);
 /* RandomApply(GaussianBlur) (augment/__init__.py:53-78): separable (2*radius+1)-tap blur with reflect
  * padding on samples whose blur_mask != 0, copy-through otherwise; tmp is a scratch image batch. */
 int contrad_gaussian_blur_masked(const float* x, float* tmp, float* y, const float* params,
                                  const float* kernel1d, int B, int H, int W, int radius,
                                  contrad_stream_t stream);
+/* Adjoint of contrad_gaussian_blur_masked (the generator step through simclr_hq): grad_in = blur^T(grad_out) on the
+ * masked samples (reflect-padding transpose: border contributions fold back), copy-through otherwise. */
+int contrad_gaussian_blur_masked_bwd(const float* grad_out, float* tmp, float* grad_in, const float* params,
+                                     const float* kernel1d, int B, int H, int W, int radius,
+                                     contrad_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * The reference's two native ops (models/gan/stylegan2/op/), same tensor contracts.
@@ -280,6 +287,13 @@ int contrad_nhwc_scale(const float* x, const float* s, float* y, int N, long lon
  * demod / noise may be NULL. */
 int contrad_modconv_epilogue(const float* x, const float* demod, const float* noise, const float* noise_w,
                              const float* bias, float* y, int N, long long HW, int K, contrad_stream_t stream);
+/* out[n,c] = sum_hw a[n,hw,c] * b[n,hw,c] (b_per_channel != 0) or sum_hw a[n,hw,c] * b[n,hw] (b broadcast over the
+ * channels): the gradients of the style vector, the demodulation factor and the noise strength in the backward of
+ * ModulatedConv2d / NoiseInjection (generator.py:52-94; the reference gets them from autograd over its grouped
+ * conv).  Deterministic two-stage reduction; workspace from contrad_nhwc_dot_workspace_bytes. */
+long long contrad_nhwc_dot_workspace_bytes(int N, long long HW, int C);
+int contrad_nhwc_dot(const float* a, const float* b, float* out, int N, long long HW, int C, int b_per_channel,
+                     float* workspace, long long workspace_bytes, contrad_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -631,8 +631,86 @@ def gen_stylegan2_512():
          img0_rowsum=img0.double().sum(3), img1_rowsum=img1.double().sum(3), img0_patch=img0[:, :, 200:232, 300:332])
 
 
+# ------------------------------------------------------------------------------------------------
+def gen_stylegan2_gstep():
+    """StyleGAN2 generator step (train_stylegan2.py:184-194; train_stylegan2_contraD.py:138-146 computes the same
+    d_gen): G(z, style_mix) with grad, explicit noise -> loss_G_fn = softplus(-D(augment(G(z)))).mean() -> all G
+    gradients (mapping network, modulated convs incl. demodulation, noise strengths, ToRGB + upsampled skips, const)."""
+    import augment as A
+    from oracle import stylegan2_oracle as S
+    from models.gan.stylegan2.generator import Generator
+    from models.gan.stylegan2.discriminator import ResidualDiscriminatorP
+    from training.gan import contrad as ref_contrad
+    from argparse import Namespace
+    _refshim.bind_cifar_defaults()
+    G = Generator(size=32, n_mlp=8, small32=True)
+    D = ResidualDiscriminatorP(size=32, small32=True, mlp_linear=True, d_hidden=512)
+    G.train(); D.train()
+    gshapes = {k: tuple(v.shape) for k, v in G.state_dict().items()}
+    gsd = S.fill_kernels(S.det_fill_g(gshapes, seed=779), gshapes)
+    # the reference initialises the noise strengths to 0 (their gradient is still non-zero); give them a value so the
+    # forward depends on the injected noise as it does after training
+    for k in gsd:
+        if k.endswith('noise.weight'):
+            gsd[k] = torch.full_like(gsd[k], 0.1)
+    G.load_state_dict({k: v.clone() for k, v in gsd.items()})
+    dsd = S.det_fill_d(S.d_param_shapes(32, True), seed=2025)
+    D.load_state_dict({k: v.clone() for k, v in dsd.items()})
+    for p in D.parameters():
+        p.requires_grad = False
+    B = 4
+    g = torch.Generator().manual_seed(47)
+    z = torch.randn(B, 512, generator=g)
+    noise = [torch.randn(B, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), generator=g) for i in range(G.num_layers)]
+    for mseed in range(100):           # a seed whose draws mix some samples and leave others alone
+        torch.manual_seed(mseed)
+        z_mix = torch.randn(B, 512)
+        nomix = torch.rand(B) >= 0.9
+        mix_layer = torch.randint(G.n_latent, (B,)).masked_fill(nomix, G.n_latent)
+        if 1 <= nomix.sum().item() < B:
+            break
+    torch.manual_seed(mseed)
+    gen = G(z, style_mix=0.9, noise=noise)
+    aug = A.simclr()
+    seed = 33
+    P = Namespace(augment_fn=aug, temp=0.1, lbd_a=1.0, distributed=False)
+    torch.manual_seed(seed); np.random.seed(seed)
+    g_loss = ref_contrad.loss_G_fn(P, D, {'loss': 'nonsat'}, None, gen)
+    G.zero_grad()
+    g_loss.backward()
+    ref_grads = {k: v.grad.clone() for k, v in G.named_parameters()}
+
+    osd = {k: v.clone() for k, v in gsd.items()}
+    gparams = [k for k, _ in G.named_parameters()]
+    for k in gparams:
+        osd[k].requires_grad_()
+    ogen = S.g_forward(osd, z, 32, noise, mix=(z_mix, mix_layer))
+    check(ogen, gen, 1e-5, 'sg2 gstep gen')
+    torch.manual_seed(seed); np.random.seed(seed)
+    p = O.sample_simclr_params(B, 32, 32, O.SIMCLR_CIFAR)
+    od = S.d_forward(dsd, O.simclr_apply(ogen, p), 32, sg_linear=False)[0]
+    ol = O.gan_g_loss(od, 'nonsat')
+    ol.backward()
+    check(ol, g_loss, 1e-6, 'sg2 gstep loss')
+    gerr = 0.0
+    for k, gref in ref_grads.items():
+        gerr = max(gerr, check(osd[k].grad, gref, 5e-5, 'sg2 gstep grad ' + k))
+    print('  stylegan2 G-step: max grad err oracle vs reference %.2e, loss %.5f' % (gerr, g_loss.item()))
+    out = {'z': z, 'z_mix': z_mix, 'mix_layer': mix_layer, 'seed': seed, 'B': B, 'gen': gen, 'g_loss': g_loss,
+           'gseed': 779, 'dseed': 2025}
+    for i, n in enumerate(noise):
+        out['noise%d' % i] = n
+    for k, gref in ref_grads.items():
+        out['gradnorm/' + k] = gref.norm()
+        if gref.numel() <= 2048:
+            out['grad/' + k] = gref
+        else:
+            out['gradhead/' + k] = gref.reshape(-1)[:256]
+    save('stylegan2_gstep', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['losses', 'augment', 'sndcgan', 'sndcgan_gstep', 'adam', 'stylegan2', 'stylegan2_g', 'stylegan2_512']
+    which = sys.argv[1:] or ['losses', 'augment', 'sndcgan', 'sndcgan_gstep', 'adam', 'stylegan2', 'stylegan2_g', 'stylegan2_512', 'stylegan2_gstep']
     for w in which:
         globals()['gen_' + w]()
     print('golden vectors OK')

@@ -207,3 +207,25 @@ def test_adjoint_identities_of_the_512_layer_shapes(shape):
     # |a| ~ sqrt(#terms) * rms(y) * rms(gy); fp32 accumulation noise is ~1e-6 of that, a wrong tap / stride is O(1) of it
     tol = 1e-4 * abs(a) + 2e-5 * np.sqrt(y.numel()) * y.double().pow(2).mean().sqrt().item()
     assert abs(a - b) < tol and abs(a - c) < tol, (a, b, c, tol)
+
+
+def test_config5_generator_step_at_512():
+    """train_stylegan2_contraD.py:138-146,207 at the AFHQ size: G(512) with grad -> simclr_hq (blur backward) -> D with
+    sg_linear=False -> softplus(-d).mean(); every generator parameter receives a finite gradient, D none."""
+    from contrad_amd.train_stylegan2 import loss_G_nonsat, sample_generator
+    hq = dict(scale=(0.08, 1.0), brightness=0.8, contrast=0.8, saturation=0.8, hue=0.2, p_blur=0.5,
+              sigma_range=(0.1, 2.0))
+    G, D, P, x, lr = _setup('stylegan2_512', 512, 4, hq, 0.5, 16, 2.5e-3)
+    set_grad(G, True); set_grad(D, False)
+    torch.manual_seed(3); np.random.seed(3); torch.cuda.manual_seed(3)
+    gen = sample_generator(G, 4, style_mix=0.9, enable_grad=True)
+    assert gen.shape == (4, 3, 512, 512) and gen.requires_grad
+    d_gen, _ = D(P.augment_fn(gen), sg_linear=False, projection=True, projection2=True)
+    g_loss = loss_G_nonsat(d_gen)
+    g_loss.backward()
+    assert torch.isfinite(g_loss)
+    for k, p in G.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    assert all(p.grad is None for p in D.parameters())
+    nz = sum(1 for p in G.parameters() if p.grad.abs().max().item() > 0)
+    assert nz >= len(list(G.parameters())) - 2
