@@ -709,8 +709,46 @@ def gen_stylegan2_gstep():
     save('stylegan2_gstep', **out)
 
 
+# ------------------------------------------------------------------------------------------------
+def gen_checkpoint_manifest():
+    """Structure of the checkpoint files the reference writes (train_gan.py:211-225, train_stylegan2.py:260-285):
+    state-dict key ORDER / shapes / dtypes of gen.pt, dis.pt (and gen_ema.pt), and the layout of optim.pt as produced by
+    ``torch.optim.Adam(...).state_dict()`` on the reference modules after one step.  The tensors themselves (74 MB for
+    D_SNDCGAN) are not committed: tests rebuild files of exactly this structure with seeded values and load them
+    through --resume / --finetune on the GPU box."""
+    import json
+    from models.gan import get_architecture
+    out = {}
+    for arch, size in (('sndcgan', 32), ('stylegan2', 32)):
+        G, D = get_architecture(arch, (size, size, 3))
+        ent = {}
+        for tag, m in (('gen', G), ('dis', D)):
+            ent[tag] = [[k, list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()]
+            opt = torch.optim.Adam(m.parameters(), lr=2e-4, betas=(0.5, 0.999))
+            for prm in m.parameters():
+                prm.grad = torch.zeros_like(prm)
+            opt.step()
+            sdo = opt.state_dict()
+            groups = [{k: (list(v) if isinstance(v, tuple) else v) for k, v in g.items()} for g in sdo['param_groups']]
+            st0 = sdo['state'][0]
+            ent['optim_' + tag] = {
+                'param_groups': groups,
+                'n_state': len(sdo['state']),
+                'state_keys': list(st0.keys()),
+                'step': [str(type(st0['step']).__name__), str(getattr(st0['step'], 'dtype', '')),
+                         list(getattr(st0['step'], 'shape', []))],
+                'param_names': [k for k, _ in m.named_parameters()],
+            }
+        out[arch] = ent
+    out['optim_pt_keys'] = ['epoch', 'optim_G', 'optim_D']
+    out['torch'] = torch.__version__
+    path = os.path.join(HERE, 'checkpoint_manifest.json')
+    json.dump(out, open(path, 'w'), indent=0)
+    print('wrote checkpoint_manifest.json %7.1f KiB' % (os.path.getsize(path) / 1024))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['losses', 'augment', 'sndcgan', 'sndcgan_gstep', 'adam', 'stylegan2', 'stylegan2_g', 'stylegan2_512', 'stylegan2_gstep']
+    which = sys.argv[1:] or ['losses', 'augment', 'sndcgan', 'sndcgan_gstep', 'adam', 'stylegan2', 'stylegan2_g', 'stylegan2_512', 'stylegan2_gstep', 'checkpoint_manifest']
     for w in which:
         globals()['gen_' + w]()
     print('golden vectors OK')
