@@ -21,7 +21,37 @@ struct UpfirdnArgs {
   int major, in_h, in_w, minor;
   int kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0;
   int out_h, out_w;
+  // fused epilogue (all optional): v += addend;  out = v;  out2 = v * (act_ref > 0 ? gain : slope * gain)
+  const float* addend;
+  const float* act_ref;
+  float* out2;
+  float slope, gain;
 };
+
+// epilogue store of VW consecutive channels at flat element offset `off` of the output
+template <int VW>
+__device__ __forceinline__ void uf_store(const UpfirdnArgs& a, size_t off, float* v) {
+  if (a.addend) {
+#pragma unroll
+    for (int i = 0; i < VW; ++i) v[i] += a.addend[off + i];
+  }
+  if (a.out) {
+    if (VW == 4) *reinterpret_cast<float4*>(a.out + off) = make_float4(v[0], v[1 % VW], v[2 % VW], v[3 % VW]);
+    else a.out[off] = v[0];
+  }
+  if (a.out2) {
+    const float neg = a.slope * a.gain;
+    float w[VW];
+#pragma unroll
+    for (int i = 0; i < VW; ++i) w[i] = v[i] * (a.act_ref[off + i] > 0.f ? a.gain : neg);
+    if (VW == 4) *reinterpret_cast<float4*>(a.out2 + off) = make_float4(w[0], w[1 % VW], w[2 % VW], w[3 % VW]);
+    else a.out2[off] = w[0];
+  }
+}
+__device__ __forceinline__ void uf_store4(const UpfirdnArgs& a, size_t off, float4 v) {
+  float t[4] = {v.x, v.y, v.z, v.w};
+  uf_store<4>(a, off, t);
+}
 
 constexpr int MAX_FIR = 8;
 
@@ -67,9 +97,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(UpfirdnArgs a) {
         }
       }
     }
-    float* dst = a.out + (((size_t)m * a.out_h + oy) * a.out_w + ox) * a.minor + c;
-    if (VW == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1 % VW], acc[2 % VW], acc[3 % VW]);
-    else dst[0] = acc[0];
+    uf_store<VW>(a, (((size_t)m * a.out_h + oy) * a.out_w + ox) * a.minor + c, acc);
   }
 }
 
@@ -119,9 +147,181 @@ __global__ __launch_bounds__(256) void upfirdn2d_strip_kernel(UpfirdnArgs a) {
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
-      if (oy0 + r < a.out_h)
-        *reinterpret_cast<float4*>(a.out + (((size_t)m * a.out_h + oy0 + r) * a.out_w + ox) * a.minor + c) = acc[r];
+      if (oy0 + r < a.out_h) uf_store4(a, (((size_t)m * a.out_h + oy0 + r) * a.out_w + ox) * a.minor + c, acc[r]);
   }
+}
+
+// ---- 4x4 FIR specialisations (every upfirdn2d call of the StyleGAN2 discriminator / generator uses [1,3,3,1]^2) ----
+// Weights live in scalar registers (uniform loads of the flipped kernel), all tap loops are compile-time, each thread
+// owns a small output tile so that an input value it loads feeds several outputs from registers.
+struct Fir4 { float w[16]; };
+__device__ __forceinline__ Fir4 load_fir4(const float* k) {      // flipped: correlation with k[3-ky][3-kx]
+  Fir4 f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) f.w[e] = k[15 - e];
+  return f;
+}
+__device__ __forceinline__ void fma4(float4& acc, float w, const float4& v) {
+  acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+}
+
+// up = down = 1: tile of 4 (y) x 2 (x) outputs per thread and 4 channels: 7 x 5 loads feed 8 outputs (4.4 per output
+// instead of 16).  Blur in front of the strided convs and its backward.
+__global__ __launch_bounds__(256) void upfirdn4_u1d1_kernel(UpfirdnArgs a) {
+  const Fir4 f = load_fir4(a.kernel);
+  const int mv = a.minor >> 2;
+  const int sx = (a.out_w + 1) >> 1, sy = (a.out_h + 3) >> 2;
+  const long long total = (long long)a.major * sy * sx * mv;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % mv) * 4;
+  long long t = e / mv;
+  const int ox0 = (int)(t % sx) * 2;
+  t /= sx;
+  const int oy0 = (int)(t % sy) * 4;
+  const int m = (int)(t / sy);
+  const int ix0 = ox0 - a.pad_x0, iy0 = oy0 - a.pad_y0;
+  float4 acc[4][2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { acc[r][0] = make_float4(0.f, 0.f, 0.f, 0.f); acc[r][1] = acc[r][0]; }
+  const float* base = a.in + (size_t)m * a.in_h * a.in_w * a.minor + c;
+#pragma unroll
+  for (int dy = 0; dy < 7; ++dy) {
+    const int iy = iy0 + dy;
+    const bool vy = (unsigned)iy < (unsigned)a.in_h;
+    float4 v[5];
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) {
+      const int ix = ix0 + dx;
+      v[dx] = (vy && (unsigned)ix < (unsigned)a.in_w)
+                  ? *reinterpret_cast<const float4*>(base + ((size_t)iy * a.in_w + ix) * a.minor)
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ky = dy - r;
+      if (ky >= 0 && ky < 4) {
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+          fma4(acc[r][0], f.w[ky * 4 + kx], v[kx]);
+          fma4(acc[r][1], f.w[ky * 4 + kx], v[kx + 1]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (oy0 + r < a.out_h && ox0 + q < a.out_w)
+        uf_store4(a, (((size_t)m * a.out_h + oy0 + r) * a.out_w + ox0 + q) * a.minor + c, acc[r][q]);
+}
+
+// up = 1, down = 2: out[oy][ox] = sum k[ky][kx] in[2 oy + ky - pad][2 ox + kx - pad]; tile of 2 x 2 outputs per thread:
+// 6 x 6 loads feed 4 outputs (9 per output instead of 16).  Blur + decimation of the residual skip path.
+__global__ __launch_bounds__(256) void upfirdn4_u1d2_kernel(UpfirdnArgs a) {
+  const Fir4 f = load_fir4(a.kernel);
+  const int mv = a.minor >> 2;
+  const int sx = (a.out_w + 1) >> 1, sy = (a.out_h + 1) >> 1;
+  const long long total = (long long)a.major * sy * sx * mv;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % mv) * 4;
+  long long t = e / mv;
+  const int ox0 = (int)(t % sx) * 2;
+  t /= sx;
+  const int oy0 = (int)(t % sy) * 2;
+  const int m = (int)(t / sy);
+  const int ix0 = 2 * ox0 - a.pad_x0, iy0 = 2 * oy0 - a.pad_y0;
+  float4 acc[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) { acc[r][0] = make_float4(0.f, 0.f, 0.f, 0.f); acc[r][1] = acc[r][0]; }
+  const float* base = a.in + (size_t)m * a.in_h * a.in_w * a.minor + c;
+#pragma unroll
+  for (int dy = 0; dy < 6; ++dy) {
+    const int iy = iy0 + dy;
+    const bool vy = (unsigned)iy < (unsigned)a.in_h;
+    float4 v[6];
+#pragma unroll
+    for (int dx = 0; dx < 6; ++dx) {
+      const int ix = ix0 + dx;
+      v[dx] = (vy && (unsigned)ix < (unsigned)a.in_w)
+                  ? *reinterpret_cast<const float4*>(base + ((size_t)iy * a.in_w + ix) * a.minor)
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int ky = dy - 2 * r;
+      if (ky >= 0 && ky < 4) {
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+          fma4(acc[r][0], f.w[ky * 4 + kx], v[kx]);
+          fma4(acc[r][1], f.w[ky * 4 + kx], v[kx + 2]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (oy0 + r < a.out_h && ox0 + q < a.out_w)
+        uf_store4(a, (((size_t)m * a.out_h + oy0 + r) * a.out_w + ox0 + q) * a.minor + c, acc[r][q]);
+}
+
+// up = 2, down = 1 (zero-insertion upsampling: the backward of the decimating blur, and the generator's Upsample):
+// out[oy][ox] = sum_{ky,kx} k[ky][kx] z[oy + ky - pad_y0][ox + kx - pad_x0],  z[2i][2j] = in[i][j], zero elsewhere.
+// Each output sees a 2 x 2 subset of the taps; a thread produces the 2 x 2 output quad at (2 qy .. +1, 2 qx .. +1) from
+// the <= 3 x 3 input pixels it can touch (9 loads for 4 outputs instead of 16 tap tests each).
+__global__ __launch_bounds__(256) void upfirdn4_u2d1_kernel(UpfirdnArgs a) {
+  const Fir4 f = load_fir4(a.kernel);
+  const int mv = a.minor >> 2;
+  const int sx = (a.out_w + 1) >> 1, sy = (a.out_h + 1) >> 1;
+  const long long total = (long long)a.major * sy * sx * mv;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % mv) * 4;
+  long long t = e / mv;
+  const int ox0 = (int)(t % sx) * 2;
+  t /= sx;
+  const int oy0 = (int)(t % sy) * 2;
+  const int m = (int)(t / sy);
+  // zero-inserted coordinates touched by the quad: py in [oy0 - pad_y0, oy0 + 1 - pad_y0 + 3] (5 values) -> input rows
+  // ceil(lo / 2) .. floor(hi / 2): at most 3
+  const int py_lo = oy0 - a.pad_y0, px_lo = ox0 - a.pad_x0;
+  const int iy_lo = (py_lo + 1) >> 1, ix_lo = (px_lo + 1) >> 1;         // arithmetic shift == floor for negatives
+  float4 acc[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) { acc[r][0] = make_float4(0.f, 0.f, 0.f, 0.f); acc[r][1] = acc[r][0]; }
+  const float* base = a.in + (size_t)m * a.in_h * a.in_w * a.minor + c;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int iy = iy_lo + dy;
+    const bool vy = (unsigned)iy < (unsigned)a.in_h;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ix = ix_lo + dx;
+      if (!(vy && (unsigned)ix < (unsigned)a.in_w)) continue;
+      const float4 v = *reinterpret_cast<const float4*>(base + ((size_t)iy * a.in_w + ix) * a.minor);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int ky = 2 * iy - (oy0 + r - a.pad_y0);
+        if (ky < 0 || ky > 3) continue;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int kx = 2 * ix - (ox0 + q - a.pad_x0);
+          if (kx < 0 || kx > 3) continue;
+          fma4(acc[r][q], f.w[ky * 4 + kx], v);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (oy0 + r < a.out_h && ox0 + q < a.out_w)
+        uf_store4(a, (((size_t)m * a.out_h + oy0 + r) * a.out_w + ox0 + q) * a.minor + c, acc[r][q]);
 }
 
 // y = act(x + b[(i / step_b) % size_b]) * scale  (grad 0) | x * act'(ref) * scale (grad 1) | 0 (grad 2)
@@ -323,12 +523,14 @@ extern "C" int contrad_modconv_epilogue(const float* x, const float* demod, cons
   return 0;
 }
 
-extern "C" int contrad_upfirdn2d(const float* input, const float* kernel, float* out, int major, int in_h,
-                                 int in_w, int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
-                                 int pad_x0, int pad_x1, int pad_y0, int pad_y1, contrad_stream_t stream) {
-  CONTRAD_ARG(input && kernel && out && major > 0 && in_h > 0 && in_w > 0 && minor > 0);
+static int upfirdn2d_launch(const float* input, const float* kernel, float* out, int major, int in_h, int in_w,
+                            int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
+                            int pad_x1, int pad_y0, int pad_y1, const float* addend, const float* act_ref, float slope,
+                            float gain, float* out2, contrad_stream_t stream) {
+  CONTRAD_ARG(input && kernel && (out || out2) && major > 0 && in_h > 0 && in_w > 0 && minor > 0);
   CONTRAD_ARG(kh > 0 && kw > 0 && kh <= MAX_FIR && kw <= MAX_FIR);
   CONTRAD_ARG(up_x > 0 && up_y > 0 && down_x > 0 && down_y > 0);
+  CONTRAD_ARG(!out2 || act_ref);
   UpfirdnArgs a{};
   a.in = input; a.kernel = kernel; a.out = out;
   a.major = major; a.in_h = in_h; a.in_w = in_w; a.minor = minor;
@@ -336,23 +538,55 @@ extern "C" int contrad_upfirdn2d(const float* input, const float* kernel, float*
   a.pad_x0 = pad_x0; a.pad_y0 = pad_y0;
   a.out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) / down_y + 1;   // op/upfirdn2d_kernel.cu:227-228
   a.out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
+  a.addend = addend; a.act_ref = act_ref; a.out2 = out2; a.slope = slope; a.gain = gain;
   CONTRAD_ARG(a.out_h > 0 && a.out_w > 0);
+  hipStream_t s = (hipStream_t)stream;
   const bool vec = (minor & 3) == 0;
+  const bool fir4 = vec && kh == 4 && kw == 4 && up_x == up_y && down_x == down_y;
+  if (fir4 && up_x == 1 && down_x == 1) {
+    const long long tot = (long long)major * ((a.out_h + 3) / 4) * ((a.out_w + 1) / 2) * (minor / 4);
+    hipLaunchKernelGGL(upfirdn4_u1d1_kernel, dim3((unsigned)cdivll(tot, 256)), dim3(256), 0, s, a);
+    CONTRAD_CHECK_LAUNCH();
+    return 0;
+  }
+  if (fir4 && ((up_x == 1 && down_x == 2) || (up_x == 2 && down_x == 1))) {
+    const long long tot = (long long)major * ((a.out_h + 1) / 2) * ((a.out_w + 1) / 2) * (minor / 4);
+    if (down_x == 2) hipLaunchKernelGGL(upfirdn4_u1d2_kernel, dim3((unsigned)cdivll(tot, 256)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(upfirdn4_u2d1_kernel, dim3((unsigned)cdivll(tot, 256)), dim3(256), 0, s, a);
+    CONTRAD_CHECK_LAUNCH();
+    return 0;
+  }
   if (vec && up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && a.out_h >= 4) {
     const long long tot = (long long)major * ((a.out_h + 3) / 4) * a.out_w * (minor / 4);
     long long g = (tot + 255) / 256;
     if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(upfirdn2d_strip_kernel<4>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(upfirdn2d_strip_kernel<4>, dim3((int)g), dim3(256), 0, s, a);
     CONTRAD_CHECK_LAUNCH();
     return 0;
   }
   const long long total = (long long)major * a.out_h * a.out_w * (vec ? minor / 4 : minor);
   long long grid = (total + 255) / 256;
   if (grid > 16384) grid = 16384;
-  if (vec) hipLaunchKernelGGL(upfirdn2d_kernel<4>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(upfirdn2d_kernel<1>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a);
+  if (vec) hipLaunchKernelGGL(upfirdn2d_kernel<4>, dim3((int)grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(upfirdn2d_kernel<1>, dim3((int)grid), dim3(256), 0, s, a);
   CONTRAD_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int contrad_upfirdn2d(const float* input, const float* kernel, float* out, int major, int in_h,
+                                 int in_w, int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                                 int pad_x0, int pad_x1, int pad_y0, int pad_y1, contrad_stream_t stream) {
+  return upfirdn2d_launch(input, kernel, out, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0,
+                          pad_x1, pad_y0, pad_y1, nullptr, nullptr, 1.f, 1.f, nullptr, stream);
+}
+
+extern "C" int contrad_upfirdn2d_fused(const float* input, const float* kernel, float* out, int major, int in_h,
+                                       int in_w, int minor, int kh, int kw, int up_x, int up_y, int down_x,
+                                       int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* addend,
+                                       const float* act_ref, float slope, float gain, float* out2,
+                                       contrad_stream_t stream) {
+  return upfirdn2d_launch(input, kernel, out, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0,
+                          pad_x1, pad_y0, pad_y1, addend, act_ref, slope, gain, out2, stream);
 }
 
 extern "C" int contrad_fused_bias_act(const float* x, const float* bias, const float* ref, float* y, long long n,

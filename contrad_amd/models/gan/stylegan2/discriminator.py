@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .... import autograd_ops as A
+from .... import ops
 from ..base import BaseDiscriminator, PlainParams, TinyHead, _Act, make_projection
 
 _SLOPE, _GAIN = 0.2, math.sqrt(2.0)
@@ -85,6 +86,98 @@ def minibatch_stddev_nhwc(x, stddev_group=4):
     return torch.cat(parts, dim=3)
 
 
+class _TrunkFn(torch.autograd.Function):
+    """FromRGB + all ResBlocks as ONE first-order autograd node (the ContraD discriminator calls: augmented images are
+    constants there, so neither d/d images nor a double backward is needed; the R1 call and the generator step keep the
+    any-order node family).  What the fusion buys over the node-per-op graph:
+      * the residual merge (out + skip) / sqrt2 (discriminator.py:72-74) costs no scaling pass: 1/sqrt2 is folded into
+        the conv2 activation gain (sqrt2 / sqrt2 = 1) and into the packed skip weights;
+      * no FusedLeakyReLU backward pass (op/fused_act.py:20-55) and no gradient-accumulation add exists: the
+        transposed blur of the conv1 branch multiplies by act'(o) in its epilogue, and the transposed decimating blur
+        of the skip branch adds the conv1 branch's input gradient and emits BOTH the plain sum (for the next skip
+        branch) and the sum times act'(y2) (for the next conv2 branch) -- contrad_upfirdn2d_fused.
+    Inputs: images, blur kernel, then (wp, bias) of FromRGB and per block (wp1, b1, wp2, b2, wp_skip)."""
+
+    @staticmethod
+    def forward(ctx, D, images, kernel, *wb):
+        blocks = list(D.layers)[1:]
+        wp_rgb, b_rgb = wb[0], wb[1]
+        K0 = D.layers[0][0].weight.shape[0]
+        r0 = ops.rgb_conv_fwd(images, wp_rgb, b_rgb, K0, 1, 2.0, -1.0, _SLOPE, _GAIN)
+        saved, geo = [r0], []
+        x = r0
+        for bi, blk in enumerate(blocks):
+            wp1, b1, wp2, b2, wps = wb[2 + 5 * bi: 7 + 5 * bi]
+            ci, co = blk.cin, blk.cout
+            o = ops.conv2d_fwd(x, wp1, b1, ci, 3, 3, 1, 1, _SLOPE, _GAIN)
+            p0, p1 = blk.conv2[0].pad
+            ob = ops.upfirdn2d(o, kernel, 1, 1, (p0, p1, p0, p1))
+            y2 = ops.conv2d_fwd(ob, wp2, b2, co, 3, 3, 2, 0, _SLOPE, 1.0)         # gain sqrt2 * (1/sqrt2 of the merge)
+            q0, q1 = blk.skip[0].pad
+            sb = ops.upfirdn2d(x, kernel, 1, 2, (q0, q1, q0, q1))
+            sk = ops.conv2d_fwd(sb, wps, None, co, 1, 1, 1, 0)                    # skip weights carry the 1/sqrt2
+            xn = ops.lincomb(y2, sk, 1.0, 1.0)
+            saved += [x, o, ob, y2, sb]
+            geo.append((ci, co, (p0, p1), (q0, q1)))
+            x = xn
+        if getattr(D, '_record_activations', False):             # test hook: the linear regions actually used
+            D._trunk_rec = [r0] + [t for bi in range(len(blocks)) for t in (saved[2 + 5 * bi], saved[4 + 5 * bi])]
+        ctx.save_for_backward(images, kernel, *wb, *saved)
+        ctx.n_wb, ctx.geo = len(wb), geo
+        return x
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        t = ctx.saved_tensors
+        images, kernel = t[0], t[1]
+        wb = t[2:2 + ctx.n_wb]
+        saved = t[2 + ctx.n_wb:]
+        r0 = saved[0]
+        nb = len(ctx.geo)
+        gk = torch.flip(kernel, [0, 1]).contiguous()
+        grads = [None] * ctx.n_wb
+        g = g.contiguous()
+        gm = None                                   # g * act'(y2 of the current block)
+        for bi in range(nb - 1, -1, -1):
+            x, o, ob, y2, sb = saved[1 + 5 * bi: 6 + 5 * bi]
+            wp1, b1, wp2, b2, wps = wb[2 + 5 * bi: 7 + 5 * bi]
+            ci, co, (p0, p1), (q0, q1) = ctx.geo[bi]
+            if gm is None:
+                gm = ops.fused_bias_act(g, None, y2, 3, 1, _SLOPE, 1.0)
+            # conv2 (3x3 stride 2 on the blurred map)
+            gw2 = torch.zeros_like(wp2); gb2 = torch.empty_like(b2)
+            ops.conv2d_wgrad(ob, gm, 3, 3, 2, 0, out=gw2, dbias=gb2)
+            g_ob = ops.conv2d_dgrad(gm, wp2, tuple(ob.shape), 3, 3, 2, 0)
+            # blur^T, times act'(o) * sqrt2
+            gp = (4 - p0 - 1, o.shape[2] - ob.shape[2] + p0, 4 - p0 - 1, o.shape[1] - ob.shape[1] + p0)
+            _, g_o = ops.upfirdn2d_fused(g_ob, gk, 1, 1, gp, act_ref=o, slope=_SLOPE, gain=_GAIN, want_out=False,
+                                         want_out2=True)
+            del g_ob
+            gw1 = torch.zeros_like(wp1); gb1 = torch.empty_like(b1)
+            ops.conv2d_wgrad(x, g_o, 3, 3, 1, 1, out=gw1, dbias=gb1)
+            g_x1 = ops.conv2d_dgrad(g_o, wp1, tuple(x.shape), 3, 3, 1, 1)
+            del g_o
+            # skip branch (1x1 conv on the blurred + decimated map), driven by the un-masked g
+            gws = torch.zeros_like(wps)
+            ops.conv2d_wgrad(sb, g, 1, 1, 1, 0, out=gws)
+            g_sb = ops.conv2d_dgrad(g, wps, tuple(sb.shape), 1, 1, 1, 0)
+            gq = (4 - q0 - 1, x.shape[2] - sb.shape[2] * 2 + q0, 4 - q0 - 1, x.shape[1] - sb.shape[1] * 2 + q0)
+            if bi > 0:      # gradient of this block's input = previous block's output: plain sum + masked sum
+                y2_prev = saved[1 + 5 * (bi - 1) + 3]
+                g, gm = ops.upfirdn2d_fused(g_sb, gk, 2, 1, gq, addend=g_x1, act_ref=y2_prev, slope=_SLOPE, gain=1.0,
+                                            want_out=True, want_out2=True)
+            else:           # FromRGB output: only the masked sum is needed
+                _, gm = ops.upfirdn2d_fused(g_sb, gk, 2, 1, gq, addend=g_x1, act_ref=r0, slope=_SLOPE, gain=_GAIN,
+                                            want_out=False, want_out2=True)
+            del g_sb, g_x1
+            grads[2 + 5 * bi: 7 + 5 * bi] = [gw1, gb1, gw2, gb2, gws]
+        gw0 = torch.zeros_like(wb[0]); gb0 = torch.empty_like(wb[1])
+        ops.rgb_conv_wgrad(images, gm, 1, 2.0, -1.0, gw0, gb0)
+        grads[0], grads[1] = gw0, gb0
+        return (None, None, None) + tuple(grads)
+
+
 class ResidualDiscriminatorP(BaseDiscriminator):
     def __init__(self, size, channel_multiplier=2, blur_kernel=(1, 3, 3, 1), small32=False, mlp_linear=True,
                  d_hidden=512, d_project=128):
@@ -116,9 +209,11 @@ class ResidualDiscriminatorP(BaseDiscriminator):
         self.layers = nn.Sequential(*layers)
         self.last_conv = _conv_layer(in_channel + 1, channels[4], 3)
         self.c_last_in = in_channel
+        self.fuse_trunk = True          # (tests switch it off to compare the two graph constructions)
 
     # ---- weight packing plan -------------------------------------------------------------------------
-    def _pack(self):
+    def _pack(self, fused=False):
+        """``fused``: layout for _TrunkFn -- the skip weights carry the residual merge's 1/sqrt2."""
         ws, entries, groups = [], [], []
 
         def add(w, K, C, T, scale, group=None, col=0):
@@ -136,7 +231,8 @@ class ResidualDiscriminatorP(BaseDiscriminator):
             for name, seq, ci in (('conv1', blk.conv1, 0), ('conv2', blk.conv2, 1), ('skip', blk.skip, 1)):
                 m = seq[ci]
                 K, C, k, _ = m.weight.shape
-                idx[(bi, name)] = add(m.weight, K, C, k * k, m.scale)
+                idx[(bi, name)] = add(m.weight, K, C, k * k,
+                                      m.scale / math.sqrt(2.0) if (fused and name == 'skip') else m.scale)
         m = self.last_conv[0]
         cpad = A.ops.round_up(self.c_last_in + 1, 4)
         w_last = F.pad(m.weight, (0, 0, 0, 0, 0, cpad - (self.c_last_in + 1)))     # zero rows for the pad channels
@@ -155,6 +251,22 @@ class ResidualDiscriminatorP(BaseDiscriminator):
         return packed, idx
 
     # ---- forward ---------------------------------------------------------------------------------------
+    def _trunk_fused(self, images, wp, idx, rec=None):
+        wb = [wp[idx['rgb']], self.layers[0][1].bias]
+        for bi, blk in enumerate(list(self.layers)[1:]):
+            wb += [wp[idx[(bi, 'conv1')]], blk.conv1[1].bias, wp[idx[(bi, 'conv2')]], blk.conv2[2].bias,
+                   wp[idx[(bi, 'skip')]]]
+        blur = list(self.layers)[1].conv2[0].kernel
+        x = _TrunkFn.apply(self, images, blur, *wb)
+        if rec is not None:
+            rec.extend(self._trunk_rec)
+        x = minibatch_stddev_nhwc(x)
+        x = A.ConvBiasActFn.apply(x, wp[idx['last']], self.last_conv[1].bias,
+                                  (self.last_conv[0].weight.shape[0], 3, 3, 1, 1), _SLOPE, _GAIN)
+        if rec is not None:
+            rec.append(x)
+        return x
+
     def _trunk(self, images, wp, idx, rec=None):
         rgb = self.layers[0]
         K0 = rgb[0].weight.shape[0]
@@ -189,15 +301,19 @@ class ResidualDiscriminatorP(BaseDiscriminator):
     def _run(self, inputs, sg_linear, finetuning, want_features):
         if not inputs.is_cuda:
             raise RuntimeError('contrad_amd.ResidualDiscriminatorP runs on the MI355X HIP path only (no CPU fallback)')
-        wp, idx = self._pack()
+        # constant images (every ContraD discriminator call): one fused first-order node; images that need a gradient
+        # (R1's create_graph, the generator step): the any-order node family
+        fused = self.fuse_trunk and not (inputs.requires_grad and torch.is_grad_enabled()) and len(self.layers) > 1
+        wp, idx = self._pack(fused)
         images = inputs.contiguous().float()
         rec = [] if getattr(self, '_record_activations', False) else None     # test hook (linear regions used)
+        trunk = self._trunk_fused if fused else self._trunk
         if finetuning:
             with torch.no_grad():
-                x = self._trunk(images, wp, idx, rec)
+                x = trunk(images, wp, idx, rec)
             x = x.detach()
         else:
-            x = self._trunk(images, wp, idx, rec)
+            x = trunk(images, wp, idx, rec)
         B = x.shape[0]
         dh, dp = self.d_hidden, self.d_project
         feat = x.reshape(B, 1, 1, self.n_features)

@@ -472,6 +472,28 @@ def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0, 0, 0)):
     return out
 
 
+def upfirdn2d_fused(x, kernel, up=1, down=1, pad=(0, 0, 0, 0), addend=None, act_ref=None, slope=1.0, gain=1.0,
+                    want_out=True, want_out2=False):
+    """upfirdn2d with the fused epilogue: v = upfirdn2d(x) [+ addend]; returns (v or None, v * act'(act_ref) or None)."""
+    _chk(x, 'x'); _chk(kernel, 'kernel'); _chk(addend, 'addend'); _chk(act_ref, 'act_ref')
+    B, H, W, C = x.shape
+    kh, kw = kernel.shape
+    px0, px1, py0, py1 = pad
+    oh = (H * up + py0 + py1 - kh) // down + 1
+    ow = (W * up + px0 + px1 - kw) // down + 1
+    shape = (B, oh, ow, C)
+    for t, nm in ((addend, 'addend'), (act_ref, 'act_ref')):
+        if t is not None and (tuple(t.shape) != shape or not t.is_contiguous()):
+            raise RuntimeError('contrad_hip: upfirdn2d_fused %s must be a contiguous tensor of the output shape' % nm)
+    if not x.is_contiguous() or not kernel.is_contiguous() or (want_out2 and act_ref is None):
+        raise RuntimeError('contrad_hip: upfirdn2d_fused needs contiguous tensors (and act_ref for the second output)')
+    out = torch.empty(shape, device=x.device, dtype=torch.float32) if want_out else None
+    out2 = torch.empty(shape, device=x.device, dtype=torch.float32) if want_out2 else None
+    lib().call('contrad_upfirdn2d_fused', _p(x), _p(kernel), _p(out), B, H, W, C, kh, kw, up, up, down, down,
+               px0, px1, py0, py1, _p(addend), _p(act_ref), float(slope), float(gain), _p(out2), _stream())
+    return out, out2
+
+
 def fused_bias_act(x, bias, ref, act, grad, alpha, scale, channels_last_size=None):
     """Elementwise on a contiguous tensor whose LAST dim is the channel (NHWC / (M,K))."""
     _chk(x, 'x'); _chk(bias, 'bias'); _chk(ref, 'ref')

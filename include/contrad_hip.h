@@ -263,6 +263,14 @@ int contrad_gaussian_blur_masked_bwd(const float* grad_out, float* tmp, float* g
 int contrad_upfirdn2d(const float* input, const float* kernel, float* out, int major, int in_h, int in_w,
                       int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
                       int pad_x1, int pad_y0, int pad_y1, contrad_stream_t stream);
+/* The same op with a fused epilogue, used by the discriminator's first-order backward so that no separate elementwise
+ * pass exists (the reference runs FusedLeakyReLUFunctionBackward and the residual-gradient adds as their own kernels,
+ * op/fused_act.py:20-55, discriminator.py:72-74):  v = upfirdn2d(input) [+ addend];  out = v (if out != NULL);
+ * out2 = v * (act_ref > 0 ? gain : slope * gain) (if out2 != NULL).  addend / act_ref / out2 have the output's shape. */
+int contrad_upfirdn2d_fused(const float* input, const float* kernel, float* out, int major, int in_h, int in_w,
+                            int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
+                            int pad_x1, int pad_y0, int pad_y1, const float* addend, const float* act_ref, float slope,
+                            float gain, float* out2, contrad_stream_t stream);
 /* fused.fused_bias_act (op/fused_bias_act.cpp:11-21): act 1 linear / 3 leaky-relu(alpha); grad 0: y = act(x +
  * bias[(i/step_b) % size_b]) * scale; grad 1: y = x * act'(ref) * scale; grad 2: y = 0.  bias / ref may be NULL
  * where unused.  (FusedLeakyReLU and its first / second backward, op/fused_act.py:20-71.) */

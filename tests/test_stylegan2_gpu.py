@@ -189,3 +189,74 @@ def test_generator_forward_against_reference(golden):
         # sampling path runs (device RNG for the second latent / noise, CPU RNG for the masks)
         out = G(G.sample_latent(5))
         assert out.shape == (5, 3, 32, 32) and torch.isfinite(out).all()
+
+
+def _upfirdn_ref(x, k, up, down, pad):
+    """Plain-torch upfirdn2d on NHWC (B,H,W,C) with pad = (x0, x1, y0, y1): zero insertion, (possibly negative) padding,
+    correlation with the flipped kernel, decimation -- the contract of op/upfirdn2d_kernel.cu:209-243."""
+    import torch.nn.functional as F
+    B, H, W, C = x.shape
+    z = x.new_zeros(B, H * up, W * up, C)
+    z[:, ::up, ::up] = x
+    px0, px1, py0, py1 = pad
+    z = F.pad(z, (0, 0, max(px0, 0), max(px1, 0), max(py0, 0), max(py1, 0)))
+    z = z[:, max(-py0, 0): z.shape[1] - max(-py1, 0), max(-px0, 0): z.shape[2] - max(-px1, 0)]
+    zz = z.permute(0, 3, 1, 2).reshape(B * C, 1, z.shape[1], z.shape[2])
+    out = F.conv2d(zz, torch.flip(k, [0, 1]).view(1, 1, *k.shape))
+    out = out[:, :, ::down, ::down]
+    return out.reshape(B, C, out.shape[2], out.shape[3]).permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize('cfg', [(1, 1, (2, 2, 2, 2)), (1, 1, (1, 1, 1, 1)), (1, 1, (1, 2, 2, 1)), (1, 1, (-1, 2, 0, 1)),
+                                 (1, 2, (1, 1, 1, 1)), (1, 2, (2, 2, 2, 2)), (1, 2, (0, 1, 1, 0)),
+                                 (2, 1, (2, 1, 2, 1)), (2, 1, (1, 2, 1, 2)), (2, 1, (0, 3, 3, 0)), (2, 1, (2, 2, 1, 1))])
+@pytest.mark.parametrize('shape', [(2, 9, 11, 4), (3, 16, 16, 32), (1, 33, 7, 8), (2, 4, 5, 64)])
+def test_fir4_specialisations_against_plain_torch(cfg, shape):
+    """The 4x4-FIR kernels (up1/down1 tile 4x2, down 2 tile 2x2, up 2 quad) incl. odd sizes, asymmetric and negative pads."""
+    up, down, pad = cfg
+    g = torch.Generator().manual_seed(sum(shape) + up * 7 + down)
+    x = torch.randn(*shape, generator=g)
+    k = torch.rand(4, 4, generator=g)                       # NOT symmetric: catches a missing flip
+    want = _upfirdn_ref(x, k, up, down, pad)
+    if want.shape[1] <= 0 or want.shape[2] <= 0:
+        pytest.skip('empty output')
+    got = ops.upfirdn2d(x.to(DEV), k.to(DEV), up, down, pad)
+    assert tuple(got.shape) == tuple(want.shape)
+    assert rel(got, want) < 1e-5
+    # fused epilogue: addend, second output with the activation derivative of a reference tensor
+    addend = torch.randn(want.shape, generator=g)
+    ref = torch.randn(want.shape, generator=g)
+    o1, o2 = ops.upfirdn2d_fused(x.to(DEV), k.to(DEV), up, down, pad, addend=addend.to(DEV), act_ref=ref.to(DEV),
+                                 slope=0.2, gain=math.sqrt(2), want_out=True, want_out2=True)
+    v = want + addend
+    assert rel(o1, v) < 1e-5
+    assert rel(o2, v * torch.where(ref > 0, math.sqrt(2), 0.2 * math.sqrt(2))) < 1e-5
+    none, o2b = ops.upfirdn2d_fused(x.to(DEV), k.to(DEV), up, down, pad, act_ref=ref.to(DEV), slope=0.2, gain=1.0,
+                                    want_out=False, want_out2=True)
+    assert none is None and rel(o2b, want * torch.where(ref > 0, 1.0, 0.2)) < 1e-5
+
+
+@pytest.mark.parametrize('size,small32,N', [(32, True, 8), (64, False, 4)])
+def test_fused_trunk_equals_the_node_per_op_graph(size, small32, N):
+    """_TrunkFn (one first-order node: folded 1/sqrt2, activation derivatives and gradient sums in the blur epilogues)
+    against the any-order node family on the same weights and inputs: forward values and every parameter gradient."""
+    import copy
+    torch.manual_seed(size)
+    D = ResidualDiscriminatorP(size, small32=small32, channel_multiplier=1.0).to(DEV).train()
+    with torch.no_grad():
+        for k, p in D.named_parameters():
+            if k.endswith('bias'):
+                p.normal_(0, 0.1)
+    D2 = copy.deepcopy(D)
+    D2.fuse_trunk = False
+    x = torch.rand(N, 3, size, size, device=DEV)
+    outs = []
+    for m in (D, D2):
+        logit, aux = m(x, sg_linear=True, projection=True, projection2=True)
+        loss = (logit * 0.3).sum() + aux['projection'].pow(2).sum() + aux['projection2'].sin().sum()
+        loss.backward()
+        outs.append((logit.detach(), aux['projection'].detach()))
+    assert rel(outs[0][0], outs[1][0]) < 1e-4 and rel(outs[0][1], outs[1][1]) < 1e-4
+    for (k, p), q in zip(D.named_parameters(), D2.parameters()):
+        assert p.grad is not None and q.grad is not None, k
+        assert l2(p.grad, q.grad) < 1e-4, (k, l2(p.grad, q.grad))
