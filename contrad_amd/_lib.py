@@ -18,7 +18,7 @@ class ConvDesc(ctypes.Structure):
 SN_MAX_LAYERS = 24
 ADAM_MAX_TENSORS = 64
 ADAM_CHUNK = 16384
-AUG_NPARAM = 12
+AUG_NPARAM = 16
 
 
 class SnLayer(ctypes.Structure):

@@ -4,7 +4,7 @@
 The reference composes ~25 PyTorch ops per call (two grid_samples, HSV round trip, blends); here the random
 parameters are drawn on the HOST in the reference's exact RNG order (numpy global RNG for geometry / op order /
 blur sigma, torch CPU generator for masks and colour factors -- SURVEY.md 8a row A7), shipped as one small
-(B, 12) tensor, and a single fused HIP kernel does crop+flip+jitter+gray (plus a separable blur for *_hq).
+(B, 16) tensor, and a single fused HIP kernel does crop+flip+jitter+gray (plus a separable blur for *_hq).
 """
 import math
 
@@ -16,7 +16,7 @@ from .. import ops
 from ..hostio import upload
 from ..config import configurable, get_bindings
 
-__all__ = ['get_augment', 'SimCLRAugment', 'simclr', 'simclr_hq']
+__all__ = ['get_augment', 'SimCLRAugment', 'simclr', 'simclr_hq', 'simclr_hq_cutout']
 
 
 def _jitter_range(value, center=1.0, clip_first_on_zero=True):
@@ -38,7 +38,7 @@ class _SimCLRFn(torch.autograd.Function):
     (its reflect-padding transpose)."""
 
     @staticmethod
-    def forward(ctx, x, Pd, contrast_first, has_contrast, blur):
+    def forward(ctx, x, Pd, contrast_first, has_contrast, blur, cutout):
         out = ops.simclr_augment(x, Pd, contrast_first, has_contrast)
         if blur is not None:
             radius, g = blur
@@ -46,27 +46,32 @@ class _SimCLRFn(torch.autograd.Function):
             ctx.save_for_backward(x, Pd, g)
         else:
             ctx.save_for_backward(x, Pd)
-        ctx.cfg = (contrast_first, has_contrast, None if blur is None else blur[0])
+        if cutout is not None:
+            ops.cutout_masked_(out, Pd, cutout)
+        ctx.cfg = (contrast_first, has_contrast, None if blur is None else blur[0], cutout)
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
-        cf, hc, radius = ctx.cfg
+        cf, hc, radius, cutout = ctx.cfg
+        if cutout is not None:
+            g = ops.cutout_masked_(g.contiguous().clone(), ctx.saved_tensors[1], cutout)
         if radius is not None:
             x, Pd, gk = ctx.saved_tensors
             g = ops.gaussian_blur_masked_bwd(g, Pd, gk, radius)
         else:
             x, Pd = ctx.saved_tensors
-        return ops.simclr_augment_bwd(x, Pd, g, cf, hc), None, None, None, None
+        return ops.simclr_augment_bwd(x, Pd, g, cf, hc), None, None, None, None, None
 
 
 class SimCLRAugment(nn.Module):
     """RandomResizeCrop -> HorizontalFlip -> RandomApply(ColorJitter, 0.8) -> RandomApply(Gray, 0.2)
-    [-> RandomApply(GaussianBlur, 0.5)] as one module; maps NCHW float [0,1] to the same shape."""
+    [-> RandomApply(GaussianBlur, 0.5)] [-> RandomApply(CutOut, 0.5)] as one module; maps NCHW float [0,1] to the same
+    shape."""
 
     def __init__(self, scale, ratio=(3. / 4., 4. / 3.), brightness=0.4, contrast=0.4, saturation=0.4, hue=0.1,
-                 p_jitter=0.8, p_gray=0.2, p_blur=None, sigma_range=None):
+                 p_jitter=0.8, p_gray=0.2, p_blur=None, sigma_range=None, p_cutout=None, cutout_length=None):
         super().__init__()
         self.scale, self.ratio = tuple(scale), tuple(ratio)
         self.r_v = _jitter_range(brightness)
@@ -77,6 +82,9 @@ class SimCLRAugment(nn.Module):
             raise ValueError('hue values should be between (-0.5, 0.5)')
         self.p_jitter, self.p_gray, self.p_blur = p_jitter, p_gray, p_blur
         self.sigma_range = sigma_range
+        self.p_cutout, self.cutout_length = p_cutout, cutout_length
+        if p_cutout is not None and (cutout_length is None or cutout_length % 2 == 0):
+            raise ValueError("Currently CutOut only accepts odd lengths: length % 2 == 1")        # spatial.py:156-157
 
     # ---- host-side sampling, reference draw order ----
     def sample(self, B, dim2, dim3):
@@ -129,6 +137,10 @@ class SimCLRAugment(nn.Module):
         if self.p_blur is not None:
             P[:, 11] = torch.bernoulli(torch.full((B,), self.p_blur))
             sigma = float(np.random.uniform(*self.sigma_range))
+        if self.p_cutout is not None:        # RandomApply mask, then CutOut's two randint draws (spatial.py:166-170)
+            P[:, 12] = torch.bernoulli(torch.full((B,), self.p_cutout))
+            P[:, 13] = torch.randint(dim2, (B, 1)).view(B).float()
+            P[:, 14] = torch.randint(dim3, (B, 1)).view(B).float()
         return P, contrast_first, sigma
 
     @staticmethod
@@ -148,13 +160,16 @@ class SimCLRAugment(nn.Module):
                 radius, g = self.blur_kernel(inputs.shape[2], sigma)
                 if radius > 0:
                     blur = (radius, g.to(inputs.device))
-            return _SimCLRFn.apply(inputs.contiguous().float(), Pd, contrast_first, self.r_c is not None, blur)
+            return _SimCLRFn.apply(inputs.contiguous().float(), Pd, contrast_first, self.r_c is not None, blur,
+                                   self.cutout_length if self.p_cutout is not None else None)
         x = inputs.detach().contiguous().float()
         out = ops.simclr_augment(x, Pd, contrast_first, self.r_c is not None)
         if sigma is not None:
             radius, g = self.blur_kernel(x.shape[2], sigma)
             if radius > 0:
                 out = ops.gaussian_blur_masked(out, Pd, g.to(x.device), radius)
+        if self.p_cutout is not None:
+            ops.cutout_masked_(out, Pd, self.cutout_length)
         return out
 
     def forward(self, inputs):
@@ -181,10 +196,16 @@ def simclr_hq():
     return SimCLRAugment(p_blur=0.5, sigma_range=gb['sigma_range'], **_kwargs_from_bindings())
 
 
+def simclr_hq_cutout():
+    gb = get_bindings('GaussianBlur')
+    return SimCLRAugment(p_blur=0.5, sigma_range=gb['sigma_range'], p_cutout=0.5,
+                         cutout_length=get_bindings('CutOut')['length'], **_kwargs_from_bindings())
+
+
 @configurable('augment')
 def get_augment(mode='none', **kwargs):
     """Same entry point as augment.get_augment (augment/__init__.py:13-28) for the modes on the hot path."""
-    mapping = {'simclr': simclr, 'simclr_hq': simclr_hq}
+    mapping = {'simclr': simclr, 'simclr_hq': simclr_hq, 'simclr_hq_cutout': simclr_hq_cutout}
     if mode not in mapping:
         raise NotImplementedError("augmentation mode '%s' is outside the ContraD hot path (SURVEY.md 2 row 6)" % mode)
     return mapping[mode]()

@@ -133,6 +133,23 @@ class ActBwdFn(Function):
         return ActBwdFn.apply(h, y, slope, gain), None, None, None
 
 
+class ActFn(Function):
+    """y = gain * lrelu_slope(x) (F.leaky_relu after a residual add, models/gan/snresnet.py:40); any-order."""
+
+    @staticmethod
+    def forward(ctx, x, slope, gain):
+        y = ops.fused_bias_act(_cont(x), None, None, 3, 0, slope, gain)
+        ctx.save_for_backward(y)
+        ctx.cfg = (slope, gain)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, = ctx.saved_tensors
+        slope, gain = ctx.cfg
+        return ActBwdFn.apply(g, y, slope, gain), None, None
+
+
 class ColSumFn(Function):
     """Bias gradient: sum over all leading dims of an (..., K) tensor."""
 
@@ -435,6 +452,40 @@ class ModconvEpilogueFn(Function):
         gnw = ops.nhwc_dot(g_pre, noise, per_channel=False).sum().reshape(1) if ctx.needs_input_grad[3] else None
         gb = ops.colstats(g_pre.view(-1, g_pre.shape[-1]))[0] if ctx.needs_input_grad[4] else None
         return gy, gdemod, None, gnw, gb
+
+
+class SnPackWeightsFn(Function):
+    """Spectral-norm weight preparation as an autograd node (torch.nn.utils.spectral_norm's pre-forward hook + its
+    autograd, applied to every Conv2d / Linear of a discriminator: sndcgan.py:111-118, snresnet.py:59-66): ONE batched
+    launch runs the power iteration of every layer (train mode; ``weight_u`` / ``weight_v`` updated in place), computes
+    sigma = u^T W v and writes W / sigma in the packed GEMM layout; the backward maps the packed gradients to
+    d loss / d weight_orig = G / sigma - (<G, W> / sigma^2) u v^T with the u, v of THIS forward.  First-order."""
+
+    @staticmethod
+    def forward(ctx, mods, training, *ws):
+        dev = ws[0].device
+        specs = [ops.SnSpec(w, m.weight_u, m.weight_v) for m, w in zip(mods, ws)]
+        ldws = [ops.round_up(sp.K, 4) for sp in specs]
+        outs = [torch.zeros(sp.T * sp.C, ld, device=dev, dtype=torch.float32) for sp, ld in zip(specs, ldws)]
+        offs, n = ops.sn_scratch_floats(specs)
+        scratch = torch.empty(n, device=dev, dtype=torch.float32)
+        sigma = torch.empty(len(specs), device=dev, dtype=torch.float32)
+        u_snaps = [torch.empty(sp.K, device=dev, dtype=torch.float32) for sp in specs]
+        v_snaps = [torch.empty(sp.C * sp.T, device=dev, dtype=torch.float32) for sp in specs]
+        ops.sn_weight_prep(specs, outs, ldws, training, scratch, offs, sigma, u_snaps, v_snaps)
+        ctx.state = (specs, ldws, offs, n, sigma, u_snaps, v_snaps, outs)
+        return tuple(outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gouts):
+        specs, ldws, offs, n, sigma, u_snaps, v_snaps, outs = ctx.state
+        dev = outs[0].device
+        gwps = [(_cont(g) if g is not None else torch.zeros_like(o)) for g, o in zip(gouts, outs)]
+        gws = [torch.empty_like(sp.w) for sp in specs]
+        scratch = torch.empty(n, device=dev, dtype=torch.float32)
+        ops.sn_weight_grad(specs, outs, ldws, gwps, gws, scratch, offs, sigma, u_snaps, v_snaps)
+        return (None, None) + tuple(gws)
 
 
 def make_blur_kernel(k=(1, 3, 3, 1)):

@@ -7,6 +7,7 @@
 //   params[n][4]     = flip sign (+1 / -1)                  (spatial.py:89-90)
 //   params[n][5]     = colour-jitter mask, [6] = contrast factor, [7..9] = f_h, f_s, f_v
 //   params[n][10]    = gray mask, [11] = blur mask (used by the blur kernels only)
+//   params[n][12..14]= cutout mask, cutout row centre, cutout column centre (used by the cutout kernel only)
 //
 // Small images (3*H*W*4 B <= 64 KiB: CIFAR 32x32, up to 64x64): one block per image, the image lives in LDS
 // between stages so the per-channel contrast mean costs no extra HBM pass.
@@ -525,6 +526,20 @@ __global__ __launch_bounds__(256) void simclr_bwd_gather_y_kernel(AugArgs a, con
   }
 }
 
+// RandomApply(CutOut) (augment/spatial.py:152-181): zero a (length x length) window, clipped at the borders
+__global__ void cutout_kernel(float* __restrict__ y, const float* __restrict__ params, int H, int W, int half) {
+  const int n = blockIdx.y;
+  const float* pr = params + (size_t)n * NPARAM;
+  if (pr[12] == 0.f) return;
+  const int hc = (int)pr[13], wc = (int)pr[14];
+  const int side = 2 * half + 1;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 3 * side * side) return;
+  const int c = e / (side * side), r = e - c * side * side;
+  const int i = hc - half + r / side, j = wc - half + r % side;
+  if ((unsigned)i < (unsigned)H && (unsigned)j < (unsigned)W) y[(((size_t)n * 3 + c) * H + i) * W + j] = 0.f;
+}
+
 // ---------------- adjoint of the masked separable Gaussian blur (reflect padding) ----------------
 // forward (one axis): out[i] = sum_t g[t] in[reflect(i + t - R)].  Adjoint: din[y] = sum over the pre-images p of y
 // under the reflection (p = y, p = -y for 1 <= y <= R, p = 2(n-1) - y for n-1-R <= y <= n-2) of the zero-padded
@@ -625,6 +640,16 @@ extern "C" int contrad_simclr_augment_bwd(const float* x, const float* params, c
   hipLaunchKernelGGL(simclr_bwd_gather_x_kernel, dim3(B, gy), dim3(256), 0, s, a, GM, partial2, nparts, T);
   CONTRAD_CHECK_LAUNCH();
   hipLaunchKernelGGL(simclr_bwd_gather_y_kernel, dim3(B, gy), dim3(256), 0, s, a, T, grad_in);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int contrad_cutout_masked(float* y, const float* params, int B, int H, int W, int length,
+                                     contrad_stream_t stream) {
+  CONTRAD_ARG(y && params && B > 0 && H > 0 && W > 0 && length > 0 && (length & 1));
+  const int half = (length - 1) / 2;
+  hipLaunchKernelGGL(cutout_kernel, dim3(cdiv(3 * length * length, 256), B), dim3(256), 0, (hipStream_t)stream, y, params,
+                     H, W, half);
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }

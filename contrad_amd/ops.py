@@ -550,6 +550,16 @@ def simclr_augment_bwd(x, params, grad_out, contrast_first, has_contrast):
     return gin
 
 
+def cutout_masked_(y, params, length):
+    """In place on a contiguous NCHW batch: RandomApply(CutOut(length)); also its own backward."""
+    _chk(y, 'y'); _chk(params, 'params')
+    if not y.is_contiguous():
+        raise RuntimeError('contrad_hip: cutout needs a contiguous NCHW batch')
+    B, C, H, W = y.shape
+    lib().call('contrad_cutout_masked', _p(y), _p(params), B, H, W, int(length), _stream())
+    return y
+
+
 def gaussian_blur_masked_bwd(grad_out, params, kernel1d, radius):
     B, C, H, W = grad_out.shape
     tmp = torch.empty_like(grad_out)

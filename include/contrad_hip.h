@@ -225,9 +225,10 @@ int contrad_pull_host(const float* host_pinned, float* dst, long long n, contrad
  * gather, RandomApply(ColorJitterLayer) (augment/color_jitter.py:16-104, augment/utils.py:6-63),
  * RandomApply(RandomColorGrayLayer) (augment/__init__.py:82-103).  NCHW in, NCHW out, x != y.
  * params[B][CONTRAD_AUG_NPARAM] = {theta00, theta11, theta02, theta12, flip_sign, jitter_mask,
- * f_contrast, f_h, f_s, f_v, gray_mask, blur_mask}, sampled on the host in the reference's draw order.
+ * f_contrast, f_h, f_s, f_v, gray_mask, blur_mask, cutout_mask, cutout_h_center, cutout_w_center, (spare)},
+ * sampled on the host in the reference's draw order.
  * ---------------------------------------------------------------------------------------------- */
-#define CONTRAD_AUG_NPARAM 12
+#define CONTRAD_AUG_NPARAM 16
 long long contrad_simclr_workspace_bytes(int B, int H, int W);
 int contrad_simclr_augment(const float* x, float* y, const float* params, int B, int H, int W,
                            int contrast_first, int has_contrast, float* workspace,
@@ -246,6 +247,10 @@ int contrad_simclr_augment_bwd(const float* x, const float* params, const float*
 int contrad_gaussian_blur_masked(const float* x, float* tmp, float* y, const float* params,
                                  const float* kernel1d, int B, int H, int W, int radius,
                                  contrad_stream_t stream);
+/* RandomApply(CutOut(length)) (augment/spatial.py:152-181; the last stage of `simclr_hq_cutout`, augment/__init__.py:
+ * 124-133): in place, y[n,:,i,j] = 0 where |i - h_center| <= (length-1)/2 and |j - w_center| <= (length-1)/2, on the
+ * samples whose cutout_mask != 0.  The op is its own backward (a 0/1 mask on the gradient). */
+int contrad_cutout_masked(float* y, const float* params, int B, int H, int W, int length, contrad_stream_t stream);
 /* Adjoint of contrad_gaussian_blur_masked (the generator step through simclr_hq): grad_in = blur^T(grad_out) on the
  * masked samples (reflect-padding transpose: border contributions fold back), copy-through otherwise. */
 int contrad_gaussian_blur_masked_bwd(const float* grad_out, float* tmp, float* grad_in, const float* params,

@@ -33,6 +33,9 @@ SIMCLR_HQ_AFHQ = dict(scale=(0.08, 1.0), ratio=(3. / 4., 4. / 3.), brightness=0.
                       sigma_range=(0.1, 2.0))                                   # afhq_dog_style64.gin:16-20
 
 
+SIMCLR_HQ_CUTOUT_AFHQ = dict(SIMCLR_HQ_AFHQ, p_cutout=0.5, cutout_length=15)   # augment/__init__.py:124-133, augment.gin:16
+
+
 def _jitter_range(value, center=1.0, clip_first_on_zero=True):
     """ColorJitterLayer._check_input for a scalar (augment/color_jitter.py:25-42)."""
     lo, hi = center - value, center + value
@@ -117,6 +120,11 @@ def sample_simclr_params(B, H, W, cfg):
     if 'p_blur' in cfg:
         p['blur_mask'] = torch.bernoulli(torch.full((B,), cfg['p_blur']))
         p['sigma'] = float(np.random.uniform(*cfg['sigma_range']))            # augment/__init__.py:73
+    if 'p_cutout' in cfg:
+        p['cut_mask'] = torch.bernoulli(torch.full((B,), cfg['p_cutout']))
+        p['cut_h'] = torch.randint(H, (B, 1)).view(B)                         # spatial.py:169-170
+        p['cut_w'] = torch.randint(W, (B, 1)).view(B)
+        p['cut_length'] = cfg['cutout_length']
     return p
 
 
@@ -235,6 +243,17 @@ def gaussian_blur(x, sigma):
     return F.conv2d(xp, k2, groups=C)
 
 
+def cutout(x, h_center, w_center, length):
+    """CutOut.forward (augment/spatial.py:163-181) with explicit centres."""
+    N, _, h, w = x.shape
+    mask_h = x.new_zeros(N, h).scatter_(1, h_center.view(N, 1), 1).unsqueeze(1)
+    mask_w = x.new_zeros(N, w).scatter_(1, w_center.view(N, 1), 1).unsqueeze(1)
+    wgt = torch.ones(1, 1, length)
+    mask_h = F.conv1d(mask_h, wgt, padding=(length - 1) // 2)
+    mask_w = F.conv1d(mask_w, wgt, padding=(length - 1) // 2)
+    return x * (1. - torch.einsum('bci,bcj->bcij', mask_h, mask_w))
+
+
 def simclr_apply(x, p):
     """nn.Sequential of simclr()/simclr_hq() with explicit parameters ``p``."""
     x = resized_crop(x, p['theta'])
@@ -244,6 +263,8 @@ def simclr_apply(x, p):
     x = blend(x, color_gray(x), p['gray_mask'])
     if 'blur_mask' in p:
         x = blend(x, gaussian_blur(x, p['sigma']), p['blur_mask'])
+    if 'cut_mask' in p:
+        x = blend(x, cutout(x, p['cut_h'], p['cut_w'], p['cut_length']), p['cut_mask'])
     return x
 
 
@@ -383,6 +404,72 @@ def sndcgan_d_forward(sd, x, sg_linear=False, training=True, act_masks=None, hid
     feats = sndcgan_d_features(sd, x, training, act_masks)
     out, proj, proj2 = d_heads(sd, feats, sg_linear, training, hidden_masks)
     return out, proj, proj2, feats
+
+
+# ----------------------------------------------------------------------------------------------
+# D_SNResNet18 (models/gan/snresnet.py:21-89, built at models/gan/__init__.py:8-12 with d_hidden=1024)
+# ----------------------------------------------------------------------------------------------
+SNRESNET18_STAGES = [(64, 1), (128, 2), (256, 2), (512, 2)]      # (planes, stride of the first block), 2 blocks each
+
+
+def snresnet18_blocks():
+    """[(prefix, in_planes, planes, stride, has_shortcut)] in module order (snresnet.py:68-75)."""
+    out, inp = [], 64
+    for li, (planes, stride) in enumerate(SNRESNET18_STAGES, 1):
+        for bi, s in enumerate([stride, 1]):
+            out.append(('layer%d.%d' % (li, bi), inp, planes, s, s != 1 or inp != planes))
+            inp = planes
+    return out
+
+
+def snresnet18_param_shapes(d_hidden=1024, d_project=128):
+    shapes = {}
+
+    def sn(prefix, wshape):
+        out = wshape[0]
+        shapes[prefix + '.bias'] = (out,)
+        shapes[prefix + '.weight_orig'] = tuple(wshape)
+        shapes[prefix + '.weight_u'] = (out,)
+        shapes[prefix + '.weight_v'] = (int(np.prod(wshape[1:])),)
+
+    sn('linear.l1', (d_hidden, 512)); sn('linear.l2', (1, d_hidden))
+    sn('projection.0', (d_hidden, 512)); sn('projection.2', (d_project, d_hidden))
+    sn('projection2.0', (d_hidden, 512)); sn('projection2.2', (d_project, d_hidden))
+    sn('conv1', (64, 3, 3, 3))
+    for pre, inp, planes, s, sc in snresnet18_blocks():
+        sn(pre + '.conv1', (planes, inp, 3, 3))
+        sn(pre + '.conv2', (planes, planes, 3, 3))
+        if sc:
+            sn(pre + '.shortcut.0', (planes, inp, 1, 1))
+    return shapes
+
+
+def snresnet18_features(sd, x, training=True):
+    """SNResNet.penultimate (snresnet.py:77-89) with BasicBlock.forward (:36-41)."""
+    def conv(pre, h, stride, pad):
+        return F.conv2d(h, spectral_norm_weight(sd, pre, training), sd[pre + '.bias'], stride=stride, padding=pad)
+    h = F.leaky_relu(conv('conv1', x * 2. - 1., 1, 1), 0.1)
+    for pre, inp, planes, s, sc in snresnet18_blocks():
+        o = F.leaky_relu(conv(pre + '.conv1', h, s, 1), 0.1)
+        o = conv(pre + '.conv2', o, 1, 1)
+        o = o + (conv(pre + '.shortcut.0', h, s, 0) if sc else h)
+        h = F.leaky_relu(o, 0.1)
+    h = F.avg_pool2d(h, 4)
+    return h.reshape(h.size(0), -1)
+
+
+def snresnet18_forward(sd, x, sg_linear=False, training=True):
+    feats = snresnet18_features(sd, x, training)
+    out, proj, proj2 = d_heads(sd, feats, sg_linear, training)
+    return out, proj, proj2, feats
+
+
+def simclr_only_loss_d(d_forward, images_aug2n, N, temp=0.1):
+    """simclr_only.loss_D_fn (training/gan/simclr_only.py:9-21) on already-augmented cat([x, x]):
+    d_forward(x) -> (logits, projection)."""
+    d, proj = d_forward(images_aug2n)
+    views = F.normalize(proj + d.mean() * 0)
+    return nt_xent(views[:N], views[N:], temperature=temp)
 
 
 def gan_g_loss(d_gen, kind):

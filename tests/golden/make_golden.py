@@ -184,6 +184,19 @@ def gen_augment():
     check(mine, ref, 1e-6, 'simclr_hq')
     out.update({'hq_x': x, 'hq_out': ref, 'hq_seed': 5})
     out.update({'hq_' + k: v for k, v in _param_dict(p).items()})
+
+    # --- simclr_hq_cutout (augment/__init__.py:124-133), CutOut.length = 15 (augment.gin) ---
+    _refshim.bind('CutOut', length=15)
+    B = 8
+    g = torch.Generator().manual_seed(322)
+    x = torch.rand(B, 3, 64, 64, generator=g)
+    torch.manual_seed(6); np.random.seed(6)
+    ref = A.simclr_hq_cutout()(x)
+    torch.manual_seed(6); np.random.seed(6)
+    p = O.sample_simclr_params(B, 64, 64, O.SIMCLR_HQ_CUTOUT_AFHQ)
+    check(O.simclr_apply(x, p), ref, 1e-6, 'simclr_hq_cutout')
+    out.update({'cut_x': x, 'cut_out': ref, 'cut_seed': 6})
+    out.update({'cut_' + k: v for k, v in _param_dict(p).items()})
     _refshim.bind_cifar_defaults()
     save('augment', **out)
 
@@ -747,8 +760,76 @@ def gen_checkpoint_manifest():
     print('wrote checkpoint_manifest.json %7.1f KiB' % (os.path.getsize(path) / 1024))
 
 
+# ------------------------------------------------------------------------------------------------
+def gen_snresnet():
+    """Scope row N4: D_SNResNet18 (models/gan/snresnet.py, built by get_architecture('snresnet18')) under the ContraD
+    discriminator loss, and the simclr_only mode (training/gan/simclr_only.py) on the same network."""
+    from models.gan import get_architecture
+    from training.gan import contrad as ref_contrad
+    from training.gan import simclr_only as ref_so
+    from argparse import Namespace
+    G, D = get_architecture('snresnet18', (32, 32, 3))
+    D.train()
+    shapes = O.snresnet18_param_shapes()
+    ref_shapes = {k: tuple(v.shape) for k, v in D.state_dict().items()}
+    assert ref_shapes == shapes, set(ref_shapes) ^ set(shapes)
+    assert list(ref_shapes) == list(shapes), 'snresnet state-dict ORDER'
+    sd = O.det_fill(shapes, seed=1818, weight_std=0.05)
+    N = 4
+    g = torch.Generator().manual_seed(181)
+    x = torch.rand(N, 3, 32, 32, generator=g)
+    fake = torch.rand(N, 3, 32, 32, generator=g)
+    aug = torch.rand(3 * N, 3, 32, 32, generator=g)
+    out = {'x': x, 'fake': fake, 'aug': aug, 'N': N, 'wseed': 1818}
+    for mode in ('contrad', 'simclr_only'):
+        _load_sd(D, sd)
+        P = Namespace(augment_fn=lambda t: aug[:t.size(0)], temp=0.1, lbd_a=1.0, distributed=False)
+        D.zero_grad()
+        fn = ref_contrad.loss_D_fn if mode == 'contrad' else ref_so.loss_D_fn
+        d_loss, aux = fn(P, D, {'loss': 'nonsat'}, x, fake)
+        (d_loss + aux['penalty']).backward()
+        ref_grads = {k: (v.grad.clone() if v.grad is not None else torch.zeros_like(v)) for k, v in D.named_parameters()}
+        ref_after = {k: v.clone() for k, v in D.state_dict().items()}
+        osd = {k: v.clone() for k, v in sd.items()}
+        for k in osd:
+            if k.endswith('weight_orig') or k.endswith('bias'):
+                osd[k].requires_grad_()
+        if mode == 'contrad':
+            closs, gloss, _, _ = O.contrad_loss_d(lambda t: O.snresnet18_forward(osd, t, sg_linear=True)[:3], aug, N)
+            (closs + gloss).backward()
+            check(closs, d_loss, 1e-6, 'snresnet contrad'); check(gloss, aux['penalty'], 1e-6, 'snresnet gan')
+            out.update({'contrad_loss': d_loss, 'gan_loss': aux['penalty']})
+        else:
+            l = O.simclr_only_loss_d(lambda t: O.snresnet18_forward(osd, t)[:2], aug[:2 * N], N)
+            l.backward()
+            check(l, d_loss, 1e-6, 'simclr_only loss')
+            assert aux['penalty'].item() == 0.0
+            out['simclr_only_loss'] = d_loss
+        gerr = 0.0
+        for k, gref in ref_grads.items():
+            og = osd[k].grad if osd[k].grad is not None else torch.zeros_like(gref)
+            gerr = max(gerr, check(og, gref, 2e-5, 'snresnet %s grad %s' % (mode, k)))
+        for k in osd:
+            if k.endswith('weight_u'):
+                check(osd[k], ref_after[k], 1e-6, 'snresnet sn buffer ' + k)
+        print('  snresnet18 %s: max grad err oracle vs reference %.2e' % (mode, gerr))
+        for k, gref in ref_grads.items():
+            out['%s/gradnorm/%s' % (mode, k)] = gref.norm()
+            if gref.numel() <= 2048:
+                out['%s/grad/%s' % (mode, k)] = gref
+        if mode == 'contrad':
+            for k in ('conv1.weight_u', 'layer4.1.conv2.weight_u', 'linear.l1.weight_u'):
+                out['after/' + k] = ref_after[k]
+    _load_sd(D, sd)
+    with torch.no_grad():
+        logit, auxo = D(aug, sg_linear=True, projection=True, projection2=True, penultimate=True)
+    out.update({'logit': logit, 'projection': auxo['projection'], 'projection2': auxo['projection2'],
+                'penultimate': auxo['penultimate']})
+    save('snresnet', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['losses', 'augment', 'sndcgan', 'sndcgan_gstep', 'adam', 'stylegan2', 'stylegan2_g', 'stylegan2_512', 'stylegan2_gstep', 'checkpoint_manifest']
+    which = sys.argv[1:] or ['losses', 'augment', 'sndcgan', 'sndcgan_gstep', 'adam', 'stylegan2', 'stylegan2_g', 'stylegan2_512', 'stylegan2_gstep', 'checkpoint_manifest', 'snresnet']
     for w in which:
         globals()['gen_' + w]()
     print('golden vectors OK')

@@ -160,3 +160,44 @@ def test_simclr_hq_at_512_matches_oracle():
     q = O.sample_simclr_params(B, H, H, O.SIMCLR_HQ_AFHQ)
     assert cf2 == q['contrast_first'] and abs(s2 - q['sigma']) < 1e-12
     assert torch.equal(P2[:, 11], q['blur_mask']) and torch.equal(P2[:, 0], q['theta'][:, 0, 0])
+
+
+def test_simclr_hq_cutout_against_reference_golden(golden):
+    """Scope row N4: `simclr_hq_cutout` (augment/__init__.py:124-133) = simclr_hq + RandomApply(CutOut(15), 0.5); golden
+    from the reference pipeline, host sampler reproduces the draw order incl. CutOut's two randint draws."""
+    from contrad_amd import config
+    from contrad_amd.augment import get_augment
+    import os
+    g = golden('augment')
+    x = torch.from_numpy(g['cut_x'])
+    B = x.shape[0]
+    P = _params(B, theta=torch.from_numpy(g['cut_p_theta']), flip=g['cut_p_flip_sign'], jitter=g['cut_p_jitter_mask'],
+                fc=g['cut_p_f_contrast'], fh=g['cut_p_f_h'], fs=g['cut_p_f_s'], fv=g['cut_p_f_v'],
+                gray=g['cut_p_gray_mask'], blur=g['cut_p_blur_mask'])
+    P[:, 12] = torch.from_numpy(g['cut_p_cut_mask'])
+    P[:, 13] = torch.from_numpy(g['cut_p_cut_h']).float()
+    P[:, 14] = torch.from_numpy(g['cut_p_cut_w']).float()
+    assert 0 < P[:, 12].sum().item() < B                       # the fixture exercises both branches of the mask
+    config.clear_config()
+    config.parse_config_files_and_bindings([os.path.join(config.CONFIG_ROOT, 'defaults', 'augment.gin'),
+                                            os.path.join(config.CONFIG_ROOT, 'gan', 'stylegan2', 'afhq_dog_style64.gin')])
+    aug = get_augment(mode='simclr_hq_cutout')
+    assert aug.cutout_length == 15 and aug.p_cutout == 0.5
+    out = aug.apply(x.to(DEV), P, bool(g['cut_p_contrast_first']), float(g['cut_p_sigma'])).cpu()
+    assert (out - torch.from_numpy(g['cut_out'])).abs().max().item() < 1e-4
+    seed = int(g['cut_seed'])
+    torch.manual_seed(seed); np.random.seed(seed)
+    P2, cf2, s2 = aug.sample(B, 64, 64)
+    assert cf2 == bool(g['cut_p_contrast_first']) and abs(s2 - float(g['cut_p_sigma'])) < 1e-12
+    assert torch.equal(P2[:, :15], P[:, :15])
+    # backward through the whole pipeline (cutout mask -> blur transpose -> colour / gather transpose) vs the oracle
+    p = {k[len('cut_p_'):]: torch.from_numpy(np.asarray(g[k])) for k in g.files if k.startswith('cut_p_')}
+    p['contrast_first'], p['sigma'], p['cut_length'] = bool(p['contrast_first']), float(p['sigma']), 15
+    p['cut_h'], p['cut_w'] = p['cut_h'].long(), p['cut_w'].long()
+    w = torch.randn(x.shape, generator=torch.Generator().manual_seed(2))
+    xr = x.clone().requires_grad_()
+    (O.simclr_apply(xr, p) * w).sum().backward()
+    xd = x.to(DEV).requires_grad_()
+    (aug.apply(xd, P, p['contrast_first'], p['sigma']) * w.to(DEV)).sum().backward()
+    e = ((xd.grad.cpu() - xr.grad).norm() / xr.grad.norm()).item()
+    assert e < 2e-3, e

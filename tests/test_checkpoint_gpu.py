@@ -79,12 +79,12 @@ def test_resume_from_a_reference_format_checkpoint(tmp_path):
     log = open(os.path.join(ck, 'log.txt')).read()
     assert '[Steps       4]' in log and '[Steps       5]' in log and '[Steps       3]' not in log
     assert 'nan' not in log.lower()
-    after = torch.load(os.path.join(ck, 'dis.pt'))
+    after = torch.load(os.path.join(ck, 'dis.pt'), map_location='cpu')
     assert list(after) == list(dsd)                                  # same keys, same order: loadable by the reference
     # two Adam steps at lr 2e-4 from the loaded moments: every weight moved, none by more than ~2 * lr
     d = (after['main.0.weight_orig'] - dsd['main.0.weight_orig']).abs()
     assert 0 < d.max().item() < 1e-3
-    ck2 = torch.load(os.path.join(ck, 'optim.pt'))
+    ck2 = torch.load(os.path.join(ck, 'optim.pt'), map_location='cpu')
     assert ck2['epoch'] == 5 and int(ck2['optim_D']['state'][0]['step']) == 5
 
 
@@ -97,7 +97,7 @@ def test_finetune_loads_the_trunk_and_reinitialises_the_linear_head(tmp_path):
     logdir = str(tmp_path / 'ft')
     main([gin, 'sndcgan', '--mode=contrad', '--aug=simclr', '--synthetic', '--max_steps', '1', '--evaluate_every', '1',
           '--finetune', ck, '--logdir', logdir])
-    after = torch.load(os.path.join(logdir, 'dis.pt'))
+    after = torch.load(os.path.join(logdir, 'dis.pt'), map_location='cpu')
     for k in ('main.0.weight_orig', 'main.12.weight_orig', 'projection.0.weight_orig', 'projection2.2.weight_orig'):
         assert (after[k] - dsd[k]).abs().max().item() < 5e-4, k       # loaded, then one Adam step
     for k in ('linear.l1.weight_orig', 'linear.l2.weight_orig'):

@@ -15,6 +15,11 @@ LAYERS_SG2 = [(512, 32, 32, 3, 1, 1), (513, 32, 64, 3, 2, 0), (256, 64, 64, 3, 1
               (128, 128, 128, 3, 1, 1), (64, 256, 256, 3, 1, 1), (32, 512, 512, 3, 1, 1)]
 if os.environ.get('CONV_SET') == 'sg2':
     LAYERS = LAYERS_SG2
+if os.environ.get('CONV_SET') == 'sg2full':       # every conv of ResidualDiscriminatorP(512, channel_multiplier=1)
+    ch = {512: 32, 256: 64, 128: 128, 64: 256, 32: 512, 16: 512, 8: 512, 4: 512}
+    LAYERS = []
+    for R in (512, 256, 128, 64, 32, 16, 8):
+        LAYERS += [(R, ch[R], ch[R], 3, 1, 1), (R + 1, ch[R], ch[R // 2], 3, 2, 0), (R // 2, ch[R], ch[R // 2], 1, 1, 0)]
 
 ITERS = int(os.environ.get('CONV_ITERS', '10'))
 WARM = int(os.environ.get('CONV_WARM', '3'))
