@@ -247,8 +247,12 @@ def run_config(name, args, world, rank, dev, multi):
     images = torch.rand(n_local, 3, size, size, device=dev)     # synthetic batch, resident in HBM
 
     counter = [0]
+    graphed = [None]
+    use_graph = name == 'c10_b512' and not multi and args.graph != 'off'
     if name == 'c10_b512':
         def one_step():
+            if graphed[0] is not None:
+                return graphed[0]()
             return d_step(P, G, D, opt_D, options, images, reducer)
     else:
         fn = d_step_stylegan2 if name == 'sg2_32' else d_step_stylegan2_contrad
@@ -283,6 +287,14 @@ def run_config(name, args, world, rank, dev, multi):
         a[2] += 1
     del warm_prof
     ops.PROFILE_ONLY = max(wagg.items(), key=lambda kv: kv[1][0])[0] if wagg else None
+    if use_graph:
+        # the timed region replays ONE captured hipGraph per step (engine.GraphedDStep); events cannot sit inside a
+        # graph, so the dominant kernel is bracketed on eager steps run right after the timed region instead
+        from contrad_amd.engine import GraphedDStep
+        ops.PROFILE = None
+        graphed[0] = GraphedDStep(P, G, D, opt_D, options, images, warmup=1)
+        for _ in range(2):
+            one_step()
     # the lazy-R1 schedule: start the timed window right after an R1 step so that K steps contain exactly K // period
     if cfg['d_reg_every'] > 1:
         counter[0] = 0
@@ -292,8 +304,15 @@ def run_config(name, args, world, rank, dev, multi):
         d_loss, aux = one_step()
     barrier()
     dt = time.perf_counter() - t0
+    if use_graph:                       # same kernels, same shapes, eager launches with the dominant kernel bracketed
+        graphed[0] = None
+        ops.PROFILE = []
+        for _ in range(max(3, steps // 4)):
+            one_step()
+        torch.cuda.synchronize()
     prof, ops.PROFILE = ops.PROFILE, None
     dom_name, ops.PROFILE_ONLY = ops.PROFILE_ONLY, None
+    nprof_steps = max(3, steps // 4) if use_graph else steps
     if multi:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -324,10 +343,12 @@ def run_config(name, args, world, rank, dev, multi):
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic,
                     "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                    "launches_per_step": cnt / steps, "avg_launch_ms": round(tsum / cnt * 1e3, 4),
+                    "launches_per_step": cnt / nprof_steps, "avg_launch_ms": round(tsum / cnt * 1e3, 4),
                     "algorithmic_gflop_per_launch": round(fsum / cnt / 1e9, 2),
                     "bracket": "HIP events around the C-ABI call on its stream" +
-                               (" (igemm WGRAD kernel + its wgrad_reduce_kernel)" if "<2," in dom_name else ""),
+                               (" (igemm WGRAD kernel + its wgrad_reduce_kernel)" if "<2," in dom_name else "") +
+                               ("; the timed region replays one captured hipGraph per step, so the bracketed launches are "
+                                "those of %d eager steps run right after it" % nprof_steps if use_graph else ""),
                     "conv_engine_share_of_step": round(conv_time_per_step / (dt / steps), 3),
                     "all_kernels_warmup": {k: {"tflops": round(v[1] / v[0] / 1e12, 1),
                                                "ms_per_step": round(v[0] / wsteps * 1e3, 3)}
@@ -342,6 +363,7 @@ def run_config(name, args, world, rank, dev, multi):
                "config": {"workload": cfg['workload'] % batch, "name": name,
                           "global_batch": global_batch, "per_gpu_batch": n_local,
                           "parallelism": "dp%d" % world, "losses_finite": finite,
+                          "launch": "hipGraph replay" if use_graph else "eager",
                           "rccl_ranks": dist.get_world_size() if multi else 1,
                           "peak_hbm_gib": round(peak_mem, 2)},
                "roofline": roofline}
@@ -362,6 +384,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=None, help='untimed warm-up steps (default: 5 / 3 / 2)')
     ap.add_argument('--config', default='all', choices=sorted(CONFIGS) + ['all'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', default='on', choices=['on', 'off'],
+                    help='single-process c10_b512: replay the D-step as one captured hipGraph (engine.GraphedDStep)')
     ap.add_argument('--force-dist', action='store_true',
                     help='dev: run all collective code paths on a 1-rank RCCL group (single GPU)')
     ap.add_argument('--dev-local-batch', type=int, default=0,

@@ -137,6 +137,7 @@ class SimCLRAugment(nn.Module):
         if self.p_blur is not None:
             P[:, 11] = torch.bernoulli(torch.full((B,), self.p_blur))
             sigma = float(np.random.uniform(*self.sigma_range))
+        P[:, 15] = float(contrast_first)    # also carried in the block: a captured hipGraph reads it from there
         if self.p_cutout is not None:        # RandomApply mask, then CutOut's two randint draws (spatial.py:166-170)
             P[:, 12] = torch.bernoulli(torch.full((B,), self.p_cutout))
             P[:, 13] = torch.randint(dim2, (B, 1)).view(B).float()

@@ -49,6 +49,10 @@ struct AugArgs {
   int contrast_first, has_contrast;
 };
 
+// op order of ColorJitterLayer.transform (color_jitter.py:65-75): a launch argument, or -- contrast_first < 0 -- read
+// from the parameter block (column 15), so that a captured hipGraph replays with each step's own draw
+#define CF(a, pr) ((a).contrast_first < 0 ? ((pr)[15] != 0.f) : ((a).contrast_first != 0))
+
 // bilinear sample of channel plane `src` (H x W) at output pixel (i, j) under the crop+flip of sample n
 struct Sampler {
   int x0, y0, x1, y1;
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256) void simclr_small_kernel(AugArgs a) {
     const int i = p / a.W, j = p - i * a.W;
     const Sampler s = make_sampler(pr, i, j, a.H, a.W);
     float r = sample_plane(src, s, a.W), g = sample_plane(src + HW, s, a.W), b = sample_plane(src + 2 * HW, s, a.W);
-    if (jitter && !a.contrast_first) hsv_jitter(r, g, b, fh, fs, fv);
+    if (jitter && !CF(a, pr)) hsv_jitter(r, g, b, fh, fs, fv);
     img[p] = r; img[HW + p] = g; img[2 * HW + p] = b;
   }
   __syncthreads();
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(256) void simclr_small_kernel(AugArgs a) {
         r = (r - mean[0]) * fc + mean[0]; g = (g - mean[1]) * fc + mean[1]; b = (b - mean[2]) * fc + mean[2];
       }
       r = clamp01(r); g = clamp01(g); b = clamp01(b);
-      if (a.contrast_first) hsv_jitter(r, g, b, fh, fs, fv);
+      if (CF(a, pr)) hsv_jitter(r, g, b, fh, fs, fv);
       img[p] = r; img[HW + p] = g; img[2 * HW + p] = b;
     }
     __syncthreads();
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(256) void simclr_small_bwd_kernel(AugArgs a, const 
     const int i = p / W, j = p - i * W;
     const Sampler s = make_sampler(pr, i, j, H, W);
     float r = sample_plane(src, s, W), gg = sample_plane(src + HW, s, W), b = sample_plane(src + 2 * HW, s, W);
-    if (jitter && !a.contrast_first) hsv_jitter(r, gg, b, fh, fs, fv);
+    if (jitter && !CF(a, pr)) hsv_jitter(r, gg, b, fh, fs, fv);
     cimg[p] = r; cimg[HW + p] = gg; cimg[2 * HW + p] = b;
     const float* go = gout + (size_t)n * 3 * HW;
     float g0 = go[p], g1 = go[HW + p], g2 = go[2 * HW + p];
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(256) void simclr_stats_kernel(AugArgs a, float* __r
       const int i = p / a.W, j = p - i * a.W;
       const Sampler s = make_sampler(pr, i, j, a.H, a.W);
       float r = sample_plane(src, s, a.W), g = sample_plane(src + HW, s, a.W), b = sample_plane(src + 2 * HW, s, a.W);
-      if (!a.contrast_first) hsv_jitter(r, g, b, pr[7], pr[8], pr[9]);
+      if (!CF(a, pr)) hsv_jitter(r, g, b, pr[7], pr[8], pr[9]);
       s0 += r; s1 += g; s2 += b;
     }
   }
@@ -309,12 +313,12 @@ __global__ __launch_bounds__(256) void simclr_apply_kernel(AugArgs a, const floa
     const Sampler s = make_sampler(pr, i, j, a.H, a.W);
     float r = sample_plane(src, s, a.W), g = sample_plane(src + HW, s, a.W), b = sample_plane(src + 2 * HW, s, a.W);
     if (jitter) {
-      if (!a.contrast_first) hsv_jitter(r, g, b, fh, fs, fv);
+      if (!CF(a, pr)) hsv_jitter(r, g, b, fh, fs, fv);
       if (a.has_contrast) {
         r = (r - mean[0]) * fc + mean[0]; g = (g - mean[1]) * fc + mean[1]; b = (b - mean[2]) * fc + mean[2];
       }
       r = clamp01(r); g = clamp01(g); b = clamp01(b);
-      if (a.contrast_first) hsv_jitter(r, g, b, fh, fs, fv);
+      if (CF(a, pr)) hsv_jitter(r, g, b, fh, fs, fv);
     }
     if (gray) gray3(r, g, b);
     dst[p] = r; dst[HW + p] = g; dst[2 * HW + p] = b;
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(256) void simclr_bwd_gm_kernel(AugArgs a, const flo
       const int i = p / a.W, j = p - i * a.W;
       const Sampler s = make_sampler(pr, i, j, a.H, a.W);
       float r = sample_plane(src, s, a.W), g = sample_plane(src + HW, s, a.W), b = sample_plane(src + 2 * HW, s, a.W);
-      if (!a.contrast_first) hsv_jitter(r, g, b, pr[7], pr[8], pr[9]);
+      if (!CF(a, pr)) hsv_jitter(r, g, b, pr[7], pr[8], pr[9]);
       if (a.has_contrast) {
         r = (r - mean[0]) * fc + mean[0]; g = (g - mean[1]) * fc + mean[1]; b = (b - mean[2]) * fc + mean[2];
       }

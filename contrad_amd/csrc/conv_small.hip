@@ -20,6 +20,11 @@ namespace {
 #ifndef RGB_MIN_WAVES
 #define RGB_MIN_WAVES 3   // 168 VGPRs, no spill -> 3 waves per SIMD (the weights of all 27 taps live in registers)
 #endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// v_pk_fma_f32: two fp32 FMAs per lane per issue slot -- these kernels sit at the VALU roofline as much as at the HBM one
+// (27 taps x 4 channels of FMA per 16 B stored), so the packed form is what brings them under the store time
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 constexpr int MAX_TAPS = 9;  // k <= 3
 constexpr int MAX_CIN = 4;
 
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(256, RGB_MIN_WAVES) void rgb_conv_fwd_kernel(RgbArg
     const int rows = min(a.TH, a.H - h0);
     for (int pix = slot; pix < rows * a.W; pix += slots) {
       const int r = pix / a.W, c = pix - r * a.W;
-      float4 acc = b4;
+      f32x2 a01 = {b4.x, b4.y}, a23 = {b4.z, b4.w};
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         const int kh = t / KSZ, kw = t % KSZ;
@@ -80,10 +85,12 @@ __global__ __launch_bounds__(256, RGB_MIN_WAVES) void rgb_conv_fwd_kernel(RgbArg
         for (int ci = 0; ci < CIN; ++ci) {
           const float xv = lds[(ci * HH + r + kh) * HW + c + kw];
           const float4 ww = w[t * CIN + ci];
-          acc.x = fmaf(xv, ww.x, acc.x); acc.y = fmaf(xv, ww.y, acc.y);
-          acc.z = fmaf(xv, ww.z, acc.z); acc.w = fmaf(xv, ww.w, acc.w);
+          const f32x2 xx = {xv, xv};
+          a01 = pk_fma(xx, f32x2{ww.x, ww.y}, a01);
+          a23 = pk_fma(xx, f32x2{ww.z, ww.w}, a23);
         }
       }
+      float4 acc = make_float4(a01.x, a01.y, a23.x, a23.y);
       acc.x = (acc.x > 0.f ? acc.x : acc.x * a.slope) * a.gain;
       acc.y = (acc.y > 0.f ? acc.y : acc.y * a.slope) * a.gain;
       acc.z = (acc.z > 0.f ? acc.z : acc.z * a.slope) * a.gain;
@@ -114,9 +121,9 @@ __global__ __launch_bounds__(256, RGB_MIN_WAVES) void rgb_conv_wgrad_kernel(RgbW
   h.img = a.img; h.Cin = a.Cin; h.H = a.H; h.W = a.W; h.pad = a.pad; h.TH = a.TH;
   h.in_scale = a.in_scale; h.in_shift = a.in_shift;
 
-  float4 acc[TAPS * CIN];
+  f32x2 acc[TAPS * CIN][2];
 #pragma unroll
-  for (int i = 0; i < TAPS * CIN; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < TAPS * CIN; ++i) { acc[i][0] = f32x2{0.f, 0.f}; acc[i][1] = f32x2{0.f, 0.f}; }
   float4 accb = make_float4(0.f, 0.f, 0.f, 0.f);
 
   for (int tile = blockIdx.x; tile < a.N * tiles_h; tile += gridDim.x) {
@@ -129,15 +136,16 @@ __global__ __launch_bounds__(256, RGB_MIN_WAVES) void rgb_conv_wgrad_kernel(RgbW
       const int r = pix / a.W, c = pix - r * a.W;
       const float4 g = *reinterpret_cast<const float4*>(a.gy + ((size_t)(n * a.H + h0 + r) * a.W + c) * a.ldy + cg * 4);
       accb.x += g.x; accb.y += g.y; accb.z += g.z; accb.w += g.w;
+      const f32x2 g01 = {g.x, g.y}, g23 = {g.z, g.w};
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         const int kh = t / KSZ, kw = t % KSZ;
 #pragma unroll
         for (int ci = 0; ci < CIN; ++ci) {
           const float xv = lds[(ci * HH + r + kh) * HW + c + kw];
-          float4& q = acc[t * CIN + ci];
-          q.x = fmaf(xv, g.x, q.x); q.y = fmaf(xv, g.y, q.y);
-          q.z = fmaf(xv, g.z, q.z); q.w = fmaf(xv, g.w, q.w);
+          const f32x2 xx = {xv, xv};
+          acc[t * CIN + ci][0] = pk_fma(xx, g01, acc[t * CIN + ci][0]);
+          acc[t * CIN + ci][1] = pk_fma(xx, g23, acc[t * CIN + ci][1]);
         }
       }
     }
@@ -149,7 +157,8 @@ __global__ __launch_bounds__(256, RGB_MIN_WAVES) void rgb_conv_wgrad_kernel(RgbW
 #pragma unroll
   for (int q = 0; q <= TAPS * CIN; ++q) {   // fully unrolled: acc[] stays in registers
     const bool is_bias = (q == TAPS * CIN);
-    const float4 v = is_bias ? accb : acc[q < TAPS * CIN ? q : 0];
+    const int qi = q < TAPS * CIN ? q : 0;
+    const float4 v = is_bias ? accb : make_float4(acc[qi][0].x, acc[qi][0].y, acc[qi][1].x, acc[qi][1].y);
     red[slot * tpp + cg] = v;
     __syncthreads();
     if (slot == 0) {
@@ -265,6 +274,73 @@ __global__ __launch_bounds__(256) void rgb_conv_dgrad_kernel(RgbDgradArgs a) {
   }
 }
 
+// The 3x3 transposed conv onto <= 3 channels with ONE THREAD PER OUTPUT PIXEL (no per-sample modulation / residual: the
+// generator's last ConvTranspose2d + Tanh and d loss / d image of D's first layer).  A block owns TH rows x W columns
+// (TH * W <= 256 pixels); the gy halo tile goes through LDS in chunks of 32 channels with coalesced float4 loads (a
+// pixel's channels are one contiguous run), pixel stride 36 floats = conflict-free ds_read_b128 across the lanes; the
+// weights are wave-uniform (scalar loads); the NCHW stores of a wave are contiguous per channel.  The lane-group
+// formulation above spends its time in xor-shuffle reductions and holds 144 weight registers per lane (192 us for the
+// 512-image batch of the headline config = 9 % of the HBM roofline; a thread-per-pixel version reading gy straight
+// from global memory is bound by the vector-L1 line rate -- 64 lines per load instruction -- at the same 165 us).
+constexpr int DG_CK = 32;            // channels per LDS pass
+constexpr int DG_PS = DG_CK + 4;     // padded pixel stride (floats)
+__global__ __launch_bounds__(256) void rgb_dgrad3_tile_kernel(const float* __restrict__ gy, const float* __restrict__ wp,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              int N, int C, int H, int W, int K, int ldy, int ldw, int TH,
+                                                              int act, float out_scale, float out_shift) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // [(TH + 2)][(W + 2)][DG_PS]
+  const int tiles_h = cdiv_dev(H, TH);
+  const int n = blockIdx.x / tiles_h, h0 = (blockIdx.x % tiles_h) * TH;
+  const int HW2 = W + 2, HH2 = TH + 2;
+  const int r = threadIdx.x / W, c = threadIdx.x - r * W;
+  const bool live = threadIdx.x < TH * W && h0 + r < H;
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += DG_CK) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < HH2 * HW2 * (DG_CK / 4); e += blockDim.x) {
+      const int q = e % (DG_CK / 4), p = e / (DG_CK / 4);
+      const int pr = p / HW2, pc = p - pr * HW2;
+      const int h = h0 - 1 + pr, w = pc - 1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W)
+        v = *reinterpret_cast<const float4*>(gy + ((size_t)(n * H + h) * W + w) * ldy + k0 + q * 4);
+      *reinterpret_cast<float4*>(tile + (size_t)p * DG_PS + q * 4) = v;
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          // out[h][w] += gy[h + 1 - kh][w + 1 - kw] * w[kh][kw]; tile row of gy row (h + 1 - kh) is (r + 2 - kh)
+          const float4* g4 = reinterpret_cast<const float4*>(tile + (size_t)((r + 2 - kh) * HW2 + (c + 2 - kw)) * DG_PS);
+          const float* wt = wp + (size_t)((kh * 3 + kw) * C) * ldw + k0;
+#pragma unroll
+          for (int q = 0; q < DG_CK / 4; ++q) {
+            const float4 g = g4[q];
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+              if (cc < C) {
+                const float4 ww = *reinterpret_cast<const float4*>(wt + (size_t)cc * ldw + q * 4);   // wave-uniform
+                acc[cc] = fmaf(g.x, ww.x, fmaf(g.y, ww.y, fmaf(g.z, ww.z, fmaf(g.w, ww.w, acc[cc]))));
+              }
+            }
+          }
+        }
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      if (cc < C) {
+        float v = acc[cc] + (bias ? bias[cc] : 0.f);
+        if (act == 1) v = tanhf(v);
+        out[((size_t)(n * C + cc) * H + h0 + r) * W + c] = v * out_scale + out_shift;
+      }
+    }
+  }
+}
+
 int rgb_common_check(int N, int Cin, int H, int W, int K, int k, int ldy, int ldw) {
   CONTRAD_ARG(N > 0 && H > 0 && W > 0 && Cin == 3);  /* RGB images (nc = 3 everywhere in the reference) */
   CONTRAD_ARG(k == 1 || k == 3);
@@ -273,7 +349,9 @@ int rgb_common_check(int N, int Cin, int H, int W, int K, int k, int ldy, int ld
   return 0;
 }
 
-int pick_th(int W) { int th = 256 / W; return th < 1 ? 1 : (th > 8 ? 8 : th); }
+// rows per tile: ~1024 output pixels per staging pass (a whole CIFAR image: one halo load + one barrier pair per image
+// instead of four; at W = 512 two rows instead of one, which halves the 3-row halo traffic of the k3 kernels)
+int pick_th(int W) { int th = 1024 / W; return th < 1 ? 1 : (th > 32 ? 32 : th); }
 
 }  // namespace
 
@@ -300,7 +378,7 @@ extern "C" int contrad_rgb_conv_fwd(const float* img, const float* wp, const flo
 
 static int rgb_wgrad_grid(int N, int H, int W) {
   const int tiles = N * cdiv(H, pick_th(W));
-  return tiles < 512 ? tiles : 512;
+  return tiles < 1024 ? tiles : 1024;
 }
 
 extern "C" long long contrad_rgb_conv_wgrad_workspace_bytes(int N, int Cin, int H, int W, int K, int k) {
@@ -347,6 +425,16 @@ extern "C" int contrad_rgb_conv_dgrad(const float* gy, const float* wp, const fl
   a.N = N; a.C = C; a.H = H; a.W = W; a.K = K; a.ldy = ldy; a.ldw = ldw; a.k = k; a.pad = k / 2;
   a.act = act; a.out_scale = out_scale; a.out_shift = out_shift;
   const long long total = (long long)N * H * W;
+  if (k == 3 && !mod && !residual && C <= 3 && (K % DG_CK) == 0 && W <= 256) {   // LDS-tiled thread-per-pixel form
+    const int TH = 256 / W < 1 ? 1 : (256 / W > H ? H : 256 / W);
+    const size_t smem = (size_t)(TH + 2) * (W + 2) * DG_PS * sizeof(float);
+    if (smem <= 64 * 1024) {
+      hipLaunchKernelGGL(rgb_dgrad3_tile_kernel, dim3(N * cdiv(H, TH)), dim3(256), smem, (hipStream_t)stream, gy, wp, bias,
+                         out, N, C, H, W, K, ldy, ldw, TH, act, out_scale, out_shift);
+      CONTRAD_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   const int ch = (K > 256) ? 2 : 1;
   const int slots = 256 / (K / (4 * ch));
   long long grid = (total + slots - 1) / slots;

@@ -293,7 +293,10 @@ __global__ void gan_g_loss_kernel(const float* __restrict__ d, int ldd, int N, i
 
 // ---- fused multi-tensor Adam (torch.optim.Adam semantics: no weight decay, no amsgrad) ----
 __global__ void adam_kernel(contrad_adam_batch b, float step_size, float beta1, float beta2,
-                            float inv_sqrt_bc2, float eps, float grad_scale) {
+                            float inv_sqrt_bc2, float eps, float grad_scale, const float* __restrict__ hyper) {
+  if (hyper) {   // step-dependent scalars from device memory: a captured hipGraph replays with each step's values
+    step_size = hyper[0]; inv_sqrt_bc2 = hyper[1]; grad_scale = hyper[2];
+  }
   // block -> (tensor, chunk)
   int t = 0;
   while (t + 1 < b.n && (int)blockIdx.x >= b.block_start[t + 1]) ++t;
@@ -460,7 +463,24 @@ extern "C" int contrad_adam_step(const contrad_adam_batch* b, int step, float lr
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, bb, (float)(lr / bc1), beta1,
-                     beta2, (float)(1.0 / sqrt(bc2)), eps, grad_scale);
+                     beta2, (float)(1.0 / sqrt(bc2)), eps, grad_scale, (const float*)nullptr);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int contrad_adam_step_dev(const contrad_adam_batch* b, const float* hyper_dev, float beta1, float beta2,
+                                     float eps, contrad_stream_t stream) {
+  CONTRAD_ARG(b && hyper_dev && b->n > 0 && b->n <= CONTRAD_ADAM_MAX_TENSORS);
+  contrad_adam_batch bb = *b;
+  int blocks = 0;
+  for (int i = 0; i < bb.n; ++i) {
+    CONTRAD_ARG(bb.t[i].p && bb.t[i].g && bb.t[i].m && bb.t[i].v && bb.t[i].numel > 0);
+    bb.block_start[i] = blocks;
+    blocks += (int)((bb.t[i].numel + CONTRAD_ADAM_CHUNK - 1) / CONTRAD_ADAM_CHUNK);
+  }
+  bb.block_start[bb.n] = blocks;
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, bb, 0.f, beta1, beta2, 1.f, eps, 1.f,
+                     hyper_dev);
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }

@@ -193,3 +193,77 @@ def d_step_stylegan2_contrad(P, G, D, opt_D, options, images, step, reducer=None
     opt_D.step(grad_scale=1.0 / world) if world > 1 else opt_D.step()
     THROTTLE.end()
     return d_loss, aux
+
+
+# ----------------------------------------------------------------------------------------------------------
+# the SNDCGAN D-step as one hipGraph
+# ----------------------------------------------------------------------------------------------------------
+class GraphedDStep(object):
+    """``d_step`` (train_gan.py:153-163) captured ONCE into a hipGraph and replayed every iteration.
+
+    One D-step is ~120 kernel launches; enqueued from Python they cost ~2.8 ms of host time -- hidden behind 17.7 ms of
+    GPU work at batch 512, but most of the 3.5 ms step one rank of an 8-GPU job runs at batch 64.
+    Replaying a captured graph takes the host out: per step it only draws the random numbers (latents, augmentation
+    parameters -- on the host, in the reference's RNG order, exactly as the eager path), hands them over into STATIC
+    device tensors, refreshes three Adam scalars, and launches the graph.  What had to move from launch arguments into
+    device memory for that: the colour-op order of the augmentation (column 15 of the parameter block) and Adam's
+    step-dependent scalars (``contrad_adam_step_dev``).  Single process; with a process group the eager path stays
+    (RCCL inside a captured graph is not validated on this stack).
+    """
+
+    def __init__(self, P, G, D, opt_D, options, images, warmup=3):
+        from .augment import SimCLRAugment
+        from . import ops
+        self.P, self.G, self.D, self.opt, self.options = P, G, D, opt_D, options
+        self.aug = P.augment_fn
+        if not isinstance(self.aug, SimCLRAugment) or self.aug.p_blur is not None or dist_on():
+            raise NotImplementedError('GraphedDStep: single-process simclr pipeline')
+        self.images = images
+        N = images.size(0)
+        dev = images.device
+        self.N = N
+        for _ in range(max(warmup, 1)):                 # optimizer state, workspaces, allocator pools
+            d_step(P, G, D, opt_D, options, images)
+        self.z = torch.zeros(N, G.nz, device=dev)
+        self.params = torch.zeros(3 * N, ops.AUG_NPARAM, device=dev)
+        self.hyper = torch.ones(3, device=dev)
+        torch.cuda.synchronize()          # (capture records launches, it does not run them: the inputs stay untouched)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.d_loss, self.aux = self._body()
+        torch.cuda.synchronize()
+
+    def _refresh_inputs(self):
+        from .hostio import upload
+        G, N = self.G, self.N
+        dev = self.images.device
+        z = torch.empty(N, G.nz).uniform_(-1, 1)                        # G.sample_latent's draw (sndcgan.py:50-52)
+        Pm, cf, _ = self.aug.sample(3 * N, self.images.shape[2], self.images.shape[3])
+        Pm[:, 15] = float(cf)
+        self.z.copy_(upload(z, dev))
+        self.params.copy_(upload(Pm, dev))
+        self.hyper.copy_(upload(torch.tensor([self.opt.hyper_values()], dtype=torch.float32), dev).view(3))
+
+    def _body(self):
+        from . import ops
+        from .training.gan.contrad import _ContraDContrastive, _GanDLoss
+        P, G, D, N = self.P, self.G, self.D, self.N
+        with torch.no_grad():
+            gen = G(self.z)
+            cat = torch.cat([self.images, self.images, gen], dim=0)
+            aug = ops.simclr_augment(cat, self.params, -1, self.aug.r_c is not None)
+        d_all, aux = D(aug, sg_linear=True, projection=True, projection2=True)
+        simclr, sup = _ContraDContrastive.apply(aux['projection'], aux['projection2'], N, P.temp, False)
+        gan, d_real, d_gen = _GanDLoss.apply(d_all, N, self.options['loss'])
+        d_loss = simclr + P.lbd_a * sup
+        self.opt.zero_grad(set_to_none=True)
+        (d_loss + gan).backward()
+        self.opt.step_captured(self.hyper)
+        return d_loss, {'penalty': gan, 'd_real': d_real, 'd_gen': d_gen}
+
+    def __call__(self):
+        THROTTLE.begin()
+        self._refresh_inputs()
+        self.graph.replay()
+        THROTTLE.end()
+        return self.d_loss, self.aux

@@ -417,6 +417,24 @@ def adam_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, beta2, eps=
                    float(eps), float(grad_scale), _stream())
 
 
+def adam_step_dev(params, grads, exp_avgs, exp_avg_sqs, hyper, beta1, beta2, eps=1e-8):
+    """adam_step with {lr / bc1, 1 / sqrt(bc2), grad_scale} taken from the device tensor ``hyper`` (3 floats)."""
+    n = len(params)
+    for start in range(0, n, ADAM_MAX_TENSORS):
+        b = AdamBatch()
+        m = min(ADAM_MAX_TENSORS, n - start)
+        b.n = m
+        for j in range(m):
+            p, g = params[start + j], grads[start + j]
+            if not (p.is_contiguous() and g.is_contiguous()):
+                raise RuntimeError('contrad_hip: Adam needs contiguous parameters and gradients')
+            t = b.t[j]
+            t.p, t.g = p.data_ptr(), g.data_ptr()
+            t.m, t.v = exp_avgs[start + j].data_ptr(), exp_avg_sqs[start + j].data_ptr()
+            t.numel = p.numel()
+        lib().call('contrad_adam_step_dev', ctypes.byref(b), _p(hyper), float(beta1), float(beta2), float(eps), _stream())
+
+
 def axpby_(y, x, a, b):
     lib().call('contrad_axpby', _p(y), _p(x), ctypes.c_longlong(y.numel()), float(a), float(b), _stream())
     torch.autograd.graph.increment_version(y)          # raw-pointer write: keep ``_version``-keyed caches honest

@@ -38,3 +38,34 @@ class FusedAdam(torch.optim.Optimizer):
                 for p in ps:
                     torch.autograd.graph.increment_version(p)
         return loss
+
+    # ---- hipGraph support: the launch sequence is captured once, the step-dependent scalars live in device memory ----
+    def hyper_values(self, grad_scale=1.0):
+        """Advance every parameter's step count by one and return [lr / bc1, 1 / sqrt(bc2), grad_scale] of the (single)
+        param group for THAT step -- what ``step_captured`` reads from its device tensor."""
+        import math
+        group = self.param_groups[0]
+        beta1, beta2 = group['betas']
+        step = None
+        for p in group['params']:
+            st = self.state[p]
+            st['step'] = int(st['step']) + 1
+            step = st['step']
+            torch.autograd.graph.increment_version(p)
+        bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+        return [group['lr'] / bc1, 1.0 / math.sqrt(bc2), float(grad_scale)]
+
+    @torch.no_grad()
+    def step_captured(self, hyper):
+        """The update as it is captured into a graph: same kernel, scalars from ``hyper`` (device, 3 floats).  All
+        parameters must already carry optimizer state (run eager steps first) and share one step count."""
+        if len(self.param_groups) != 1:
+            raise RuntimeError('step_captured: one param group')
+        group = self.param_groups[0]
+        ps = [p for p in group['params'] if p.grad is not None]
+        steps = {int(self.state[p]['step']) for p in ps}
+        if len(steps) != 1:
+            raise RuntimeError('step_captured: parameters at different step counts')
+        beta1, beta2 = group['betas']
+        ops.adam_step_dev([p.data for p in ps], [p.grad.data for p in ps], [self.state[p]['exp_avg'] for p in ps],
+                          [self.state[p]['exp_avg_sq'] for p in ps], hyper, beta1, beta2, group['eps'])

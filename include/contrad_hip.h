@@ -213,6 +213,11 @@ typedef struct {
 } contrad_adam_batch;
 int contrad_adam_step(const contrad_adam_batch* b, int step, float lr, float beta1, float beta2, float eps,
                       float grad_scale, contrad_stream_t stream);
+/* The same update with the step-dependent scalars read from DEVICE memory: hyper_dev = {lr / (1 - beta1^t),
+ * 1 / sqrt(1 - beta2^t), grad_scale}.  For a D-step captured once into a hipGraph and replayed every iteration (LR
+ * warm-up and the bias corrections change per step; launch arguments are frozen at capture). */
+int contrad_adam_step_dev(const contrad_adam_batch* b, const float* hyper_dev, float beta1, float beta2, float eps,
+                          contrad_stream_t stream);
 /* y = a*y + b*x (G EMA `accumulate`, utils.py:130-143) */
 int contrad_axpby(float* y, const float* x, long long n, float a, float b, contrad_stream_t stream);
 /* dst[0..n) (device) = host_pinned[0..n): a kernel reads device-mapped pinned host memory (hipHostMalloc) directly --
@@ -224,8 +229,9 @@ int contrad_pull_host(const float* host_pinned, float* dst, long long n, contrad
  * RandomResizeCropLayer + HorizontalFlipLayer (augment/spatial.py:84-148) as ONE bilinear/reflection
  * gather, RandomApply(ColorJitterLayer) (augment/color_jitter.py:16-104, augment/utils.py:6-63),
  * RandomApply(RandomColorGrayLayer) (augment/__init__.py:82-103).  NCHW in, NCHW out, x != y.
+ * contrast_first < 0: the colour-op order is read per sample from params[.][15] (hipGraph replay).
  * params[B][CONTRAD_AUG_NPARAM] = {theta00, theta11, theta02, theta12, flip_sign, jitter_mask,
- * f_contrast, f_h, f_s, f_v, gray_mask, blur_mask, cutout_mask, cutout_h_center, cutout_w_center, (spare)},
+ * f_contrast, f_h, f_s, f_v, gray_mask, blur_mask, cutout_mask, cutout_h_center, cutout_w_center, contrast_first},
  * sampled on the host in the reference's draw order.
  * ---------------------------------------------------------------------------------------------- */
 #define CONTRAD_AUG_NPARAM 16
