@@ -292,9 +292,14 @@ def run_config(name, args, world, rank, dev, multi):
         # graph, so the dominant kernel is bracketed on eager steps run right after the timed region instead
         from contrad_amd.engine import GraphedDStep
         ops.PROFILE = None
-        graphed[0] = GraphedDStep(P, G, D, opt_D, options, images, warmup=1)
-        for _ in range(2):
-            one_step()
+        try:
+            graphed[0] = GraphedDStep(P, G, D, opt_D, options, images, warmup=1)
+            for _ in range(2):
+                one_step()
+        except Exception as e:              # capture not available on this stack: the eager launch sequence is the same work
+            sys.stderr.write('bench.py: hipGraph capture failed (%r); timing the eager launch sequence\n' % (e,))
+            graphed[0], use_graph = None, False
+            ops.PROFILE = []
     # the lazy-R1 schedule: start the timed window right after an R1 step so that K steps contain exactly K // period
     if cfg['d_reg_every'] > 1:
         counter[0] = 0

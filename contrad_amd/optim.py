@@ -44,8 +44,11 @@ class FusedAdam(torch.optim.Optimizer):
         """Advance every parameter's step count by one and return [lr / bc1, 1 / sqrt(bc2), grad_scale] of the (single)
         param group for THAT step -- what ``step_captured`` reads from its device tensor."""
         import math
+        import struct
         group = self.param_groups[0]
-        beta1, beta2 = group['betas']
+        # the C launcher receives the betas as floats and forms the bias corrections in double from those
+        f32 = lambda v: struct.unpack('f', struct.pack('f', v))[0]
+        beta1, beta2 = (f32(b) for b in group['betas'])
         step = None
         for p in group['params']:
             st = self.state[p]
@@ -53,7 +56,7 @@ class FusedAdam(torch.optim.Optimizer):
             step = st['step']
             torch.autograd.graph.increment_version(p)
         bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
-        return [group['lr'] / bc1, 1.0 / math.sqrt(bc2), float(grad_scale)]
+        return [f32(group['lr']) / bc1, 1.0 / math.sqrt(bc2), float(grad_scale)]
 
     @torch.no_grad()
     def step_captured(self, hyper):
