@@ -378,7 +378,7 @@ extern "C" int contrad_rgb_conv_fwd(const float* img, const float* wp, const flo
 
 static int rgb_wgrad_grid(int N, int H, int W) {
   const int tiles = N * cdiv(H, pick_th(W));
-  return tiles < 1024 ? tiles : 1024;
+  return tiles < 512 ? tiles : 512;
 }
 
 extern "C" long long contrad_rgb_conv_wgrad_workspace_bytes(int N, int Cin, int H, int W, int K, int k) {
