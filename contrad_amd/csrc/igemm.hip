@@ -678,35 +678,56 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
   }
 }
 
-// dwp[i][co] = sum_s ws[s][i][co]   (fixed summation order -> deterministic)
+// dwp[i][co] = sum_s ws[s][i][co]   (fixed summation order -> deterministic).
+// R (power of two <= 64) consecutive lanes share one output element group and each sums the splits r, r + R, ... ; the R
+// partial sums are combined by a fixed xor-butterfly.  Small outputs with hundreds of splits (the 288 x 32 weight gradient
+// of a 32-channel layer at 512 x 512 has 341) otherwise run as 9 blocks of threads that each walk all splits serially:
+// 55 us per call, 3.2 ms per StyleGAN2-512 step.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int Kg, int Ncol,
                                     int ldw, int splits, const float* __restrict__ bias_ws,
-                                    float* __restrict__ dbias) {
+                                    float* __restrict__ dbias, int R) {
   const long long total = (long long)Kg * Ncol;
-  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long nthreads = (long long)gridDim.x * blockDim.x;
   const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = (int)(t0 % R);
+  const long long g0 = t0 / R, gstride = nthreads / R;
   if (ldw == Ncol && (total & 3) == 0) {   // dense packed rows: float4 streams, no index arithmetic
-    for (long long q = t0; q < total / 4; q += stride) {
+    const long long n4 = total / 4;
+    for (long long q0 = g0 - (g0 % (64 / R)); q0 < n4; q0 += gstride) {   // (whole waves iterate together: shuffles below)
+      const long long q = q0 + (g0 % (64 / R));
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int k = 0; k < splits; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(ws + (long long)k * total + q * 4);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      if (q < n4)
+        for (int k = r; k < splits; k += R) {
+          const float4 v = *reinterpret_cast<const float4*>(ws + (long long)k * total + q * 4);
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+      for (int o = R >> 1; o > 0; o >>= 1) {
+        s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64);
+        s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
       }
-      *reinterpret_cast<float4*>(out + q * 4) = s;
+      if (r == 0 && q < n4) *reinterpret_cast<float4*>(out + q * 4) = s;
     }
   } else {
-    for (long long e = t0; e < total; e += stride) {
+    for (long long e0 = g0 - (g0 % (64 / R)); e0 < total; e0 += gstride) {
+      const long long e = e0 + (g0 % (64 / R));
       float s = 0.f;
-      for (int k = 0; k < splits; ++k) s += ws[(long long)k * total + e];
-      const int i = (int)(e / Ncol), c = (int)(e - (long long)i * Ncol);
-      out[(size_t)i * ldw + c] = s;
+      if (e < total)
+        for (int k = r; k < splits; k += R) s += ws[(long long)k * total + e];
+      for (int o = R >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      if (r == 0 && e < total) {
+        const int i = (int)(e / Ncol), c = (int)(e - (long long)i * Ncol);
+        out[(size_t)i * ldw + c] = s;
+      }
     }
   }
   if (dbias)
-    for (long long c = t0; c < Ncol; c += stride) {
+    for (long long c0 = g0 - (g0 % (64 / R)); c0 < Ncol; c0 += gstride) {
+      const long long c = c0 + (g0 % (64 / R));
       float s = 0.f;
-      for (int k = 0; k < splits; ++k) s += bias_ws[(long long)k * Ncol + c];
-      dbias[c] = s;
+      if (c < Ncol)
+        for (int k = r; k < splits; k += R) s += bias_ws[(long long)k * Ncol + c];
+      for (int o = R >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      if (r == 0 && c < Ncol) dbias[c] = s;
     }
 }
 
@@ -798,7 +819,11 @@ bool vec_ok(const contrad_conv_desc* d, int mode) {
 // though it does 4x the LDS traffic per flop.  mult = independent grids of this size (DGRAD parity classes).
 void pick_tile(long long M, int Ncol, bool vec, bool lean, int mult, int* bm, int* bn) {
   if (!vec) { *bm = 64; *bn = 64; return; }
-  if (lean && Ncol <= 32) { *bm = 128; *bn = 32; return; }   // lean only: 4 x 1 waves, no MFMA columns wasted
+  // lean only: 4 x 1 waves, no MFMA columns wasted.  (A 256 x 32 tile -- two MFMA tiles per wave sharing one B fragment --
+  // was tried in round 2: 89.0 vs 88.3 TF/s.  These layers are not short of issue slots: every A element fetched feeds
+  // only 32 MACs, i.e. 16 FLOP per byte pulled through L2 -> ~10 TB/s of L2 -> L1 traffic at the MFMA peak; the cure is a
+  // spatial halo tile in LDS that serves all nine taps, a different kernel.)
+  if (lean && Ncol <= 32) { *bm = 128; *bn = 32; return; }
   static const int forced = []() { const char* e = getenv("CONTRAD_IGEMM_TILE"); return e ? atoi(e) : 0; }();  // dev: "128064"
   if (forced) { *bm = forced / 1000; *bn = forced % 1000; return; }
   static const int cand[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
@@ -1048,11 +1073,14 @@ extern "C" int contrad_conv2d_wgrad(const contrad_conv_desc* d, const float* x, 
                             (hipStream_t)stream);
   if (rc) return rc;
   const long long total = (long long)a.M * a.Ncol;
-  int blocks = (int)((total / 4 + 255) / 256);
+  // split-lanes per element group: enough threads (~64 k) to cover the memory latency when the output is small
+  int R = 1;
+  while (R < 64 && R * 2 <= splits && (total / 4) * R < 65536) R <<= 1;
+  long long blocks = ((total / 4) * R + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, workspace, dwp,
-                     a.M, a.Ncol, d->ldw, splits, a.bias_ws, fused_bias ? dbias : nullptr);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, workspace, dwp,
+                     a.M, a.Ncol, d->ldw, splits, a.bias_ws, fused_bias ? dbias : nullptr, R);
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }
