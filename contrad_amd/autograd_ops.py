@@ -388,7 +388,15 @@ class UnpackWeightsFn(Function):
     def forward(ctx, meta, shapes, *gouts):
         dev = next(g for g in gouts if g is not None).device
         gouts = [(_cont(g) if g is not None else torch.zeros(meta.groups[i], device=dev)) for i, g in enumerate(gouts)]
-        gws = [torch.empty(s, device=dev, dtype=torch.float32) for s in shapes]
+        # one flat allocation, per-parameter views: the data-parallel exchange (engine.GradAllReducer) then moves all
+        # weight gradients of a network in ONE collective instead of one per parameter
+        sizes = [int(math.prod(s)) for s in shapes]
+        offs, tot = [], 0
+        for n_ in sizes:
+            offs.append(tot)
+            tot += ops.round_up(n_, 4)
+        flat = torch.empty(max(tot, 4), device=dev, dtype=torch.float32)
+        gws = [flat[o:o + n_].view(s) for o, n_, s in zip(offs, sizes, shapes)]
         specs = _specs_from(meta, gws)           # .w is only a non-null placeholder on the fixed-scale path
         gwps = [gouts[e[4]][:, e[5]:e[5] + e[0]] for e in meta.entries]
         ldws = [meta.groups[e[4]][1] for e in meta.entries]
