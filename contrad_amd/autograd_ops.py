@@ -26,6 +26,14 @@ def _cont(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _packed_buffer(shape, k_written, device):
+    """Output buffer in the packed [(tap, c)][ldw] layout: the kernels write columns [0, k_written) of every row, so a
+    zero fill is needed only when padding columns exist (ldw > K) -- ~110 fill launches per StyleGAN2-32 step otherwise."""
+    if shape[1] == k_written:
+        return torch.empty(shape, device=device, dtype=torch.float32)
+    return torch.zeros(shape, device=device, dtype=torch.float32)
+
+
 # ----------------------------------------------------------------------------------------------------------
 # convolution family.  geom = (K, KH, KW, stride, pad)
 # ----------------------------------------------------------------------------------------------------------
@@ -70,7 +78,7 @@ class ConvWgradFn(Function):
         x, gy = _cont(x), _cont(gy)
         ctx.save_for_backward(x, gy)
         ctx.geom = geom
-        out = torch.zeros(wp_shape, device=x.device, dtype=torch.float32)   # padding columns (ldw > K) stay 0
+        out = _packed_buffer(wp_shape, K, x.device)   # padding columns (ldw > K) stay 0
         return ops.conv2d_wgrad(x, gy, KH, KW, s, p, out=out)
 
     @staticmethod
@@ -93,7 +101,7 @@ class ConvWgradBiasFn(Function):
         x, gy = _cont(x), _cont(gy)
         ctx.save_for_backward(x, gy)
         ctx.geom = geom
-        out = torch.zeros(wp_shape, device=x.device, dtype=torch.float32)
+        out = _packed_buffer(wp_shape, K, x.device)
         db = torch.empty(K, device=x.device, dtype=torch.float32)
         ops.conv2d_wgrad(x, gy, KH, KW, s, p, out=out, dbias=db)
         return out, db
@@ -241,7 +249,7 @@ class RgbWgradFn(Function):
         img, g = _cont(img), _cont(g)
         ctx.save_for_backward(img, g)
         ctx.cfg = rgb
-        out = torch.zeros(wp_shape, device=img.device, dtype=torch.float32)
+        out = _packed_buffer(wp_shape, g.shape[3], img.device)
         return ops.rgb_conv_wgrad(img, g, k, a, b, out)
 
     @staticmethod
@@ -361,7 +369,8 @@ class PackWeightsFn(Function):
     def forward(ctx, meta, *ws):
         dev = ws[0].device
         ws = [_cont(w) for w in ws]
-        outs = [torch.zeros(r, c, device=dev, dtype=torch.float32) for (r, c) in meta.groups]
+        kcols = [sum(e[0] for e in meta.entries if e[4] == gi) for gi in range(len(meta.groups))]
+        outs = [_packed_buffer((r, c), kcols[gi], dev) for gi, (r, c) in enumerate(meta.groups)]
         specs = _specs_from(meta, ws)
         wps = [outs[e[4]][:, e[5]:e[5] + e[0]] for e in meta.entries]
         ldws = [meta.groups[e[4]][1] for e in meta.entries]
@@ -474,7 +483,7 @@ class SnPackWeightsFn(Function):
         dev = ws[0].device
         specs = [ops.SnSpec(w, m.weight_u, m.weight_v) for m, w in zip(mods, ws)]
         ldws = [ops.round_up(sp.K, 4) for sp in specs]
-        outs = [torch.zeros(sp.T * sp.C, ld, device=dev, dtype=torch.float32) for sp, ld in zip(specs, ldws)]
+        outs = [_packed_buffer((sp.T * sp.C, ld), sp.K, dev) for sp, ld in zip(specs, ldws)]
         offs, n = ops.sn_scratch_floats(specs)
         scratch = torch.empty(n, device=dev, dtype=torch.float32)
         sigma = torch.empty(len(specs), device=dev, dtype=torch.float32)

@@ -146,7 +146,7 @@ class _TrunkFn(torch.autograd.Function):
             if gm is None:
                 gm = ops.fused_bias_act(g, None, y2, 3, 1, _SLOPE, 1.0)
             # conv2 (3x3 stride 2 on the blurred map)
-            gw2 = torch.zeros_like(wp2); gb2 = torch.empty_like(b2)
+            gw2 = A._packed_buffer(wp2.shape, co, wp2.device); gb2 = torch.empty_like(b2)
             ops.conv2d_wgrad(ob, gm, 3, 3, 2, 0, out=gw2, dbias=gb2)
             g_ob = ops.conv2d_dgrad(gm, wp2, tuple(ob.shape), 3, 3, 2, 0)
             # blur^T, times act'(o) * sqrt2
@@ -154,12 +154,12 @@ class _TrunkFn(torch.autograd.Function):
             _, g_o = ops.upfirdn2d_fused(g_ob, gk, 1, 1, gp, act_ref=o, slope=_SLOPE, gain=_GAIN, want_out=False,
                                          want_out2=True)
             del g_ob
-            gw1 = torch.zeros_like(wp1); gb1 = torch.empty_like(b1)
+            gw1 = A._packed_buffer(wp1.shape, ci, wp1.device); gb1 = torch.empty_like(b1)
             ops.conv2d_wgrad(x, g_o, 3, 3, 1, 1, out=gw1, dbias=gb1)
             g_x1 = ops.conv2d_dgrad(g_o, wp1, tuple(x.shape), 3, 3, 1, 1)
             del g_o
             # skip branch (1x1 conv on the blurred + decimated map), driven by the un-masked g
-            gws = torch.zeros_like(wps)
+            gws = A._packed_buffer(wps.shape, co, wps.device)
             ops.conv2d_wgrad(sb, g, 1, 1, 1, 0, out=gws)
             g_sb = ops.conv2d_dgrad(g, wps, tuple(sb.shape), 1, 1, 1, 0)
             gq = (4 - q0 - 1, x.shape[2] - sb.shape[2] * 2 + q0, 4 - q0 - 1, x.shape[1] - sb.shape[1] * 2 + q0)
@@ -172,7 +172,7 @@ class _TrunkFn(torch.autograd.Function):
                                             want_out=False, want_out2=True)
             del g_sb, g_x1
             grads[2 + 5 * bi: 7 + 5 * bi] = [gw1, gb1, gw2, gb2, gws]
-        gw0 = torch.zeros_like(wb[0]); gb0 = torch.empty_like(wb[1])
+        gw0 = A._packed_buffer(wb[0].shape, wb[1].numel(), wb[0].device); gb0 = torch.empty_like(wb[1])
         ops.rgb_conv_wgrad(images, gm, 1, 2.0, -1.0, gw0, gb0)
         grads[0], grads[1] = gw0, gb0
         return (None, None, None) + tuple(grads)
