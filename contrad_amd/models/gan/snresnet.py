@@ -89,9 +89,17 @@ class D_SNResNet18(BaseDiscriminator):
         if not inputs.is_cuda:
             raise RuntimeError('contrad_amd.D_SNResNet18 runs on the MI355X HIP path only (no CPU fallback)')
         mods = self._sn_modules()
-        # finetuning: features in eval mode (no power iteration in the trunk) under no_grad, base.py:114-119
-        packed = A.SnPackWeightsFn.apply(mods, self.training and not finetuning, *[m.weight_orig for m in mods])
-        wp = dict(zip(mods, packed))
+        if finetuning:
+            # base.py:114-119: the features are computed in eval mode (no power iteration in the trunk) under no_grad,
+            # the heads stay in the caller's mode -> two weight-prep launches
+            trunk, heads = mods[:-6], mods[-6:]
+            with torch.no_grad():
+                pt = A.SnPackWeightsFn.apply(trunk, False, *[m.weight_orig for m in trunk])
+            ph = A.SnPackWeightsFn.apply(heads, self.training, *[m.weight_orig for m in heads])
+            wp = dict(zip(trunk + heads, tuple(pt) + tuple(ph)))
+        else:
+            packed = A.SnPackWeightsFn.apply(mods, self.training, *[m.weight_orig for m in mods])
+            wp = dict(zip(mods, packed))
         images = inputs.contiguous().float()
         if finetuning:
             with torch.no_grad():

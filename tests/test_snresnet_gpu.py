@@ -104,3 +104,17 @@ def test_simclr_only_generator_loss_and_training_loop_run(tmp_path):
           '--evaluate_every', '2', '--logdir', logdir])
     log = open(os.path.join(logdir, 'log.txt')).read()
     assert '[Steps       2]' in log and 'nan' not in log.lower()
+
+
+def test_snresnet18_finetuning_flag_freezes_the_trunk(golden):
+    """forward(..., finetuning=True) (base.py:111-119): features under eval + no_grad (no power iteration, no gradient
+    in the trunk); the heads keep training."""
+    g = golden('snresnet')
+    D = _build(int(g['wseed']))
+    u_trunk, u_head = D.conv1.weight_u.clone(), D.linear.l1.weight_u.clone()
+    x = torch.from_numpy(g['aug'])[:4].to(DEV)
+    out, aux = D(x, finetuning=True, projection=True)
+    (out.sum() + aux['projection'].sum()).backward()
+    assert torch.equal(D.conv1.weight_u, u_trunk) and not torch.equal(D.linear.l1.weight_u, u_head)
+    assert D.conv1.weight_orig.grad is None or D.conv1.weight_orig.grad.abs().max().item() == 0.0
+    assert D.linear.l1.weight_orig.grad.abs().max().item() > 0 and D.projection[0].weight_orig.grad.abs().max().item() > 0
