@@ -97,7 +97,14 @@ class _DFunction(torch.autograd.Function):
         u_snaps, v_snaps = snaps[0::2], snaps[1::2]
         scratch = torch.empty(scr_n, device=dev, dtype=torch.float32)
         sigma = torch.empty(n, device=dev, dtype=torch.float32)
-        ops.sn_weight_prep(specs, wps, ldws, training, scratch, offs, sigma, u_snaps, v_snaps)
+        if trunk_grad:
+            ops.sn_weight_prep(specs, wps, ldws, training, scratch, offs, sigma, u_snaps, v_snaps)
+        else:
+            # finetuning (base.py:111-119): the features come from the network in eval mode -- no power iteration in the
+            # seven trunk layers -- while the heads stay in the caller's mode
+            ops.sn_weight_prep(specs[:7], wps[:7], ldws[:7], False, scratch, offs[:7], sigma, u_snaps[:7], v_snaps[:7])
+            ops.sn_weight_prep(specs[7:], wps[7:], ldws[7:], training, scratch, offs[7:], sigma[7:], u_snaps[7:],
+                               v_snaps[7:])
 
         biases = [m.bias for m in plan.layers]
         acts = []
@@ -277,8 +284,8 @@ class D_SNDCGAN(BaseDiscriminator):
         if not inputs.is_cuda:
             raise RuntimeError('contrad_amd.D_SNDCGAN runs on the MI355X HIP path only (no CPU fallback)')
         if finetuning:
-            # reference: features in eval mode under no_grad (base.py:114-119); power iteration is skipped
-            # for the trunk there, approximated here by freezing the trunk gradient (heads still train).
+            # reference: features in eval mode under no_grad (base.py:114-119): no trunk gradient, no power iteration
+            # in the trunk (handled inside the node); the heads still train
             inputs = inputs.detach()
         images = inputs.contiguous().float()
         logits, proj, proj2, feats = _DFunction.apply(self, images, bool(sg_linear), bool(want_features),

@@ -189,6 +189,31 @@ def test_eval_mode_and_input_gradient():
     assert rel(xd.grad, xr.grad) < TOL
 
 
+def test_finetuning_flag_matches_the_reference_semantics():
+    """forward(..., finetuning=True) (base.py:111-119): features from the network in eval mode under no_grad -- trunk u / v
+    untouched, zero trunk gradients -- while the heads run in train mode (their power iteration advances) and train;
+    values against the oracle evaluated the same way."""
+    _, D = build()
+    sd0 = {k: v.clone() for k, v in D.state_dict().items()}
+    x = torch.rand(6, 3, 32, 32, generator=torch.Generator().manual_seed(8))
+    out, aux = D(x.to(DEV), finetuning=True, projection=True)
+    (out.sum() + aux['projection'].pow(2).sum()).backward()
+    sd1 = D.state_dict()
+    for k in sd0:
+        if k.endswith(('weight_u', 'weight_v')) and sd0[k].numel() > 1:      # (a 1-vector u is +-1 before and after)
+            moved = not torch.equal(sd0[k], sd1[k])
+            assert moved == (not k.startswith('main.')), k
+    for k, p in D.named_parameters():
+        if k.startswith('main.'):
+            assert p.grad is None or p.grad.abs().max().item() == 0.0, k
+    assert D.linear.l1.weight_orig.grad.abs().max().item() > 0
+    osd = O.det_fill(O.sndcgan_d_param_shapes(), seed=1234)
+    with torch.no_grad():
+        feats = O.sndcgan_d_features(osd, x, training=False)
+    o, proj, _ = O.d_heads(osd, feats, sg_linear=False, training=True)
+    assert rel(out, o) < TOL and rel(aux['projection'], proj) < TOL
+
+
 def test_overlapped_gradient_exchange_single_rank_rccl():
     """The in-backward gradient exchange on a 1-rank RCCL group: every async all-reduce / wait is exercised and the
     gradients must be bitwise those of the plain backward (SUM over one rank)."""
