@@ -163,9 +163,15 @@ def loss_D_fn_separate(P, D, options, images, gen_images):
     calls; the losses act on the concatenated embeddings.  Same return contract as contrad.loss_D_fn."""
     from .training.gan.contrad import _ContraDContrastive, _GanDLoss
     N = images.size(0)
-    d_gen, aux_g = D(P.augment_fn(gen_images.detach()), sg_linear=True, projection=True, projection2=True)
-    d_real2, aux_r = D(P.augment_fn(torch.cat([images, images], dim=0)), sg_linear=True, projection=True,
-                       projection2=True)
+    aug_f = P.augment_fn(gen_images.detach())                       # (same RNG draw order as the two reference calls)
+    aug_r = P.augment_fn(torch.cat([images, images], dim=0))
+    if hasattr(D, 'call_batches'):
+        # the two calls as one pass over 3N images: only the minibatch-stddev statistics see the call boundary
+        (d_gen, aux_g), (d_real2, aux_r) = D.call_batches([aug_f, aug_r], sg_linear=True, projection=True,
+                                                          projection2=True)
+    else:
+        d_gen, aux_g = D(aug_f, sg_linear=True, projection=True, projection2=True)
+        d_real2, aux_r = D(aug_r, sg_linear=True, projection=True, projection2=True)
     proj = torch.cat([aux_r['projection'], aux_g['projection']], dim=0)
     proj2 = torch.cat([aux_r['projection2'], aux_g['projection2']], dim=0)
     d_all = torch.cat([d_real2, d_gen], dim=0)

@@ -68,6 +68,15 @@ class _ResBlock(nn.Module):
         self.cin, self.cout = in_channel, out_channel
 
 
+def minibatch_stddev_batches(x, batch_splits, stddev_group=4):
+    """The stddev channel with the statistics confined to consecutive sub-batches: ``batch_splits`` = sizes of the
+    discriminator calls that were merged into this one (see ResidualDiscriminatorP.call_batches)."""
+    if not batch_splits or len(batch_splits) == 1:
+        return minibatch_stddev_nhwc(x, stddev_group)
+    assert sum(batch_splits) == x.shape[0]
+    return torch.cat([minibatch_stddev_nhwc(t, stddev_group) for t in torch.split(x, list(batch_splits), dim=0)], dim=0)
+
+
 def minibatch_stddev_nhwc(x, stddev_group=4):
     """_minibatch_stddev_layer (discriminator.py:22-33) on NHWC: one extra channel holding, for sample b, the
     mean over (C,H,W) of the std over the group {b mod M, + M, + 2M, ...}, M = B / group.  (Tiny (B,4,4,512)
@@ -210,6 +219,26 @@ class ResidualDiscriminatorP(BaseDiscriminator):
         self.last_conv = _conv_layer(in_channel + 1, channels[4], 3)
         self.c_last_in = in_channel
         self.fuse_trunk = True          # (tests switch it off to compare the two graph constructions)
+        self._batch_splits = None
+
+    def call_batches(self, batches, **flags):
+        """Several discriminator calls with the same flags as ONE pass: every layer of this network acts per sample
+        except the minibatch-stddev statistics (discriminator.py:22-33), which stay confined to each original call's
+        batch.  Same results as ``[self(b, **flags) for b in batches]`` -- with one weight preparation, one launch per
+        layer over the concatenated batch and one weight-gradient reduction instead of one per call.  Returns the list
+        of per-call results."""
+        sizes = [int(b.shape[0]) for b in batches]
+        self._batch_splits = sizes
+        try:
+            out = self(torch.cat(list(batches), dim=0), **flags)
+        finally:
+            self._batch_splits = None
+        if isinstance(out, tuple):
+            logits, aux = out
+            parts = torch.split(logits, sizes, dim=0)
+            auxs = [{k: torch.split(v, sizes, dim=0)[i] for k, v in aux.items()} for i in range(len(sizes))]
+            return [(parts[i], auxs[i]) for i in range(len(sizes))]
+        return list(torch.split(out, sizes, dim=0))
 
     # ---- weight packing plan -------------------------------------------------------------------------
     def _pack(self, fused=False):
@@ -260,7 +289,7 @@ class ResidualDiscriminatorP(BaseDiscriminator):
         x = _TrunkFn.apply(self, images, blur, *wb)
         if rec is not None:
             rec.extend(self._trunk_rec)
-        x = minibatch_stddev_nhwc(x)
+        x = minibatch_stddev_batches(x, self._batch_splits)
         x = A.ConvBiasActFn.apply(x, wp[idx['last']], self.last_conv[1].bias,
                                   (self.last_conv[0].weight.shape[0], 3, 3, 1, 1), _SLOPE, _GAIN)
         if rec is not None:
@@ -291,7 +320,7 @@ class ResidualDiscriminatorP(BaseDiscriminator):
             s = A.UpFirDn2dFn.apply(x, blk.skip[0].kernel, 1, 2, (p0, p1, p0, p1))
             s = A.Conv2dFn.apply(s, wp[idx[(bi, 'skip')]], (co, 1, 1, 1, 0))
             x = A.LinCombFn.apply(o, s, inv, inv)
-        x = minibatch_stddev_nhwc(x)
+        x = minibatch_stddev_batches(x, self._batch_splits)
         x = A.ConvBiasActFn.apply(x, wp[idx['last']], self.last_conv[1].bias,
                                   (self.last_conv[0].weight.shape[0], 3, 3, 1, 1), _SLOPE, _GAIN)
         if rec is not None:

@@ -260,3 +260,28 @@ def test_fused_trunk_equals_the_node_per_op_graph(size, small32, N):
     for (k, p), q in zip(D.named_parameters(), D2.parameters()):
         assert p.grad is not None and q.grad is not None, k
         assert l2(p.grad, q.grad) < 1e-4, (k, l2(p.grad, q.grad))
+
+
+def test_call_batches_equals_separate_calls():
+    """ResidualDiscriminatorP.call_batches: train_stylegan2_contraD.py's two discriminator calls (fakes N, real views 2N)
+    as one pass -- the minibatch-stddev statistics stay inside each call's batch, everything else is per sample."""
+    import copy
+    torch.manual_seed(5)
+    D = ResidualDiscriminatorP(32, small32=True).to(DEV).train()
+    D2 = copy.deepcopy(D)
+    a, b = torch.rand(4, 3, 32, 32, device=DEV), torch.rand(8, 3, 32, 32, device=DEV)
+    flags = dict(sg_linear=True, projection=True, projection2=True)
+    (la, xa), (lb, xb) = D.call_batches([a, b], **flags)
+    la2, xa2 = D2(a, **flags)
+    lb2, xb2 = D2(b, **flags)
+    assert la.shape == (4, 1) and lb.shape == (8, 1) and xa['projection'].shape == (4, 128)
+    assert rel(la, la2) < 1e-5 and rel(lb, lb2) < 1e-5
+    assert rel(xa['projection2'], xa2['projection2']) < 1e-5 and rel(xb['projection'], xb2['projection']) < 1e-5
+    # NOT what one plain call on the concatenated batch gives (its stddev groups mix the two calls)
+    lc, _ = copy.deepcopy(D)(torch.cat([a, b]), **flags)
+    assert rel(lc[:4], la2) > 1e-4
+    w = torch.randn(12, 1, device=DEV)
+    ((torch.cat([la, lb]) * w).sum() + xa['projection'].pow(2).sum() + xb['projection2'].sin().sum()).backward()
+    ((torch.cat([la2, lb2]) * w).sum() + xa2['projection'].pow(2).sum() + xb2['projection2'].sin().sum()).backward()
+    for (k, p), q in zip(D.named_parameters(), D2.parameters()):
+        assert l2(p.grad, q.grad) < 1e-4, (k, l2(p.grad, q.grad))
