@@ -52,6 +52,7 @@ struct IgemmArgs {
   int P;                 // WGRAD: total positions n*ho*wo
   int ptiles_per_split;  // WGRAD
   int ny;                // lean kernels: grid.y folded into the 1-D grid (DGRAD classes / WGRAD splits)
+  int cgroup;            // lean DGRAD, stride 2: M-tiles per class group of the block order (0: class-interleaved)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -1011,7 +1012,20 @@ extern "C" int contrad_conv2d_dgrad(const contrad_conv_desc* d, const float* gy,
   const bool vec = vec_ok(d, MODE_DGRAD);
   pick_tile(Mc, d->C, vec, vec && lean_ok(d, MODE_DGRAD, 0), s * s, &bm, &bn);
   a.tiles_m = cdiv((int)Mc, bm); a.tiles_n = cdiv(d->C, bn);
-  return dispatch<MODE_DGRAD>(a, bm, bn, vec, dim3(a.tiles_m * a.tiles_n, s * s), (hipStream_t)stream);
+  // Block order of the strided lean DGRAD: the parity classes of a 3x3 stride-2 conv contract over 4, 2, 2 and 1 taps.
+  // With the classes of one M-tile on consecutive block ids (tile_n, class, tile_m) the kernel took exactly as long as
+  // its heaviest class alone (measured by launching single classes: 1.03 ms for class (0,0) vs 1.10 ms for all four;
+  // k3 / k4 / k5 kernels: 72 / 128 / 96 TF/s = 9/16, 16/16, 25/36 of the balanced rate) -- blocks that become resident
+  // together should carry equal work.  Groups of 8 M-tiles, class-major inside a group: neighbours are equal, and the
+  // gy rows a group's classes share are still cache-resident when the next class reads them.  3x3 s2 at batch 32:
+  // 72 -> 99, 84 -> 102, 78 -> 117, 82 -> 99 TF/s; groups of 32 / 64 lose again on layers with < ~100 M-tiles (few
+  // groups -> a tail of light classes).  tools/bench_conv.py; CONTRAD_DGRAD_CGROUP=0 restores the old order.
+  {
+    static const int g = []() { const char* e = getenv("CONTRAD_DGRAD_CGROUP"); return e ? atoi(e) : 8; }();
+    a.cgroup = (s > 1) ? (g < a.tiles_m ? g : a.tiles_m) : 0;
+  }
+  const int tm_pad = a.cgroup > 0 ? cdiv(a.tiles_m, a.cgroup) * a.cgroup : a.tiles_m;
+  return dispatch<MODE_DGRAD>(a, bm, bn, vec, dim3(tm_pad * a.tiles_n, s * s), (hipStream_t)stream);
 }
 
 extern "C" int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm, int* bn) {

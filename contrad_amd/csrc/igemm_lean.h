@@ -67,7 +67,8 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
 
   // 1-D grid, remapped so that each XCD (own L2) owns a contiguous run of ids.  Decode order = who shares operands:
   //   FWD    tile_n fastest                      (the N-tiles of one M-tile read the same im2col rows)
-  //   DGRAD  tile_n, then parity class, tile_m   (the s*s classes of one M-tile read the same gy pixels)
+  //   DGRAD  tile_n, then parity class, tile_m   (the s*s classes of one M-tile read the same gy pixels); stride 2:
+  //          groups of M-tiles, class-major inside a group (equal work on neighbouring block ids)
   //   WGRAD  all (tile_m, tile_n) of one split   (every tile of a split reads the same positions of x and gy)
   // Before this the 9..36 tiles of a WGRAD split sat on 8 different XCDs and HBM traffic was 6.5x the algorithmic bytes.
   const int lin = xcd_remap(blockIdx.x, gridDim.x);
@@ -77,6 +78,15 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     by = lin / tiles;
     const int b = lin - by * tiles;
     tile_n = b % p.tiles_n; tile_m = b / p.tiles_n;
+  } else if (MODE == MODE_DGRAD && p.cgroup > 0) {
+    // strided DGRAD: groups of cgroup M-tiles, class-major inside a group (igemm.hip, contrad_conv2d_dgrad)
+    const int per_group = p.cgroup * p.ny * p.tiles_n;
+    const int g = lin / per_group, r = lin - g * per_group;
+    by = r / (p.cgroup * p.tiles_n);
+    const int q = r - by * (p.cgroup * p.tiles_n);
+    tile_m = g * p.cgroup + q / p.tiles_n;
+    tile_n = q % p.tiles_n;
+    if (tile_m >= p.tiles_m) return;
   } else {
     tile_n = lin % p.tiles_n;
     const int r = lin / p.tiles_n;

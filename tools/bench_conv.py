@@ -21,6 +21,9 @@ if os.environ.get('CONV_SET') == 'sg2full':       # every conv of ResidualDiscri
     for R in (512, 256, 128, 64, 32, 16, 8):
         LAYERS += [(R, ch[R], ch[R], 3, 1, 1), (R + 1, ch[R], ch[R // 2], 3, 2, 0), (R // 2, ch[R], ch[R // 2], 1, 1, 0)]
 
+if os.environ.get('CONV_CUSTOM'):     # "H,C,K,k,s,p;H,C,K,k,s,p;..."
+    LAYERS = [tuple(int(v) for v in item.split(',')) for item in os.environ['CONV_CUSTOM'].split(';')]
+
 ITERS = int(os.environ.get('CONV_ITERS', '10'))
 WARM = int(os.environ.get('CONV_WARM', '3'))
 
