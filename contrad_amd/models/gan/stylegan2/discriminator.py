@@ -81,14 +81,15 @@ def minibatch_stddev_nhwc(x, stddev_group=4):
     """_minibatch_stddev_layer (discriminator.py:22-33) on NHWC: one extra channel holding, for sample b, the
     mean over (C,H,W) of the std over the group {b mod M, + M, + 2M, ...}, M = B / group.  (Tiny (B,4,4,512)
     tensor; kept in differentiable torch ops so the R1 double backward through sqrt/var is exact.)  The channel
-    dimension is padded to a multiple of 4 (zeros) for the float4 loaders of the conv engine."""
+    dimension is padded with zeros to a multiple of 16 (513 -> 528): a K-tile of the lean conv loop must not straddle a
+    filter tap, and the 516-channel layout of round 1 sent last_conv to the general kernel (37 TF/s)."""
     B, H, W, C = x.shape
     group = min(B, stddev_group)
     y = x.reshape(group, B // group, H, W, C)
     std = torch.sqrt(y.var(0, unbiased=False) + 1e-8)
     std = std.mean([1, 2, 3], keepdim=True)                       # (M,1,1,1)
     std = std.repeat(group, H, W, 1)                              # (B,H,W,1)
-    pad = (-(C + 1)) % 4
+    pad = (-(C + 1)) % 16
     parts = [x, std]
     if pad:
         parts.append(x.new_zeros(B, H, W, pad))
@@ -263,7 +264,7 @@ class ResidualDiscriminatorP(BaseDiscriminator):
                 idx[(bi, name)] = add(m.weight, K, C, k * k,
                                       m.scale / math.sqrt(2.0) if (fused and name == 'skip') else m.scale)
         m = self.last_conv[0]
-        cpad = A.ops.round_up(self.c_last_in + 1, 4)
+        cpad = A.ops.round_up(self.c_last_in + 1, 16)
         w_last = F.pad(m.weight, (0, 0, 0, 0, 0, cpad - (self.c_last_in + 1)))     # zero rows for the pad channels
         idx['last'] = add(w_last, m.weight.shape[0], cpad, 9, m.scale)
         dh, dp, T = self.d_hidden, self.d_project, 16

@@ -188,7 +188,8 @@ def test_config4_full_size_step_is_finite_and_deterministic():
     (4, 256, 256, 32, 64, 1, 1, 0),       # skip 1x1 on the blurred + decimated map
     (4, 259, 259, 64, 128, 3, 2, 0),
     (8, 67, 67, 256, 512, 3, 2, 0),
-    (16, 4, 4, 516, 512, 3, 1, 1),        # last_conv (513 channels padded to 516)
+    (16, 4, 4, 516, 512, 3, 1, 1),        # 513 channels padded to 516: the general float4 kernel
+    (16, 4, 4, 528, 512, 3, 1, 1),        # last_conv as the model lays it out (513 -> 528: the lean loop)
 ])
 def test_adjoint_identities_of_the_512_layer_shapes(shape):
     """<conv(x), g> == <x, dgrad(g)> == <W, wgrad(x, g)> on the kernels the 512^2 model selects."""
