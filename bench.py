@@ -248,7 +248,7 @@ def run_config(name, args, world, rank, dev, multi):
 
     counter = [0]
     graphed = [None]
-    use_graph = name == 'c10_b512' and not multi and args.graph != 'off'
+    use_graph = not multi and args.graph != 'off'
     if name == 'c10_b512':
         def one_step():
             if graphed[0] is not None:
@@ -259,6 +259,8 @@ def run_config(name, args, world, rank, dev, multi):
 
         def one_step():
             counter[0] += 1
+            if graphed[0] is not None:
+                return graphed[0](counter[0])
             return fn(P, G, D, opt_D, options, images, counter[0], reducer)
 
     def barrier():
@@ -290,10 +292,13 @@ def run_config(name, args, world, rank, dev, multi):
     if use_graph:
         # the timed region replays ONE captured hipGraph per step (engine.GraphedDStep); events cannot sit inside a
         # graph, so the dominant kernel is bracketed on eager steps run right after the timed region instead
-        from contrad_amd.engine import GraphedDStep
+        from contrad_amd.engine import GraphedDStep, GraphedSG2DStep
         ops.PROFILE = None
         try:
-            graphed[0] = GraphedDStep(P, G, D, opt_D, options, images, warmup=1)
+            if name == 'c10_b512':
+                graphed[0] = GraphedDStep(P, G, D, opt_D, options, images, warmup=1)
+            else:
+                graphed[0] = GraphedSG2DStep(P, G, D, opt_D, options, images, contrad_script=(name == 'sg2_512'), warmup=1)
             for _ in range(2):
                 one_step()
         except Exception as e:              # capture not available on this stack: the eager launch sequence is the same work
@@ -390,7 +395,7 @@ def main():
     ap.add_argument('--config', default='all', choices=sorted(CONFIGS) + ['all'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', default='on', choices=['on', 'off'],
-                    help='single-process c10_b512: replay the D-step as one captured hipGraph (engine.GraphedDStep)')
+                    help='single process: replay the D-step as one captured hipGraph (engine.GraphedDStep / GraphedSG2DStep)')
     ap.add_argument('--force-dist', action='store_true',
                     help='dev: run all collective code paths on a 1-rank RCCL group (single GPU)')
     ap.add_argument('--dev-local-batch', type=int, default=0,

@@ -273,3 +273,123 @@ class GraphedDStep(object):
         self.graph.replay()
         THROTTLE.end()
         return self.d_loss, self.aux
+
+
+class _StaticAugment(object):
+    """Stand-in for ``P.augment_fn`` inside a captured step: the k-th call of a step applies the k-th parameter block.
+    ``refresh()`` draws every block on the host with the pipeline's own sampler, in call order (the reference's RNG
+    order), and hands it into static device memory; the colour-op order travels in column 15, the Gaussian taps of
+    simclr_hq in a static kernel tensor."""
+
+    def __init__(self, aug, sizes, H, W, device):
+        from . import ops
+        self.aug, self.sizes, self.H, self.W, self.dev = aug, list(sizes), H, W, device
+        self.blocks = [torch.zeros(n, ops.AUG_NPARAM, device=device) for n in self.sizes]
+        self.radius = int((H // 10) / 2) if aug.p_blur is not None else 0
+        self.taps = [torch.zeros(2 * self.radius + 1, device=device) for _ in self.sizes] if self.radius > 0 else None
+        self.k = 0
+
+    def refresh(self):
+        from .hostio import upload
+        for i, n in enumerate(self.sizes):
+            Pm, _cf, sigma = self.aug.sample(n, self.H, self.W)
+            self.blocks[i].copy_(upload(Pm, self.dev))
+            if self.taps is not None:
+                _r, g = self.aug.blur_kernel(self.H, sigma)
+                self.taps[i].copy_(upload(g.view(1, -1), self.dev).view(-1))
+
+    def __call__(self, x):
+        from . import ops
+        i, self.k = self.k, self.k + 1
+        if x.shape[0] != self.sizes[i]:
+            raise RuntimeError('captured step: augmentation call %d saw %d images, planned %d' % (i, x.shape[0], self.sizes[i]))
+        out = ops.simclr_augment(x.detach().contiguous().float(), self.blocks[i], -1, self.aug.r_c is not None)
+        if self.taps is not None:
+            out = ops.gaussian_blur_masked(out, self.blocks[i], self.taps[i], self.radius)
+        if self.aug.p_cutout is not None:
+            ops.cutout_masked_(out, self.blocks[i], self.aug.cutout_length)
+        return out
+
+
+class GraphedSG2DStep(object):
+    """The StyleGAN2 D-steps (``d_step_stylegan2`` / ``d_step_stylegan2_contrad``) as ONE captured hipGraph.
+
+    These steps are 500-800 launches of mostly small kernels (the R1 double backward alone builds ~300 nodes); enqueued
+    from Python they cost 19-27 ms of host time per step depending on the host core -- the same order as the 19 ms of GPU
+    work of BASELINE config 4, which therefore flipped between GPU-bound (20.5 ms) and host-bound (27 ms) from run to run.
+    Everything random is drawn OUTSIDE the graph, in the eager path's order -- device draws (latents, mixing latents,
+    per-layer noise) into static tensors, host draws (mixing layers, augmentation blocks, blur taps) handed over -- so a
+    replay consumes exactly the random numbers the eager step would: ``tests/test_graph_gpu.py`` checks bitwise equality.
+    With lazy R1 (``d_reg_every`` > 1) the graph holds the plain step and the R1 steps run eagerly."""
+
+    def __init__(self, P, G, D, opt_D, options, images, contrad_script, style_mix=0.9, warmup=2):
+        import argparse
+        if dist_on():
+            raise NotImplementedError('GraphedSG2DStep: single process')
+        self.P, self.G, self.D, self.opt, self.options, self.images = P, G, D, opt_D, options, images
+        self.contrad_script, self.style_mix = contrad_script, style_mix
+        self.eager = d_step_stylegan2_contrad if contrad_script else d_step_stylegan2
+        N, dev = images.size(0), images.device
+        self.N = N
+        self.r1_in_graph = P.lbd_r1 > 0 and P.d_reg_every == 1
+        for s in range(1, max(warmup, 1) + 1):                      # optimizer state, workspaces, caches
+            self.eager(P, G, D, opt_D, options, images, s if P.d_reg_every == 1 else 1, None, style_mix)
+        H, W = images.shape[2], images.shape[3]
+        sizes = ([N, 2 * N] if contrad_script else [3 * N]) + ([N] if self.r1_in_graph else [])
+        self.saug = _StaticAugment(P.augment_fn, sizes, H, W, dev)
+        self.Pg = argparse.Namespace(**vars(P))
+        self.Pg.augment_fn = self.saug
+        self.z = torch.zeros(N, G.style_dim, device=dev)
+        self.z_mix = torch.zeros(N, G.style_dim, device=dev)
+        self.mix_layer = torch.zeros(N, device=dev)
+        self.noise = [torch.zeros(N, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), device=dev) for i in range(G.num_layers)]
+        self.hyper = torch.ones(3, device=dev)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.d_loss, self.aux = self._body()
+        torch.cuda.synchronize()
+
+    def _refresh(self):
+        from .hostio import upload
+        G, N, dev = self.G, self.N, self.images.device
+        self.z.normal_()                                             # G.sample_latent (generator.py:233-234)
+        mixing = G.training and self.style_mix > 0
+        if mixing:                                                   # generator.py:252-259
+            self.z_mix.normal_()
+            nomix = torch.rand(N) >= self.style_mix
+            mix_layer = torch.randint(G.n_latent, (N,)).masked_fill(nomix, G.n_latent)
+            self.mix_layer.copy_(upload(mix_layer.float().view(-1, 1), dev).view(-1))
+        for t in self.noise:                                         # NoiseInjection, layer order (generator.py:91-92)
+            t.normal_()
+        self.saug.refresh()
+        self.hyper.copy_(upload(torch.tensor([self.opt.hyper_values()], dtype=torch.float32), dev).view(3))
+
+    def _body(self):
+        P, G, D = self.Pg, self.G, self.D
+        self.saug.k = 0
+        with torch.no_grad():
+            gen = G(self.z, style_mix=self.style_mix, noise=self.noise, _mix=(self.z_mix, self.mix_layer))
+        if self.contrad_script:
+            d_loss, aux = loss_D_fn_separate(P, D, self.options, self.images, gen)
+        else:
+            d_loss, aux = P.train_fn["D"](P, D, self.options, self.images, gen)
+        loss = d_loss + aux['penalty']
+        if self.r1_in_graph:
+            r1 = r1_loss(D, self.images, self.saug)
+            loss = loss + (0.5 * P.lbd_r1) * r1 * P.d_reg_every
+            aux['r1'] = r1
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        self.opt.step_captured(self.hyper)
+        return d_loss, aux
+
+    def __call__(self, step):
+        P = self.P
+        if P.lbd_r1 > 0 and P.d_reg_every > 1 and step % P.d_reg_every == 0:      # lazy-R1 step: eager
+            return self.eager(P, self.G, self.D, self.opt, self.options, self.images, step, None, self.style_mix)
+        THROTTLE.begin()
+        self._refresh()
+        self.graph.replay()
+        THROTTLE.end()
+        return self.d_loss, self.aux

@@ -23,6 +23,7 @@ import torch.nn as nn
 
 from .... import ops
 from .... import autograd_ops as A
+from ....hostio import upload
 
 
 class _EqualLinearParams(nn.Module):
@@ -148,6 +149,12 @@ class Generator(nn.Module):
 
     def sample_latent(self, num_samples):
         return torch.randn(num_samples, self.style_dim, device=self.device)
+
+    def _layer_idx(self, device):
+        t = getattr(self, '_layer_idx_cache', None)
+        if t is None or t.device != device:
+            t = self._layer_idx_cache = torch.arange(self.n_latent, device=device, dtype=torch.float32)[None]
+        return t
 
     # ---- cached weight preparation -----------------------------------------------------------------------
     def _modconvs(self):
@@ -353,8 +360,10 @@ class Generator(nn.Module):
             noise = [None] * self.num_layers
         latents = latent.unsqueeze(1).repeat(1, self.n_latent, 1) if latent.ndim < 3 else latent
         if mixing:
-            layer_idx = torch.arange(self.n_latent)[None]
-            mask = (layer_idx < mix_layer.unsqueeze(1)).float().unsqueeze(-1).to(latents.device)
+            if not mix_layer.is_cuda:       # CPU draw -> device without a host-side wait (contrad_amd/hostio.py)
+                mix_layer = upload(mix_layer.float().view(-1, 1), latents.device).view(-1)
+            layer_idx = self._layer_idx(latents.device)
+            mask = (layer_idx < mix_layer.float().unsqueeze(1)).float().unsqueeze(-1)
             latents = latents * mask + latent_mix.unsqueeze(1) * (1 - mask)
         B = latents.shape[0]
         x = self.input.const.permute(0, 2, 3, 1).expand(B, -1, -1, -1).contiguous()        # NHWC const input

@@ -60,3 +60,53 @@ def test_graph_replay_equals_eager_steps(N):
     assert torch.equal(want_u, D.main[0].weight_u) and torch.equal(want_bn, G.norm_init.running_mean)
     st = opt.state[next(iter(D.parameters()))]
     assert int(st['step']) == W + K
+
+
+@pytest.mark.parametrize('contrad_script,every', [(False, 1), (True, 2)])
+def test_stylegan2_graph_replay_equals_eager_steps(contrad_script, every):
+    """GraphedSG2DStep: the StyleGAN2 D-steps (single 3N call + R1 every step / separate calls + lazy R1) replayed from a
+    captured graph consume exactly the eager path's random numbers -> bitwise identical weights and losses."""
+    from contrad_amd.augment import SimCLRAugment
+    from contrad_amd.engine import GraphedSG2DStep, d_step_stylegan2, d_step_stylegan2_contrad, set_grad
+    from contrad_amd.models.gan import get_architecture
+    from contrad_amd.optim import FusedAdam
+    from contrad_amd.training.gan import setup
+    N, K, W = 8, 4, 2
+    eager = d_step_stylegan2_contrad if contrad_script else d_step_stylegan2
+
+    def build():
+        torch.manual_seed(0); np.random.seed(0)
+        G, D = get_architecture('stylegan2', (32, 32, 3))
+        G, D = G.to(DEV).train(), D.to(DEV).train()
+        P = setup(argparse.Namespace(mode='contrad', aug='simclr', temp=0.1, lbd_a=1.0, distributed=False, lbd_r1=0.1,
+                                     d_reg_every=every))
+        P.augment_fn = SimCLRAugment(scale=(0.2, 1.0))
+        opt = FusedAdam(D.parameters(), lr=2e-3, betas=(0.0, 0.99))
+        set_grad(G, False)
+        x = torch.rand(N, 3, 32, 32, generator=torch.Generator().manual_seed(1)).to(DEV)
+        return P, G, D, opt, x
+
+    def seed():
+        torch.manual_seed(7); np.random.seed(7); torch.cuda.manual_seed(7)
+
+    P, G, D, opt, x = build()
+    seed()
+    le = []
+    for s in range(1, W + 1):
+        eager(P, G, D, opt, {'loss': 'nonsat'}, x, s if every == 1 else 1)
+    for s in range(1, K + 1):
+        dl, aux = eager(P, G, D, opt, {'loss': 'nonsat'}, x, s)
+        le.append((dl.item(), aux['penalty'].item(), aux['r1'].item() if 'r1' in aux else None))
+    want = [p.detach().clone() for p in D.parameters()]
+
+    P, G, D, opt, x = build()
+    seed()
+    g = GraphedSG2DStep(P, G, D, opt, {'loss': 'nonsat'}, x, contrad_script=contrad_script, warmup=W)
+    lg = []
+    for s in range(1, K + 1):
+        dl, aux = g(s)
+        lg.append((dl.item(), aux['penalty'].item(), aux['r1'].item() if 'r1' in aux else None))
+    assert lg == le
+    assert any(v[2] is not None for v in lg)
+    for a, p in zip(want, D.parameters()):
+        assert torch.equal(a, p.detach())
