@@ -26,6 +26,19 @@ def _cont(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+_CONSTS = {}
+
+
+def _device_constant(values, device):
+    """Small read-only float tensor on the device, built once per (values, device): a host -> device copy inside a
+    captured hipGraph is not permitted (and costs a synchronisation outside one)."""
+    key = (values, str(device))
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.tensor(values, device=device, dtype=torch.float32)
+    return t
+
+
 def _packed_buffer(shape, k_written, device):
     """Output buffer in the packed [(tap, c)][ldw] layout: the kernels write columns [0, k_written) of every row, so a
     zero fill is needed only when padding columns exist (ldw > K) -- ~110 fill launches per StyleGAN2-32 step otherwise."""
@@ -411,7 +424,7 @@ class UnpackWeightsFn(Function):
         ldws = [meta.groups[e[4]][1] for e in meta.entries]
         offs, n = ops.sn_scratch_floats(specs)
         scratch = torch.empty(n, device=dev, dtype=torch.float32)
-        sigma = torch.tensor([1.0 / e[3] for e in meta.entries], device=dev, dtype=torch.float32)
+        sigma = _device_constant(tuple(1.0 / e[3] for e in meta.entries), dev)
         ops.sn_weight_grad(specs, gwps, ldws, gwps, gws, scratch, offs, sigma)
         ctx.meta, ctx.shapes = meta, shapes
         return tuple(gws)
