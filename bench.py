@@ -303,6 +303,11 @@ def run_config(name, args, world, rank, dev, multi):
                 graphed[0] = GraphedSG2DStep(P, G, D, opt_D, options, images, contrad_script=(name == 'sg2_512'), warmup=1)
             for _ in range(2):
                 one_step()
+            if cfg['d_reg_every'] > 1:
+                # torch.cuda.graph() empties the caching allocator before capturing: run the eager lazy-R1 step once
+                # more so that its ~25 GB of buffers are cached again before the timed window (a cold process paid 0.5 s
+                # of hipMalloc inside the window for it: 96 instead of 67 ms per step over the 16-step window)
+                graphed[0](cfg['d_reg_every'])
         except Exception as e:              # capture not available on this stack: the eager launch sequence is the same work
             sys.stderr.write('bench.py: hipGraph capture failed (%r); timing the eager launch sequence\n' % (e,))
             graphed[0], use_graph = None, False
@@ -312,8 +317,15 @@ def run_config(name, args, world, rank, dev, multi):
         counter[0] = 0
     barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        d_loss, aux = one_step()
+    if os.environ.get('CONTRAD_BENCH_STEP_TIMES'):          # dev: per-step wall times (synchronises every step)
+        for i in range(steps):
+            ts = time.perf_counter()
+            d_loss, aux = one_step()
+            torch.cuda.synchronize()
+            sys.stderr.write('%s step %d: %.2f ms\n' % (name, i + 1, (time.perf_counter() - ts) * 1e3))
+    else:
+        for _ in range(steps):
+            d_loss, aux = one_step()
     barrier()
     dt = time.perf_counter() - t0
     if use_graph:                       # same kernels, same shapes, eager launches with the dominant kernel bracketed
