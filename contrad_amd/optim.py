@@ -51,10 +51,14 @@ class FusedAdam(torch.optim.Optimizer):
         beta1, beta2 = (f32(b) for b in group['betas'])
         step = None
         for p in group['params']:
-            st = self.state[p]
+            st = self.state.get(p)
+            if not st:                       # never received a gradient: no optimizer state, not part of the update
+                continue
             st['step'] = int(st['step']) + 1
             step = st['step']
             torch.autograd.graph.increment_version(p)
+        if step is None:
+            raise RuntimeError('hyper_values: no parameter carries optimizer state yet (run eager steps first)')
         bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
         return [f32(group['lr']) / bc1, 1.0 / math.sqrt(bc2), float(grad_scale)]
 
