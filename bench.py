@@ -345,6 +345,42 @@ def run_config(name, args, world, rank, dev, multi):
     value = global_batch * steps / dt
     finite = bool(torch.isfinite(d_loss).item() and torch.isfinite(aux['penalty']).item())
     peak_mem = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+
+    # ---- generator step, reported separately -- never part of `value` ----
+    g_step = None
+    if not args.no_g_step and not multi:
+        try:
+            from contrad_amd.training.gan.contrad import loss_G_fn
+            opt_G = FusedAdam(G.parameters(), lr=opt['lr'], betas=tuple(opt['beta']))
+            set_grad(G, True); set_grad(D, False)
+
+            def g_once():
+                if name == 'c10_b512':
+                    gen = G(G.sample_latent(n_local))
+                else:
+                    gen = G(G.sample_latent(n_local), style_mix=0.9)
+                g_loss = loss_G_fn(P, D, options, images, gen)
+                opt_G.zero_grad()
+                g_loss.backward()
+                opt_G.step()
+                return g_loss
+            for _ in range(2):
+                g_once()
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                gl = g_once()
+            torch.cuda.synchronize()
+            tg = (time.perf_counter() - tg) / reps
+            g_step = {"ms_per_step": round(tg * 1e3, 3), "images_per_sec": round(n_local / tg, 1),
+                      "finite": bool(torch.isfinite(gl).item()),
+                      "what": "generator step (G forward with grad -> augment -> D -> loss_G_fn -> backward through D, the "
+                              "augmentation and G -> Adam on G), eager launches, %d timed steps; not part of `value`" % reps}
+            set_grad(G, False); set_grad(D, True)
+            del opt_G
+        except Exception as e:                      # never let the side measurement take the headline down
+            sys.stderr.write('bench.py: generator-step measurement skipped (%r)\n' % (e,))
     out = None
     if rank == 0:
         # dominant kernel = the conv-engine instance with the largest summed device time (chosen on the warm-up
@@ -393,6 +429,8 @@ def run_config(name, args, world, rank, dev, multi):
                "roofline": roofline}
         if cfg['d_reg_every'] > 1:
             out["config"]["r1_steps_in_window"] = steps // cfg['d_reg_every']
+        if g_step is not None:
+            out["g_step"] = g_step
     # release this workload's memory before the next one
     del G, D, opt_D, images, P
     ops._ws_cache.clear()
@@ -408,6 +446,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=None, help='untimed warm-up steps (default: 5 / 3 / 2)')
     ap.add_argument('--config', default='all', choices=sorted(CONFIGS) + ['all'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-g-step', action='store_true', help='skip the separately reported generator-step timing')
     ap.add_argument('--graph', default='on', choices=['on', 'off'],
                     help='single process: replay the D-step as one captured hipGraph (engine.GraphedDStep / GraphedSG2DStep)')
     ap.add_argument('--force-dist', action='store_true',
