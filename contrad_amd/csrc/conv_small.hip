@@ -291,10 +291,13 @@ __global__ __launch_bounds__(256) void rgb_dgrad3_tile_kernel(const float* __res
                                                               const float* __restrict__ bias, float* __restrict__ out,
                                                               int N, int C, int H, int W, int K, int ldy, int ldw, int TH,
                                                               int act, float out_scale, float out_shift) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];   // [(TH + 2)][(W + 2)][DG_PS]
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // [(TH + 2)][(W + 2)][DG_PS] + weights [9][3][DG_CK]
   const int tiles_h = cdiv_dev(H, TH);
   const int n = blockIdx.x / tiles_h, h0 = (blockIdx.x % tiles_h) * TH;
   const int HW2 = W + 2, HH2 = TH + 2;
+  float* wl = tile + (size_t)HH2 * HW2 * DG_PS;     // this pass's weights: ds_read broadcasts stay in order with the
+                                                     // tile reads (a scalar-load stream shares lgkmcnt with them and
+                                                     // returns out of order: the kernel waited on every group)
   const int r = threadIdx.x / W, c = threadIdx.x - r * W;
   const bool live = threadIdx.x < TH * W && h0 + r < H;
   float acc[3] = {0.f, 0.f, 0.f};
@@ -309,6 +312,13 @@ __global__ __launch_bounds__(256) void rgb_dgrad3_tile_kernel(const float* __res
         v = *reinterpret_cast<const float4*>(gy + ((size_t)(n * H + h) * W + w) * ldy + k0 + q * 4);
       *reinterpret_cast<float4*>(tile + (size_t)p * DG_PS + q * 4) = v;
     }
+    for (int e = threadIdx.x; e < 9 * 3 * (DG_CK / 4); e += blockDim.x) {
+      const int q = e % (DG_CK / 4), tc = e / (DG_CK / 4);      // tc = tap * 3 + cc
+      const int tap = tc / 3, cc = tc - tap * 3;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cc < C) v = *reinterpret_cast<const float4*>(wp + (size_t)(tap * C + cc) * ldw + k0 + q * 4);
+      *reinterpret_cast<float4*>(wl + tc * DG_CK + q * 4) = v;
+    }
     __syncthreads();
     if (live) {
 #pragma unroll
@@ -317,16 +327,14 @@ __global__ __launch_bounds__(256) void rgb_dgrad3_tile_kernel(const float* __res
         for (int kw = 0; kw < 3; ++kw) {
           // out[h][w] += gy[h + 1 - kh][w + 1 - kw] * w[kh][kw]; tile row of gy row (h + 1 - kh) is (r + 2 - kh)
           const float4* g4 = reinterpret_cast<const float4*>(tile + (size_t)((r + 2 - kh) * HW2 + (c + 2 - kw)) * DG_PS);
-          const float* wt = wp + (size_t)((kh * 3 + kw) * C) * ldw + k0;
+          const float4* w4 = reinterpret_cast<const float4*>(wl + (kh * 3 + kw) * 3 * DG_CK);
 #pragma unroll
           for (int q = 0; q < DG_CK / 4; ++q) {
             const float4 g = g4[q];
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc) {
-              if (cc < C) {
-                const float4 ww = *reinterpret_cast<const float4*>(wt + (size_t)cc * ldw + q * 4);   // wave-uniform
-                acc[cc] = fmaf(g.x, ww.x, fmaf(g.y, ww.y, fmaf(g.z, ww.z, fmaf(g.w, ww.w, acc[cc]))));
-              }
+              const float4 ww = w4[cc * (DG_CK / 4) + q];       // same address in every lane: LDS broadcast
+              acc[cc] = fmaf(g.x, ww.x, fmaf(g.y, ww.y, fmaf(g.z, ww.z, fmaf(g.w, ww.w, acc[cc]))));
             }
           }
         }
@@ -430,7 +438,7 @@ extern "C" int contrad_rgb_conv_dgrad(const float* gy, const float* wp, const fl
   const long long total = (long long)N * H * W;
   if (k == 3 && !mod && !residual && C <= 3 && (K % DG_CK) == 0 && W <= 256) {   // LDS-tiled thread-per-pixel form
     const int TH = 256 / W < 1 ? 1 : (256 / W > H ? H : 256 / W);
-    const size_t smem = (size_t)(TH + 2) * (W + 2) * DG_PS * sizeof(float);
+    const size_t smem = ((size_t)(TH + 2) * (W + 2) * DG_PS + 9 * 3 * DG_CK) * sizeof(float);
     if (smem <= 64 * 1024) {
       hipLaunchKernelGGL(rgb_dgrad3_tile_kernel, dim3(N * cdiv(H, TH)), dim3(256), smem, (hipStream_t)stream, gy, wp, bias,
                          out, N, C, H, W, K, ldy, ldw, TH, act, out_scale, out_shift);
