@@ -224,20 +224,25 @@ class GraphedDStep(object):
         self.aug = P.augment_fn
         if not isinstance(self.aug, SimCLRAugment) or self.aug.p_blur is not None or dist_on():
             raise NotImplementedError('GraphedDStep: single-process simclr pipeline')
-        self.images = images
+        self.images = images.clone()                    # static input: load_images() hands over a new real batch
         N = images.size(0)
         dev = images.device
         self.N = N
-        for _ in range(max(warmup, 1)):                 # optimizer state, workspaces, allocator pools
+        for _ in range(warmup if len(opt_D.state) else max(warmup, 1)):     # optimizer state, workspaces, pools
             d_step(P, G, D, opt_D, options, images)
         self.z = torch.zeros(N, G.nz, device=dev)
         self.params = torch.zeros(3 * N, ops.AUG_NPARAM, device=dev)
         self.hyper = torch.ones(3, device=dev)
         torch.cuda.synchronize()          # (capture records launches, it does not run them: the inputs stay untouched)
+        G.invalidate_cache()              # the step re-packs G's weights itself: G moves between D-steps in training
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.d_loss, self.aux = self._body()
+        G.invalidate_cache()              # (what the capture allocated is filled by the first replay, not now)
         torch.cuda.synchronize()
+
+    def load_images(self, images):
+        self.images.copy_(images)
 
     def _refresh_inputs(self):
         from .hostio import upload
@@ -265,7 +270,9 @@ class GraphedDStep(object):
         self.opt.zero_grad(set_to_none=True)
         (d_loss + gan).backward()
         self.opt.step_captured(self.hyper)
-        return d_loss, {'penalty': gan, 'd_real': d_real, 'd_gen': d_gen}
+        # detached: the step's autograd graph must not outlive the capture (its AccumulateGrad nodes are tied to the
+        # capture stream; an eager backward later on would have to synchronise with it)
+        return d_loss.detach(), {'penalty': gan.detach(), 'd_real': d_real.detach(), 'd_gen': d_gen.detach()}
 
     def __call__(self):
         THROTTLE.begin()
@@ -326,13 +333,13 @@ class GraphedSG2DStep(object):
         import argparse
         if dist_on():
             raise NotImplementedError('GraphedSG2DStep: single process')
-        self.P, self.G, self.D, self.opt, self.options, self.images = P, G, D, opt_D, options, images
+        self.P, self.G, self.D, self.opt, self.options, self.images = P, G, D, opt_D, options, images.clone()
         self.contrad_script, self.style_mix = contrad_script, style_mix
         self.eager = d_step_stylegan2_contrad if contrad_script else d_step_stylegan2
         N, dev = images.size(0), images.device
         self.N = N
         self.r1_in_graph = P.lbd_r1 > 0 and P.d_reg_every == 1
-        for s in range(1, max(warmup, 1) + 1):                      # optimizer state, workspaces, caches
+        for s in range(1, (warmup if len(opt_D.state) else max(warmup, 1)) + 1):     # optimizer state, workspaces
             self.eager(P, G, D, opt_D, options, images, s if P.d_reg_every == 1 else 1, None, style_mix)
         H, W = images.shape[2], images.shape[3]
         sizes = ([N, 2 * N] if contrad_script else [3 * N]) + ([N] if self.r1_in_graph else [])
@@ -345,10 +352,15 @@ class GraphedSG2DStep(object):
         self.noise = [torch.zeros(N, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), device=dev) for i in range(G.num_layers)]
         self.hyper = torch.ones(3, device=dev)
         torch.cuda.synchronize()
+        G.invalidate_cache()              # as GraphedDStep: the packed tables are rebuilt inside the step
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.d_loss, self.aux = self._body()
+        G.invalidate_cache()
         torch.cuda.synchronize()
+
+    def load_images(self, images):
+        self.images.copy_(images)
 
     def _refresh(self):
         from .hostio import upload
@@ -382,7 +394,7 @@ class GraphedSG2DStep(object):
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
         self.opt.step_captured(self.hyper)
-        return d_loss, aux
+        return d_loss.detach(), {k: v.detach() for k, v in aux.items()}     # (see GraphedDStep._body)
 
     def __call__(self, step):
         P = self.P

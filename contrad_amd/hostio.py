@@ -63,13 +63,18 @@ class StepThrottle(object):
 
     def __init__(self):
         self.events = []
+        self.depth = 0                      # re-entrant: a step function called inside a throttled iteration is a no-op
 
     def begin(self):
+        self.depth += 1
+        if self.depth > 1:
+            return
         while len(self.events) >= 2:
             self.events.pop(0).synchronize()
 
     def end(self):
-        if _SYNC:
+        self.depth = max(self.depth - 1, 0)
+        if _SYNC or self.depth > 0:
             return
         e = torch.cuda.Event()
         e.record()

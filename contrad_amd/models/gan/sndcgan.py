@@ -390,6 +390,11 @@ class G_SNDCGAN(nn.Module):
         _device = next(self.parameters()).device
         return upload(torch.empty(n_samples, self.nz).uniform_(-1, 1), _device)
 
+    def invalidate_cache(self):
+        """Forget the packed weights: the next forward re-packs (a captured step must RECORD the pack launch, and the
+        buffers a capture allocated hold nothing until the first replay)."""
+        self._packed, self._packed_key = None, None
+
     def _weights(self):
         ws = [self.linear.weight] + [self.main[3 * j].weight for j in range(4)]
         key = tuple((w.data_ptr(), w._version) for w in ws)

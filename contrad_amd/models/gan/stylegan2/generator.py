@@ -165,6 +165,10 @@ class Generator(nn.Module):
             out.append(t.conv)
         return out
 
+    def invalidate_cache(self):
+        """Forget the packed tables (see G_SNDCGAN.invalidate_cache)."""
+        self._cache_key, self._cache = None, None
+
     def _prepared(self, differentiable=False):
         """Packed weights / biases / Wsq tables.  Forward-only: built under no_grad and cached on the parameters'
         version counters.  ``differentiable``: rebuilt inside the autograd graph on every call."""

@@ -20,7 +20,7 @@ import torch.distributed as dist
 
 from . import config
 from .augment import get_augment
-from .engine import GradAllReducer, OverlappedGradReducer, sample_generator, set_grad
+from .engine import GradAllReducer, GraphedDStep, OverlappedGradReducer, sample_generator, set_grad
 from .hostio import THROTTLE
 from .models.gan import get_architecture
 from .optim import FusedAdam
@@ -52,6 +52,8 @@ def parse_args(argv=None):
     parser.add_argument('--max_steps', default=None, type=int, help='override options.max_steps')
     parser.add_argument('--logdir', default=None, type=str)
     parser.add_argument('--seed', default=0, type=int)
+    parser.add_argument('--graph', action='store_true',
+                        help='replay the D-step from a captured hipGraph (single process, simclr pipeline)')
     return parser.parse_args(argv)
 
 
@@ -99,7 +101,28 @@ def _dataset_loader(name, batch, rank, world, workers):
         sampler.set_epoch(epoch)
 
 
-def train_step(P, opt, G, D, opt_G, opt_D, loader, step, reducers):
+class GraphedCritic(object):
+    """``--graph``: the critic iteration of ``train_step`` replayed from ONE captured hipGraph (engine.GraphedDStep).
+    Captured lazily at the first critic iteration AFTER the optimizer holds state (i.e. from the second one on); every
+    replay consumes exactly the host random numbers the eager iteration would, so a run with ``--graph`` produces
+    bitwise the checkpoints of a run without (tests/test_graph_gpu.py)."""
+
+    def __init__(self):
+        self.step = None
+
+    def __call__(self, P, opt, G, D, opt_D, images):
+        if self.step is None:
+            if not len(opt_D.state):
+                return None                       # first iteration: eager (Adam state does not exist yet)
+            if P.mode != 'contrad':
+                raise NotImplementedError("--graph captures the ContraD critic iteration (--mode contrad), not '%s'"
+                                          % P.mode)
+            self.step = GraphedDStep(P, G, D, opt_D, opt, images, warmup=0)
+        self.step.load_images(images)
+        return self.step()
+
+
+def train_step(P, opt, G, D, opt_G, opt_D, loader, step, reducers, graphed=None):
     """One iteration of train_gan.py:141-179.  ``loader`` yields (images, labels); a fresh real batch is drawn for
     every critic iteration (train_gan.py:153-155) and the last one feeds the G-step.  Returns the loss tensors (no
     host sync)."""
@@ -112,6 +135,10 @@ def train_step(P, opt, G, D, opt_G, opt_D, loader, step, reducers):
     set_grad(G, False); set_grad(D, True)
     for _ in range(opt['n_critic']):
         images, _labels = next(loader)
+        done = graphed(P, opt, G, D, opt_D, images) if graphed is not None else None
+        if done is not None:
+            d_loss, aux = done
+            continue
         gen_images = sample_generator(G, images.size(0), enable_grad=False)
         d_loss, aux = P.train_fn["D"](P, D, opt, images, gen_images)
         loss = d_loss + aux['penalty']
@@ -128,8 +155,10 @@ def train_step(P, opt, G, D, opt_G, opt_D, loader, step, reducers):
     world = red_G() if red_G is not None else 1
     opt_G.step(grad_scale=1.0 / world) if world > 1 else opt_G.step()
     THROTTLE.end()
-    return {'G_loss': g_loss, 'D_loss': d_loss, 'D_penalty': aux['penalty'], 'D_real': aux['d_real'],
-            'D_gen': aux['d_gen']}
+    # detached: a loss that keeps last iteration's autograd graph (and its AccumulateGrad nodes) alive would tie the next
+    # D-step to the stream that graph ran on -- which breaks a hipGraph capture
+    return {'G_loss': g_loss.detach(), 'D_loss': d_loss.detach(), 'D_penalty': aux['penalty'].detach(),
+            'D_real': aux['d_real'].detach(), 'D_gen': aux['d_gen'].detach()}
 
 
 def main(argv=None):
@@ -211,9 +240,15 @@ def main(argv=None):
     log(f"# Params - G: {sum(p.numel() for p in G.parameters())}, D: {sum(p.numel() for p in D.parameters())}")
     log(str(options))
 
+    graphed = None
+    if P.graph:
+        if world > 1:
+            log('--graph: single process only (RCCL inside a captured graph is not validated here) -> eager')
+        else:
+            graphed = GraphedCritic()
     t0 = time.time()
     for step in range(starting_step, options['max_steps'] + 1):
-        losses = train_step(P, options, G, D, opt_G, opt_D, loader, step, reducers)
+        losses = train_step(P, options, G, D, opt_G, opt_D, loader, step, reducers, graphed)
         if step % P.print_every == 0:
             vals = {k: float(v.detach()) for k, v in losses.items()}              # the only host sync of the loop
             log('[Steps %7d] [G %.3f] [D %.3f] [pen %.3f] [%.1f img/s]' %

@@ -28,7 +28,7 @@ import torch.distributed as dist
 
 from . import config, ops
 from .augment import get_augment
-from .engine import GradAllReducer, loss_D_fn_separate, r1_loss, set_grad
+from .engine import GradAllReducer, GraphedSG2DStep, loss_D_fn_separate, r1_loss, set_grad
 from .hostio import THROTTLE
 from .models.gan import get_architecture
 from .optim import FusedAdam
@@ -77,6 +77,9 @@ def parse_args(argv=None, contrad_script=False):
     parser.add_argument('--batch_size', default=None, type=int, help='override options.batch_size (global)')
     parser.add_argument('--logdir', default=None, type=str)
     parser.add_argument('--seed', default=0, type=int)
+    parser.add_argument('--graph', action='store_true',
+                        help='replay the D-step from a captured hipGraph (single process; the ContraD script, whose '
+                             'D-step draws its own fakes)')
     return parser.parse_args(argv)
 
 
@@ -140,7 +143,27 @@ def _opt_step(opt, reducer):
     opt.step(grad_scale=1.0 / world) if world > 1 else opt.step()
 
 
-def train_iteration(P, opt, G, D, g_ema, opt_G, opt_D, loader, step, reducers, contrad_script):
+class GraphedCritic(object):
+    """``--graph`` for train_stylegan2_contraD.py: its D-step (fresh fakes, two D calls, lazy R1) is exactly
+    engine.d_step_stylegan2_contrad, so it is replayed from engine.GraphedSG2DStep -- captured at the first D-step after
+    the optimizer holds state; the lazy-R1 steps run eagerly inside it.  Same random numbers as the eager iteration."""
+
+    def __init__(self):
+        self.step = None
+
+    def __call__(self, P, opt, G, D, opt_D, images, step):
+        if self.step is None:
+            if not len(opt_D.state):
+                return None
+            if P.mode != 'contrad':
+                raise NotImplementedError("--graph captures the ContraD D-step (--mode contrad), not '%s'" % P.mode)
+            self.step = GraphedSG2DStep(P, G, D, opt_D, opt, images, contrad_script=True, style_mix=P.style_mix,
+                                        warmup=0)
+        self.step.load_images(images)
+        return self.step(step)
+
+
+def train_iteration(P, opt, G, D, g_ema, opt_G, opt_D, loader, step, reducers, contrad_script, graphed=None):
     """One iteration of train_stylegan2.py:147-233 (contrad_script False) / train_stylegan2_contraD.py:182-246 (True).
     Returns the loss tensors (no host sync)."""
     THROTTLE.begin()
@@ -184,17 +207,23 @@ def train_iteration(P, opt, G, D, g_ema, opt_G, opt_D, loader, step, reducers, c
             return loss_D_fn_separate(P, D, opt, images, gen_images)
         return P.train_fn["D"](P, D, opt, images, gen_images)
 
-    if contrad_script:
-        gen_images = sample_generator(G, N, style_mix=P.style_mix, enable_grad=False)
-    d_loss, aux = d_loss_of(images, gen_images.detach())
-    loss = d_loss + aux['penalty']
-    if d_regularize:
-        r1 = r1_loss(D, images, P.augment_fn)
-        loss = loss + (0.5 * P.lbd_r1) * r1 * P.d_reg_every
-        out['D_r1'] = r1.detach()
-    opt_D.zero_grad()
-    loss.backward()
-    _opt_step(opt_D, red_D)
+    done = graphed(P, opt, G, D, opt_D, images, step) if graphed is not None else None
+    if done is not None:
+        d_loss, aux = done
+        if 'r1' in aux:
+            out['D_r1'] = aux['r1'].detach()
+    else:
+        if contrad_script:
+            gen_images = sample_generator(G, N, style_mix=P.style_mix, enable_grad=False)
+        d_loss, aux = d_loss_of(images, gen_images.detach())
+        loss = d_loss + aux['penalty']
+        if d_regularize:
+            r1 = r1_loss(D, images, P.augment_fn)
+            loss = loss + (0.5 * P.lbd_r1) * r1 * P.d_reg_every
+            out['D_r1'] = r1.detach()
+        opt_D.zero_grad()
+        loss.backward()
+        _opt_step(opt_D, red_D)
     for _ in range(opt['n_critic'] - 1):
         images, _labels = next(loader)
         gen_images = sample_generator(G, images.size(0), style_mix=P.style_mix, enable_grad=False)
@@ -204,8 +233,8 @@ def train_iteration(P, opt, G, D, g_ema, opt_G, opt_D, loader, step, reducers, c
         _opt_step(opt_D, red_D)
     G.eval(); D.eval()
     THROTTLE.end()
-    out.update({'D_loss': d_loss.detach(), 'D_penalty': aux['penalty'].detach(), 'D_real': aux['d_real'],
-                'D_gen': aux['d_gen'], 'lr_note': lr_note})
+    out.update({'D_loss': d_loss.detach(), 'D_penalty': aux['penalty'].detach(), 'D_real': aux['d_real'].detach(),
+                'D_gen': aux['d_gen'].detach(), 'lr_note': lr_note})
     return out
 
 
@@ -343,9 +372,17 @@ def main(argv=None, contrad_script=False):
     log(str(options))
     log(f"Use G moving average: {P.accum}")
 
+    graphed = None
+    if P.graph:
+        if world > 1 or not contrad_script:
+            log('--graph: single-process train_stylegan2_contraD.py only (train_stylegan2.py feeds the D-step the '
+                'G-step\'s fakes) -> eager')
+        else:
+            graphed = GraphedCritic()
     t0 = time.time()
     for step in range(starting_step, options['max_steps'] + 1):
-        losses = train_iteration(P, options, G, D, g_ema, opt_G, opt_D, loader, step, reducers, contrad_script)
+        losses = train_iteration(P, options, G, D, g_ema, opt_G, opt_D, loader, step, reducers, contrad_script,
+                                 graphed)
         if losses['lr_note']:
             log('LR Updated: [G %.5f] [D %.5f]' % losses['lr_note'])
         if step % P.print_every == 0:

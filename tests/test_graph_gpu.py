@@ -110,3 +110,52 @@ def test_stylegan2_graph_replay_equals_eager_steps(contrad_script, every):
     assert any(v[2] is not None for v in lg)
     for a, p in zip(want, D.parameters()):
         assert torch.equal(a, p.detach())
+
+
+def _state(logdir, names):
+    return {n: torch.load(os.path.join(logdir, n), map_location='cpu') for n in names}
+
+
+def _assert_same(a, b):
+    if isinstance(a, dict):
+        assert list(a) == list(b)
+        for k in a:
+            _assert_same(a[k], b[k])
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            _assert_same(x, y)
+    elif torch.is_tensor(a):
+        assert torch.equal(a, b)
+    else:
+        assert a == b
+
+
+def test_train_gan_with_graph_writes_the_eager_runs_checkpoints(tmp_path):
+    """train_gan.py --graph: D-steps replayed from the captured graph, G-steps (which move G's weights, BN statistics
+    and D's power-iteration vectors between them) eager -> bitwise the checkpoints of the eager loop."""
+    from contrad_amd.train_gan import main
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gin = os.path.join(root, 'configs', 'gan', 'cifar10', 'c10_b64.gin')
+    runs = []
+    for tag, extra in (('eager', []), ('graph', ['--graph'])):
+        logdir = str(tmp_path / tag)
+        main([gin, 'sndcgan', '--mode=contrad', '--aug=simclr', '--use_warmup', '--synthetic', '--max_steps', '6',
+              '--print_every', '3', '--evaluate_every', '6', '--seed', '5', '--logdir', logdir] + extra)
+        runs.append(_state(logdir, ('gen.pt', 'dis.pt', 'optim.pt')))
+    _assert_same(runs[0], runs[1])
+
+
+def test_train_stylegan2_contrad_with_graph_writes_the_eager_runs_checkpoints(tmp_path):
+    """train_stylegan2_contraD.py --graph with lazy R1 (every 2nd step eager inside the graphed critic)."""
+    from contrad_amd.train_stylegan2_contraD import main
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gin = os.path.join(root, 'configs', 'gan', 'stylegan2', 'c10_style64.gin')
+    runs = []
+    for tag, extra in (('eager', []), ('graph', ['--graph'])):
+        logdir = str(tmp_path / tag)
+        main([gin, 'stylegan2', '--mode=contrad', '--aug=simclr', '--lbd_r1', '0.1', '--d_reg_every', '2',
+              '--synthetic', '--batch_size', '8', '--halflife_k', '1', '--ema_start_k', '0', '--print_every', '3',
+              '--max_steps', '6', '--evaluate_every', '6', '--seed', '5', '--logdir', logdir] + extra)
+        runs.append(_state(logdir, ('gen.pt', 'dis.pt', 'gen_ema.pt', 'optim.pt')))
+    _assert_same(runs[0], runs[1])
