@@ -310,12 +310,46 @@ class _StaticAugment(object):
         i, self.k = self.k, self.k + 1
         if x.shape[0] != self.sizes[i]:
             raise RuntimeError('captured step: augmentation call %d saw %d images, planned %d' % (i, x.shape[0], self.sizes[i]))
+        if x.requires_grad and torch.is_grad_enabled():      # generator step: gradient flows through the augmentation
+            from .augment import _SimCLRFn
+            return _SimCLRFn.apply(x.contiguous().float(), self.blocks[i], -1, self.aug.r_c is not None,
+                                   (self.radius, self.taps[i]) if self.taps is not None else None,
+                                   self.aug.cutout_length if self.aug.p_cutout is not None else None)
         out = ops.simclr_augment(x.detach().contiguous().float(), self.blocks[i], -1, self.aug.r_c is not None)
         if self.taps is not None:
             out = ops.gaussian_blur_masked(out, self.blocks[i], self.taps[i], self.radius)
         if self.aug.p_cutout is not None:
             ops.cutout_masked_(out, self.blocks[i], self.aug.cutout_length)
         return out
+
+
+class _StaticSG2Inputs(object):
+    """Everything random the StyleGAN2 generator consumes in one forward, as static device tensors: latents, mixing
+    latents, mixing layers, per-layer noise.  ``refresh()`` draws them in the forward's own order (device draws for the
+    latents and the noise, CPU-generator draws for the mixing mask, generator.py:233-234,252-259,91-92)."""
+
+    def __init__(self, G, N, device, style_mix):
+        self.G, self.N, self.dev, self.style_mix = G, N, device, style_mix
+        self.z = torch.zeros(N, G.style_dim, device=device)
+        self.z_mix = torch.zeros(N, G.style_dim, device=device)
+        self.mix_layer = torch.zeros(N, device=device)
+        self.noise = [torch.zeros(N, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), device=device)
+                      for i in range(G.num_layers)]
+
+    def refresh(self):
+        from .hostio import upload
+        G, N = self.G, self.N
+        self.z.normal_()
+        if G.training and self.style_mix > 0:
+            self.z_mix.normal_()
+            nomix = torch.rand(N) >= self.style_mix
+            mix_layer = torch.randint(G.n_latent, (N,)).masked_fill(nomix, G.n_latent)
+            self.mix_layer.copy_(upload(mix_layer.float().view(-1, 1), self.dev).view(-1))
+        for t in self.noise:
+            t.normal_()
+
+    def forward(self):
+        return self.G(self.z, style_mix=self.style_mix, noise=self.noise, _mix=(self.z_mix, self.mix_layer))
 
 
 class GraphedSG2DStep(object):
@@ -346,10 +380,7 @@ class GraphedSG2DStep(object):
         self.saug = _StaticAugment(P.augment_fn, sizes, H, W, dev)
         self.Pg = argparse.Namespace(**vars(P))
         self.Pg.augment_fn = self.saug
-        self.z = torch.zeros(N, G.style_dim, device=dev)
-        self.z_mix = torch.zeros(N, G.style_dim, device=dev)
-        self.mix_layer = torch.zeros(N, device=dev)
-        self.noise = [torch.zeros(N, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), device=dev) for i in range(G.num_layers)]
+        self.gin = _StaticSG2Inputs(G, N, dev, style_mix)
         self.hyper = torch.ones(3, device=dev)
         torch.cuda.synchronize()
         G.invalidate_cache()              # as GraphedDStep: the packed tables are rebuilt inside the step
@@ -364,16 +395,8 @@ class GraphedSG2DStep(object):
 
     def _refresh(self):
         from .hostio import upload
-        G, N, dev = self.G, self.N, self.images.device
-        self.z.normal_()                                             # G.sample_latent (generator.py:233-234)
-        mixing = G.training and self.style_mix > 0
-        if mixing:                                                   # generator.py:252-259
-            self.z_mix.normal_()
-            nomix = torch.rand(N) >= self.style_mix
-            mix_layer = torch.randint(G.n_latent, (N,)).masked_fill(nomix, G.n_latent)
-            self.mix_layer.copy_(upload(mix_layer.float().view(-1, 1), dev).view(-1))
-        for t in self.noise:                                         # NoiseInjection, layer order (generator.py:91-92)
-            t.normal_()
+        dev = self.images.device
+        self.gin.refresh()
         self.saug.refresh()
         self.hyper.copy_(upload(torch.tensor([self.opt.hyper_values()], dtype=torch.float32), dev).view(3))
 
@@ -381,7 +404,7 @@ class GraphedSG2DStep(object):
         P, G, D = self.Pg, self.G, self.D
         self.saug.k = 0
         with torch.no_grad():
-            gen = G(self.z, style_mix=self.style_mix, noise=self.noise, _mix=(self.z_mix, self.mix_layer))
+            gen = self.gin.forward()
         if self.contrad_script:
             d_loss, aux = loss_D_fn_separate(P, D, self.options, self.images, gen)
         else:
@@ -405,3 +428,103 @@ class GraphedSG2DStep(object):
         self.graph.replay()
         THROTTLE.end()
         return self.d_loss, self.aux
+
+
+# ----------------------------------------------------------------------------------------------------------
+# the generator steps as captured hipGraphs (the other half of a training iteration)
+# ----------------------------------------------------------------------------------------------------------
+def _hyper_upload(opt, hyper):
+    from .hostio import upload
+    hyper.copy_(upload(torch.tensor([opt.hyper_values()], dtype=torch.float32), hyper.device).view(3))
+
+
+class GraphedGStep(object):
+    """The SNDCGAN generator step (train_gan.py:170-179: fakes WITH gradient -> ``loss_G_fn`` = D(augment(G(z))) ->
+    backward through D, the augmentation and G -> Adam on G) as one captured hipGraph.  The caller has set
+    ``set_grad(G, True); set_grad(D, False)`` and both networks to train mode, and ``opt_G`` holds state (one eager step
+    has run).  Per replay the host draws the latents and the augmentation block in the eager order."""
+
+    def __init__(self, P, G, D, opt_G, options, N, H, W):
+        import argparse
+        from . import ops
+        from .augment import SimCLRAugment
+        if not isinstance(P.augment_fn, SimCLRAugment) or dist_on():
+            raise NotImplementedError('GraphedGStep: single-process simclr-family pipeline')
+        if not len(opt_G.state):
+            raise RuntimeError('GraphedGStep: capture after the first eager generator step (Adam state)')
+        self.P, self.G, self.D, self.opt, self.options, self.N = P, G, D, opt_G, options, N
+        dev = next(G.parameters()).device
+        self.saug = _StaticAugment(P.augment_fn, [N], H, W, dev)
+        self.Pg = argparse.Namespace(**vars(P))
+        self.Pg.augment_fn = self.saug
+        self.z = torch.zeros(N, G.nz, device=dev)
+        self.hyper = torch.ones(3, device=dev)
+        torch.cuda.synchronize()
+        G.invalidate_cache()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.g_loss = self._body()
+        G.invalidate_cache()
+        torch.cuda.synchronize()
+
+    def _body(self):
+        self.saug.k = 0
+        gen = self.G(self.z)
+        g_loss = self.Pg.train_fn["G"](self.Pg, self.D, self.options, None, gen)
+        self.opt.zero_grad(set_to_none=True)
+        g_loss.backward()
+        self.opt.step_captured(self.hyper)
+        return g_loss.detach()
+
+    def __call__(self):
+        from .hostio import upload
+        THROTTLE.begin()
+        z = torch.empty(self.N, self.G.nz).uniform_(-1, 1)             # G.sample_latent's draw (sndcgan.py:50-52)
+        self.z.copy_(upload(z, self.z.device))
+        self.saug.refresh()
+        _hyper_upload(self.opt, self.hyper)
+        self.graph.replay()
+        THROTTLE.end()
+        return self.g_loss
+
+
+class GraphedSG2GStep(object):
+    """The StyleGAN2 generator step of train_stylegan2_contraD.py:138-146,207 (D with ``sg_linear=False`` and both
+    projections on the augmented fakes, non-saturating loss) as one captured hipGraph; same contract as GraphedGStep."""
+
+    def __init__(self, P, G, D, opt_G, options, N, H, W, style_mix=0.9):
+        if dist_on():
+            raise NotImplementedError('GraphedSG2GStep: single process')
+        if not len(opt_G.state):
+            raise RuntimeError('GraphedSG2GStep: capture after the first eager generator step (Adam state)')
+        self.P, self.G, self.D, self.opt, self.options, self.N = P, G, D, opt_G, options, N
+        dev = next(G.parameters()).device
+        self.saug = _StaticAugment(P.augment_fn, [N], H, W, dev)
+        self.gin = _StaticSG2Inputs(G, N, dev, style_mix)
+        self.hyper = torch.ones(3, device=dev)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.g_loss = self._body()
+        G.invalidate_cache()
+        torch.cuda.synchronize()
+
+    def _body(self):
+        from .training.gan.contrad import _GanGLoss
+        self.saug.k = 0
+        gen = self.gin.forward()
+        d_gen, _aux = self.D(self.saug(gen), sg_linear=False, projection=True, projection2=True)
+        g_loss = _GanGLoss.apply(d_gen, 'nonsat')
+        self.opt.zero_grad(set_to_none=True)
+        g_loss.backward()
+        self.opt.step_captured(self.hyper)
+        return g_loss.detach()
+
+    def __call__(self):
+        THROTTLE.begin()
+        self.gin.refresh()
+        self.saug.refresh()
+        _hyper_upload(self.opt, self.hyper)
+        self.graph.replay()
+        THROTTLE.end()
+        return self.g_loss

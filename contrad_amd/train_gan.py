@@ -20,7 +20,7 @@ import torch.distributed as dist
 
 from . import config
 from .augment import get_augment
-from .engine import GradAllReducer, GraphedDStep, OverlappedGradReducer, sample_generator, set_grad
+from .engine import GradAllReducer, GraphedDStep, GraphedGStep, OverlappedGradReducer, sample_generator, set_grad
 from .hostio import THROTTLE
 from .models.gan import get_architecture
 from .optim import FusedAdam
@@ -102,13 +102,24 @@ def _dataset_loader(name, batch, rank, world, workers):
 
 
 class GraphedCritic(object):
-    """``--graph``: the critic iteration of ``train_step`` replayed from ONE captured hipGraph (engine.GraphedDStep).
-    Captured lazily at the first critic iteration AFTER the optimizer holds state (i.e. from the second one on); every
+    """``--graph``: the critic iteration of ``train_step`` replayed from ONE captured hipGraph (engine.GraphedDStep) and
+    the generator step from a second one (engine.GraphedGStep).  Each is captured lazily at its first occurrence AFTER
+    its optimizer holds state (i.e. from the second iteration on); every
     replay consumes exactly the host random numbers the eager iteration would, so a run with ``--graph`` produces
     bitwise the checkpoints of a run without (tests/test_graph_gpu.py)."""
 
     def __init__(self):
         self.step = None
+        self.gstep = None
+
+    def generator(self, P, opt, G, D, opt_G, images):
+        """The generator step of the iteration from its own captured graph (engine.GraphedGStep); None while it has to
+        run eagerly (first iteration)."""
+        if self.gstep is None:
+            if not len(opt_G.state):
+                return None
+            self.gstep = GraphedGStep(P, G, D, opt_G, opt, images.size(0), images.size(2), images.size(3))
+        return self.gstep()
 
     def __call__(self, P, opt, G, D, opt_D, images):
         if self.step is None:
@@ -148,12 +159,14 @@ def train_step(P, opt, G, D, opt_G, opt_D, loader, step, reducers, graphed=None)
         world = comm.world() if comm is not None else (red_D() if red_D is not None else 1)
         opt_D.step(grad_scale=1.0 / world) if world > 1 else opt_D.step()
     set_grad(G, True); set_grad(D, False)
-    gen_images = sample_generator(G, images.size(0))
-    g_loss = P.train_fn["G"](P, D, opt, images, gen_images)
-    opt_G.zero_grad()
-    g_loss.backward()
-    world = red_G() if red_G is not None else 1
-    opt_G.step(grad_scale=1.0 / world) if world > 1 else opt_G.step()
+    g_loss = graphed.generator(P, opt, G, D, opt_G, images) if graphed is not None else None
+    if g_loss is None:
+        gen_images = sample_generator(G, images.size(0))
+        g_loss = P.train_fn["G"](P, D, opt, images, gen_images)
+        opt_G.zero_grad()
+        g_loss.backward()
+        world = red_G() if red_G is not None else 1
+        opt_G.step(grad_scale=1.0 / world) if world > 1 else opt_G.step()
     THROTTLE.end()
     # detached: a loss that keeps last iteration's autograd graph (and its AccumulateGrad nodes) alive would tie the next
     # D-step to the stream that graph ran on -- which breaks a hipGraph capture

@@ -28,7 +28,7 @@ import torch.distributed as dist
 
 from . import config, ops
 from .augment import get_augment
-from .engine import GradAllReducer, GraphedSG2DStep, loss_D_fn_separate, r1_loss, set_grad
+from .engine import GradAllReducer, GraphedSG2DStep, GraphedSG2GStep, loss_D_fn_separate, r1_loss, set_grad
 from .hostio import THROTTLE
 from .models.gan import get_architecture
 from .optim import FusedAdam
@@ -150,6 +150,16 @@ class GraphedCritic(object):
 
     def __init__(self):
         self.step = None
+        self.gstep = None
+
+    def generator(self, P, opt, G, D, opt_G, images):
+        """The generator step from its own captured graph (engine.GraphedSG2GStep); None while it runs eagerly."""
+        if self.gstep is None:
+            if not len(opt_G.state):
+                return None
+            self.gstep = GraphedSG2GStep(P, G, D, opt_G, opt, images.size(0), images.size(2), images.size(3),
+                                         style_mix=P.style_mix)
+        return self.gstep()
 
     def __call__(self, P, opt, G, D, opt_D, images, step):
         if self.step is None:
@@ -188,15 +198,17 @@ def train_iteration(P, opt, G, D, g_ema, opt_G, opt_D, loader, step, reducers, c
 
     # ---- generator step first ----
     set_grad(G, True); set_grad(D, False)
-    gen_images = sample_generator(G, N, style_mix=P.style_mix, enable_grad=True)
-    if contrad_script:      # G_D.forward(train_G=True): D(augment(G(z)), sg_linear=False, ...) -> d_gen
-        d_gen, _aux = D(P.augment_fn(gen_images), sg_linear=False, projection=True, projection2=True)
-        g_loss = loss_G_nonsat(d_gen)
-    else:
-        g_loss = P.train_fn["G"](P, D, opt, images, gen_images)
-    opt_G.zero_grad()
-    g_loss.backward()
-    _opt_step(opt_G, red_G)
+    g_loss = graphed.generator(P, opt, G, D, opt_G, images) if graphed is not None else None
+    if g_loss is None:
+        gen_images = sample_generator(G, N, style_mix=P.style_mix, enable_grad=True)
+        if contrad_script:      # G_D.forward(train_G=True): D(augment(G(z)), sg_linear=False, ...) -> d_gen
+            d_gen, _aux = D(P.augment_fn(gen_images), sg_linear=False, projection=True, projection2=True)
+            g_loss = loss_G_nonsat(d_gen)
+        else:
+            g_loss = P.train_fn["G"](P, D, opt, images, gen_images)
+        opt_G.zero_grad()
+        g_loss.backward()
+        _opt_step(opt_G, red_G)
     out['G_loss'] = g_loss.detach()
 
     # ---- discriminator step ----
