@@ -491,14 +491,22 @@ def main():
     if args.dev_local_batch:
         names = names[:1]
     results = {}
-    for name in names:
-        results[name] = run_config(name, args, world, rank, dev, multi)
+    for i, name in enumerate(names):
+        if i == 0:
+            results[name] = run_config(name, args, world, rank, dev, multi)
+            continue
+        try:                                     # a side workload must never take the headline line down
+            results[name] = run_config(name, args, world, rank, dev, multi)
+        except Exception as e:
+            results[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if multi:
         dist.barrier()
         dist.destroy_process_group()             # before the JSON line: nothing RCCL prints can follow or split it
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             for name in names:
+                if "error" in results[name]:
+                    continue
                 if name == 'c10_b512':
                     results[name]["cpu_baseline"] = cpu_baseline_c10()
                 elif name == 'sg2_32':
