@@ -67,6 +67,8 @@ class StepThrottle(object):
 
     def begin(self):
         self.depth += 1
+        if self.depth > 4:                  # no step nests this deep: an exception left the counter stuck -- start over
+            self.depth = 1
         if self.depth > 1:
             return
         while len(self.events) >= 2:
