@@ -821,9 +821,9 @@ bool vec_ok(const contrad_conv_desc* d, int mode) {
 void pick_tile(long long M, int Ncol, bool vec, bool lean, int mult, int* bm, int* bn) {
   if (!vec) { *bm = 64; *bn = 64; return; }
   // lean only: 4 x 1 waves, no MFMA columns wasted.  (A 256 x 32 tile -- two MFMA tiles per wave sharing one B fragment --
-  // was tried in round 2: 89.0 vs 88.3 TF/s.  These layers are not short of issue slots: every A element fetched feeds
-  // only 32 MACs, i.e. 16 FLOP per byte pulled through L2 -> ~10 TB/s of L2 -> L1 traffic at the MFMA peak; the cure is a
-  // spatial halo tile in LDS that serves all nine taps, a different kernel.)
+  // was tried in round 2: 89.0 vs 88.3 TF/s, because all per-row work doubles with it.  What holds these K = 288 layers
+  // back is the instruction overhead per block -- prologue, epilogue and loop control around only 144 MFMAs per wave --
+  // plus the loop's memory instructions: ablation table in DESIGN.md section 7, tools/dev/ablate32.sh.)
   if (lean && Ncol <= 32) { *bm = 128; *bn = 32; return; }
   static const int forced = []() { const char* e = getenv("CONTRAD_IGEMM_TILE"); return e ? atoi(e) : 0; }();  // dev: "128064"
   if (forced) { *bm = forced / 1000; *bn = forced % 1000; return; }
