@@ -53,6 +53,8 @@ struct IgemmArgs {
   int ptiles_per_split;  // WGRAD
   int ny;                // lean kernels: grid.y folded into the 1-D grid (DGRAD classes / WGRAD splits)
   int cgroup;            // lean DGRAD, stride 2: M-tiles per class group of the block order (0: class-interleaved)
+  int dsplits;           // lean DGRAD, stride 1: split-K count (grid.y = splits instead of parity classes), else 0 / 1
+  long long slab_elems;  // lean DGRAD split-K: floats per partial slab (N * H * W * ldx)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -920,6 +922,34 @@ __global__ void fwd_reduce_kernel(const float* __restrict__ ws, int splits, long
 // chip, partial slabs priced at 4 TB/s).  Split-K only pays for small-M, deep-K GEMMs: the merged head layer
 // (M = 3N rows, K = 8192) and the last conv layers at small per-rank batches.
 struct FwdPlan { int bm, bn, splits, tps; };
+
+// tile + split count for a lean GEMM of M x Ncol outputs over t_total K-tiles (shared by FWD and stride-1 DGRAD)
+void split_plan(long long M, int Ncol, int t_total, double flops, FwdPlan* p) {
+  static const int cand[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
+  static const double rate[4] = {135e12, 128e12, 128e12, 115e12};
+  static const int sp[8] = {1, 2, 3, 4, 6, 8, 12, 16};
+  double best = 1e30;
+  for (int i = (Ncol > 64 ? 0 : 2); i < 4; ++i)
+    for (int j = 0; j < 8; ++j) {
+      const int s_ = sp[j];
+      const int tps = cdiv(t_total, s_);
+      if (s_ > 1 && tps < 8) break;
+      const int splits = cdiv(t_total, tps);
+      const long long tm = cdivll(M, cand[i][0]), tn = cdivll(Ncol, cand[i][1]);
+      const double blocks = (double)(tm * tn) * splits;
+      const double waste = (double)(tm * cand[i][0]) * (double)(tn * cand[i][1]) / ((double)M * Ncol);
+      const double fill = blocks >= 768.0 ? 1.0 : blocks / 768.0;
+      double t = flops * waste / (rate[i] * fill);
+      if (splits > 1) t += (2.0 * splits + 1.0) * (double)M * Ncol * 4.0 / 4e12 + 4e-6;   // slabs + one more launch
+      if (t < best) { best = t; p->bm = cand[i][0]; p->bn = cand[i][1]; p->splits = splits; p->tps = tps; }
+    }
+}
+
+bool splitk_enabled() {
+  static const bool on = []() { const char* e = getenv("CONTRAD_IGEMM_SPLITK"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 FwdPlan fwd_plan(const contrad_conv_desc* d) {
   const long long M = (long long)d->N * d->Ho * d->Wo;
   const bool vec = vec_ok(d, MODE_FWD);
@@ -928,28 +958,52 @@ FwdPlan fwd_plan(const contrad_conv_desc* d) {
   pick_tile(M, d->K, vec, lean, 1, &p.bm, &p.bn);
   const int t_total = d->KH * d->KW * d->C / BK;
   p.tps = t_total;
-  static const bool splitk_on = []() { const char* e = getenv("CONTRAD_IGEMM_SPLITK"); return !(e && e[0] == '0'); }();
-  if (!lean || !splitk_on || p.bn == 32 || t_total < 32) return p;
-  static const int cand[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
-  static const double rate[4] = {135e12, 128e12, 128e12, 115e12};
-  static const int sp[8] = {1, 2, 3, 4, 6, 8, 12, 16};
-  const double flops = 2.0 * (double)M * d->K * d->C * d->KH * d->KW;
-  double best = 1e30;
-  for (int i = (d->K > 64 ? 0 : 2); i < 4; ++i)
-    for (int j = 0; j < 8; ++j) {
-      const int s_ = sp[j];
-      const int tps = cdiv(t_total, s_);
-      if (s_ > 1 && tps < 8) break;
-      const int splits = cdiv(t_total, tps);
-      const long long tm = cdivll(M, cand[i][0]), tn = cdivll(d->K, cand[i][1]);
-      const double blocks = (double)(tm * tn) * splits;
-      const double waste = (double)(tm * cand[i][0]) * (double)(tn * cand[i][1]) / ((double)M * d->K);
-      const double fill = blocks >= 768.0 ? 1.0 : blocks / 768.0;
-      double t = flops * waste / (rate[i] * fill);
-      if (splits > 1) t += (2.0 * splits + 1.0) * (double)M * d->K * 4.0 / 4e12 + 4e-6;   // slabs + one more launch
-      if (t < best) { best = t; p.bm = cand[i][0]; p.bn = cand[i][1]; p.splits = splits; p.tps = tps; }
-    }
+  if (!lean || !splitk_enabled() || p.bn == 32 || t_total < 32) return p;
+  split_plan(M, d->K, t_total, 2.0 * (double)M * d->K * d->C * d->KH * d->KW, &p);
   return p;
+}
+
+// DGRAD plan.  Stride 1 on the lean kernel may split K like FWD (small-M, deep-K layers: the 4x4 / 8x8 levels at small
+// per-rank batches ran 64x64 tiles at 2/3 of the 128x128 tile's matrix-pipe utilisation just to have enough blocks);
+// strided DGRAD keeps grid.y for its parity classes.  Without a workspace the plan never splits.
+FwdPlan dgrad_plan(const contrad_conv_desc* d, bool may_split) {
+  const int s = d->stride;
+  const long long Mc = (long long)d->N * cdiv(d->H, s) * cdiv(d->W, s);   // largest class
+  const bool vec = vec_ok(d, MODE_DGRAD);
+  const bool lean = vec && lean_ok(d, MODE_DGRAD, 0);
+  FwdPlan p{64, 64, 1, 0};
+  pick_tile(Mc, d->C, vec, lean, s * s, &p.bm, &p.bn);
+  const int t_total = d->KH * d->KW * d->K / BK;
+  p.tps = t_total;
+  if (!may_split || s != 1 || !lean || !splitk_enabled() || p.bn == 32 || t_total < 32 || (d->C & 3) || (d->ldx & 3))
+    return p;
+  split_plan(Mc, d->C, t_total, 2.0 * (double)Mc * d->K * d->C * d->KH * d->KW, &p);
+  return p;
+}
+
+// dx[m][c] = gain * act'(act_ref[m][c]) * sum_s ws[s][m][c]   (slabs in dx's own layout, fixed summation order)
+__global__ void dgrad_reduce_kernel(const float* __restrict__ ws, int splits, long long slab, long long rows, int C,
+                                    int ldx, const float* __restrict__ act_ref, float slope, float gain,
+                                    float* __restrict__ dx) {
+  const int c4n = C >> 2;
+  const long long total = rows * c4n;
+  const float g1 = gain, g0 = gain * slope;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const long long m = e / c4n;
+    const long long off = m * ldx + (e - m * c4n) * 4;
+    float4 v = ld4(ws + off);
+    for (int k = 1; k < splits; ++k) {
+      const float4 u = ld4(ws + (long long)k * slab + off);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    if (act_ref) {
+      const float4 a = ld4(act_ref + off);
+      v.x *= (a.x > 0.f) ? g1 : g0; v.y *= (a.y > 0.f) ? g1 : g0;
+      v.z *= (a.z > 0.f) ? g1 : g0; v.w *= (a.w > 0.f) ? g1 : g0;
+    }                                   // (no act_ref: raw sums, like the kernels' own epilogue)
+    *reinterpret_cast<float4*>(dx + off) = v;
+  }
 }
 
 }  // namespace
@@ -994,9 +1048,16 @@ extern "C" int contrad_conv2d_fwd(const contrad_conv_desc* d, const float* x, co
   return 0;
 }
 
-extern "C" int contrad_conv2d_dgrad(const contrad_conv_desc* d, const float* gy, const float* wp,
-                                    float* dx, const float* act_ref, float slope, float gain,
-                                    contrad_stream_t stream) {
+extern "C" long long contrad_conv2d_dgrad_workspace_bytes(const contrad_conv_desc* d) {
+  if (check_desc(d)) return -22;
+  const FwdPlan p = dgrad_plan(d, true);
+  if (p.splits <= 1) return 0;
+  return (long long)p.splits * d->N * d->H * d->W * d->ldx * (long long)sizeof(float);
+}
+
+extern "C" int contrad_conv2d_dgrad_ws(const contrad_conv_desc* d, const float* gy, const float* wp,
+                                       float* dx, const float* act_ref, float slope, float gain,
+                                       float* workspace, long long workspace_bytes, contrad_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   CONTRAD_ARG(gy && wp && dx);
@@ -1008,10 +1069,29 @@ extern "C" int contrad_conv2d_dgrad(const contrad_conv_desc* d, const float* gy,
   const int s = d->stride;
   const long long Mc = (long long)d->N * cdiv(d->H, s) * cdiv(d->W, s);  // largest class
   CONTRAD_ARG(Mc < (1ll << 31));
-  int bm, bn;
   const bool vec = vec_ok(d, MODE_DGRAD);
-  pick_tile(Mc, d->C, vec, vec && lean_ok(d, MODE_DGRAD, 0), s * s, &bm, &bn);
+  const FwdPlan pl = dgrad_plan(d, workspace != nullptr);
+  const int bm = pl.bm, bn = pl.bn;
   a.tiles_m = cdiv((int)Mc, bm); a.tiles_n = cdiv(d->C, bn);
+  if (pl.splits > 1) {
+    // stride-1 split-K: every split writes raw partial sums into its own slab (dx's layout), dgrad_reduce_kernel sums
+    // them in a fixed order and applies the fused act' epilogue
+    CONTRAD_ARG(workspace_bytes >= contrad_conv2d_dgrad_workspace_bytes(d));
+    a.dsplits = pl.splits;
+    a.ptiles_per_split = pl.tps;
+    a.slab_elems = (long long)d->N * d->H * d->W * d->ldx;
+    CONTRAD_ARG(a.slab_elems * 4 < (1ll << 40));
+    a.C = workspace; a.act_ref = nullptr;
+    rc = dispatch<MODE_DGRAD>(a, bm, bn, vec, dim3(a.tiles_m * a.tiles_n, pl.splits), (hipStream_t)stream);
+    if (rc) return rc;
+    const long long rows = (long long)d->N * d->H * d->W;
+    long long blocks = (rows * (d->C / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, workspace,
+                       pl.splits, a.slab_elems, rows, d->C, d->ldx, act_ref, slope, gain, dx);
+    CONTRAD_CHECK_LAUNCH();
+    return 0;
+  }
   // Block order of the strided lean DGRAD: the parity classes of a 3x3 stride-2 conv contract over 4, 2, 2 and 1 taps.
   // With the classes of one M-tile on consecutive block ids (tile_n, class, tile_m) the kernel took exactly as long as
   // its heaviest class alone (measured by launching single classes: 1.03 ms for class (0,0) vs 1.10 ms for all four;
@@ -1028,6 +1108,12 @@ extern "C" int contrad_conv2d_dgrad(const contrad_conv_desc* d, const float* gy,
   return dispatch<MODE_DGRAD>(a, bm, bn, vec, dim3(tm_pad * a.tiles_n, s * s), (hipStream_t)stream);
 }
 
+extern "C" int contrad_conv2d_dgrad(const contrad_conv_desc* d, const float* gy, const float* wp,
+                                    float* dx, const float* act_ref, float slope, float gain,
+                                    contrad_stream_t stream) {
+  return contrad_conv2d_dgrad_ws(d, gy, wp, dx, act_ref, slope, gain, nullptr, 0, stream);   // never splits K
+}
+
 extern "C" int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm, int* bn) {
   int rc = check_desc(d);
   if (rc) return rc;
@@ -1036,8 +1122,8 @@ extern "C" int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm
     const FwdPlan p = fwd_plan(d);
     *bm = p.bm; *bn = p.bn;
   } else if (mode == MODE_DGRAD) {
-    pick_tile((long long)d->N * cdiv(d->H, d->stride) * cdiv(d->W, d->stride), d->C, vec_ok(d, MODE_DGRAD),
-              vec_ok(d, MODE_DGRAD) && lean_ok(d, MODE_DGRAD, 0), d->stride * d->stride, bm, bn);
+    const FwdPlan p = dgrad_plan(d, true);
+    *bm = p.bm; *bn = p.bn;
   } else {
     int tm, tn, sp, pps;
     wgrad_plan(d, bm, bn, &tm, &tn, &sp, &pps);

@@ -150,8 +150,10 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     }
   } else if constexpr (MODE == MODE_DGRAD) {
     const int s = d.stride;
-    ph = by / s;
-    pw = by % s;
+    // stride 1 with split-K (p.dsplits > 1): grid.y counts K-splits, there is a single parity class
+    const int cls = (p.dsplits > 1) ? 0 : by;
+    ph = cls / s;
+    pw = cls % s;
     Hc = (d.H - ph + s - 1) / s;
     Wc = (d.W - pw + s - 1) / s;
     kh0 = (ph + d.pad) % s;
@@ -163,6 +165,15 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     M = d.N * Hc * Wc;
     Ncol = d.C;
     T = nth * ntw * d.K / BK;
+    if (p.dsplits > 1) {   // this block contracts K-tiles [t_begin, t_begin + T) into its slab (taps-inner order)
+      const int t_begin = by * p.ptiles_per_split, ntaps = nth * ntw;
+      T = min(p.ptiles_per_split, T - t_begin);
+      if (T < 0) T = 0;
+      u_c0 = (t_begin / ntaps) * BK;
+      u_tap = t_begin % ntaps;
+      u_a = u_tap / ntw;
+      u_b = u_tap - u_a * ntw;
+    }
     if (ntw == 0) ntw = 1;
     if (m0 >= M) return;  // uniform per block, before any barrier
     const int HcWc = Hc * Wc;
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
       rowoff[tid] = off;
     }
     __syncthreads();
-    const size_t img0 = (size_t)n_first * d.H * d.W * d.ldx;
+    const size_t img0 = (size_t)n_first * d.H * d.W * d.ldx + (p.dsplits > 1 ? (size_t)by * (size_t)p.slab_elems : 0);
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C + img0, 0, (int)COL_OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsR =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.act_ref ? p.act_ref + img0 : p.C + img0), 0,

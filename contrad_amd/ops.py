@@ -149,8 +149,10 @@ def conv2d_dgrad(gy, wp, x_shape, KH, KW, stride, pad, act_ref=None, slope=1.0, 
     d = make_desc(N, H, W, C, K, KH, KW, stride, pad, _ld(out), _ld(gy), wp.stride(0))
     if (d.Ho, d.Wo) != (gy.shape[1], gy.shape[2]):
         raise RuntimeError('contrad_hip: gy spatial size does not match the conv geometry')
-    _conv_call(1, d, 'contrad_conv2d_dgrad', ctypes.byref(d), _p(gy), _p(wp), _p(out), _p(act_ref),
-               float(slope), float(gain), _stream())
+    nbytes = lib().raw('contrad_conv2d_dgrad_workspace_bytes')(ctypes.byref(d))
+    ws = _workspace(nbytes, gy.device) if nbytes > 0 else None
+    _conv_call(1, d, 'contrad_conv2d_dgrad_ws', ctypes.byref(d), _p(gy), _p(wp), _p(out), _p(act_ref),
+               float(slope), float(gain), _p(ws), nbytes, _stream())
     return out
 
 

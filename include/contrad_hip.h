@@ -62,6 +62,13 @@ long long contrad_conv2d_fwd_workspace_bytes(const contrad_conv_desc* d);
  * Stride-2 is decomposed into s*s output-parity classes so only contributing taps are multiplied. */
 int contrad_conv2d_dgrad(const contrad_conv_desc* d, const float* gy, const float* wp, float* dx,
                          const float* act_ref, float slope, float gain, contrad_stream_t stream);
+/* Same, with a scratch buffer: small-M / deep-K stride-1 layers (the 4x4 and 8x8 levels at small per-rank batches) then
+ * split the contraction into deterministic partial slabs (dx's layout) that a second kernel sums in fixed order before
+ * the fused act' epilogue.  workspace may be NULL (never splits); size from contrad_conv2d_dgrad_workspace_bytes. */
+long long contrad_conv2d_dgrad_workspace_bytes(const contrad_conv_desc* d);
+int contrad_conv2d_dgrad_ws(const contrad_conv_desc* d, const float* gy, const float* wp, float* dx,
+                            const float* act_ref, float slope, float gain, float* workspace,
+                            long long workspace_bytes, contrad_stream_t stream);
 
 /* dwp[(kh,kw,c),k] = sum_{n,ho,wo} x[n,ho*s-p+kh,wo*s-p+kw,c] * gy[n,ho,wo,k]      (split over the
  * n*ho*wo axis into deterministic partial slabs in `workspace`, then reduced in fixed order).

@@ -76,5 +76,11 @@ def test_launch_plans_are_host_logic(built):
     d = _desc(192, 1, 8192, 1536, 1, 1, 0)
     nbytes = built.raw('contrad_conv2d_fwd_workspace_bytes')(ctypes.byref(d))
     assert nbytes > 0 and nbytes % (192 * 1536 * 4) == 0 and 2 <= nbytes // (192 * 1536 * 4) <= 16
+    # deep 3x3 layer at the 4x4 level, 3N = 192 images: split-K data gradient (slabs in dx's layout); never at 1536
+    d = _desc(192, 4, 512, 512, 3, 1, 1)
+    nbytes = built.raw('contrad_conv2d_dgrad_workspace_bytes')(ctypes.byref(d))
+    assert nbytes > 0 and nbytes % (192 * 16 * 512 * 4) == 0 and 2 <= nbytes // (192 * 16 * 512 * 4) <= 16
+    assert built.raw('contrad_conv2d_dgrad_workspace_bytes')(ctypes.byref(_desc(1536, 4, 512, 512, 3, 1, 1))) == 0
+    assert built.raw('contrad_conv2d_dgrad_workspace_bytes')(ctypes.byref(_desc(192, 8, 256, 512, 4, 2, 1))) == 0   # strided
     # contrastive column splits: ~256 blocks
     assert built.raw('contrad_contrast_workspace_bytes')(1024, 128) == 16 * 1024 * 128 * 4

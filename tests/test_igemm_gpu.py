@@ -202,3 +202,33 @@ def test_full_size_sndcgan_layer_linearity():
     # spot-check 4 images against PyTorch CPU
     ref = F.conv2d(x[:4].cpu().permute(0, 3, 1, 2), w.cpu(), padding=1).permute(0, 2, 3, 1)
     assert rel(y[:4].cpu(), ref) < TOL
+
+
+def test_dgrad_split_k_equals_the_unsplit_kernel_with_fused_epilogue_and_sliced_dx():
+    """Stride-1 DGRAD of a small-M / deep-K layer splits the contraction into partial slabs (contrad_conv2d_dgrad_ws);
+    the plain entry point never does.  Same sums up to fp32 reassociation, incl. the fused act' epilogue applied by the
+    reduce kernel and a dx that is a channel slice of a wider buffer (ldx > C)."""
+    import ctypes
+    from contrad_amd.ops import _p, _stream, lib, make_desc
+    N, H, W, C, K, k, s, p = 12, 4, 4, 512, 512, 3, 1, 1
+    g = torch.Generator().manual_seed(11)
+    dev = torch.device('cuda')
+    gy = torch.randn(N, H, W, K, generator=g).to(dev)
+    wp = ops.pack_weight(torch.randn(K, C, k, k, generator=g) * 0.05).to(dev)
+    act = torch.randn(N, H, W, C + 64, generator=g).to(dev)
+    for sliced in (False, True):
+        ldx = C + 64 if sliced else C
+        d = make_desc(N, H, W, C, K, k, k, s, p, ldx, K, wp.stride(0))
+        nbytes = lib().raw('contrad_conv2d_dgrad_workspace_bytes')(ctypes.byref(d))
+        assert nbytes > 0 and nbytes % (N * H * W * ldx * 4) == 0 and nbytes // (N * H * W * ldx * 4) >= 2
+        ref_buf = torch.zeros(N, H, W, ldx, device=dev)
+        a_ref = act if sliced else act[..., :C].contiguous()
+        lib().call('contrad_conv2d_dgrad', ctypes.byref(d), _p(gy), _p(wp), _p(ref_buf), _p(a_ref), 0.2, 1.5, _stream())
+        out_buf = torch.zeros(N, H, W, ldx, device=dev)
+        dx = ops.conv2d_dgrad(gy, wp, (N, H, W, C), k, k, s, p, act_ref=a_ref[..., :C], slope=0.2, gain=1.5,
+                              out=out_buf[..., :C])
+        assert rel(dx.cpu(), ref_buf[..., :C].cpu()) < 1e-5
+        assert not sliced or out_buf[..., C:].abs().max().item() == 0       # nothing written past the slice
+        again = ops.conv2d_dgrad(gy, wp, (N, H, W, C), k, k, s, p, act_ref=a_ref[..., :C], slope=0.2, gain=1.5,
+                                 out=torch.zeros(N, H, W, ldx, device=dev)[..., :C])
+        assert torch.equal(again, dx)                                        # fixed summation order
