@@ -13,7 +13,7 @@ for c in c10_b512 sg2_32 sg2_512; do
   grep -h '^{' $O/${c}_kt.log > $O/${c}_under_rocprof.json
   rm -f $O/${c}_kt_results.db
 done
-for c in c10_b512 sg2_512; do
+for c in ${PMC_CONFIGS-c10_b512 sg2_512}; do       # PMC_CONFIGS="" skips the counter passes
   case $c in c10_b512) S="--steps 3 --warmup 2";; sg2_512) S="--steps 2 --warmup 2";; esac
   P=$O/pmc_$c; mkdir -p $P
   B="python $R/bench.py --config $c $S --no-cpu-baseline --graph off"
@@ -25,5 +25,7 @@ for c in c10_b512 sg2_512; do
   rm -f $P/*.db
 done
 cd $R
+for c in c10_b512 sg2_32 sg2_512; do cp $O/${c}_kernel_trace.txt profiles/r02_${c}_n1_kernel_trace.txt; cp $O/${c}_under_rocprof.json profiles/r02_${c}_n1_under_rocprof.json; done
+tail -1 $O/bench_n1.json > profiles/r02_bench_n1.json
 mkdir -p $O/profiles; cp profiles/r02_* $O/profiles/ 2>/dev/null
 ls -la $O $O/profiles; head -c 1500 $O/bench_n1.json; echo; cat $O/pmc_c10_b512/summary.txt | head -30
