@@ -39,6 +39,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t lean_rsrc(const float* base, b
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, on ? (int)LEAN_RANGE : 0, 0x00020000);
 }
 
+// x = q * d + r with a wave-uniform divisor: power-of-two extents (every level of the image pyramids here except the
+// blur-padded 2^k + 1 ones) take a shift and a mask instead of the ~35-instruction runtime division -- the prologue is
+// a quarter of all instructions a block of a shallow-K layer (K = 9 * 32) executes, and each of them costs matrix-pipe time
+__device__ __forceinline__ int pow2_shift(int d) { return (d & (d - 1)) == 0 ? __builtin_ctz(d) : -1; }
+__device__ __forceinline__ void divmod_u(int x, int d, int sh, int& q, int& r) {
+  if (sh >= 0) { q = x >> sh; r = x & (d - 1); }
+  else { q = x / d; r = x - q * d; }
+}
+
 template <int MODE, int BM, int BN>
 __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(const IgemmArgs p) {
   static_assert(BK == 16, "the lean loop is written for a 16-deep K-tile");
@@ -126,15 +135,17 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     u_a = u_tap / d.KW;
     u_b = u_tap - u_a * d.KW;
     const int HoWo = d.Ho * d.Wo;
-    const int n_first = m0 / HoWo;
+    const int sh_w = pow2_shift(d.Wo), sh_h = pow2_shift(d.Ho);
+    const int n_first = (sh_w >= 0 && sh_h >= 0) ? (m0 >> (sh_w + sh_h)) : m0 / HoWo;
     baseA = p.A + ((long long)n_first * d.H * d.W - (d.pad * d.W + d.pad)) * d.ldx;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       const int m = m0 + qrow + 64 * i;
       const bool ok = m < M;
       const int mm = ok ? m : m0;
-      const int wo = mm % d.Wo, t = mm / d.Wo;
-      const int ho = t % d.Ho, n = t / d.Ho;
+      int wo, t, ho, n;
+      divmod_u(mm, d.Wo, sh_w, t, wo);
+      divmod_u(t, d.Ho, sh_h, n, ho);
       va[i] = (unsigned)(((((n - n_first) * d.H + ho * d.stride) * d.W + wo * d.stride) * d.ldx + kq * 4) * 4);
       // valid taps form a rectangle: a KW-bit column mask replicated into the valid kernel rows (KH + KW steps, not KH*KW)
       unsigned wmask = 0, valid = 0;
@@ -177,16 +188,18 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     if (ntw == 0) ntw = 1;
     if (m0 >= M) return;  // uniform per block, before any barrier
     const int HcWc = Hc * Wc;
-    const int n_first = m0 / HcWc;
+    const int sh_w = pow2_shift(Wc), sh_h = pow2_shift(Hc);
+    const int n_first = (sh_w >= 0 && sh_h >= 0) ? (m0 >> (sh_w + sh_h)) : m0 / HcWc;
     baseA = p.A + ((long long)n_first * d.Ho * d.Wo - ((nth - 1) * d.Wo + (ntw - 1))) * d.ldy;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       const int m = m0 + qrow + 64 * i;
       const bool ok = m < M;
       const int mm = ok ? m : m0;
-      const int wq = mm % Wc, t = mm / Wc;
-      const int n = t / Hc;
-      const int ah = t % Hc + bh, aw = wq + bw;   // ho = ah - th, wo = aw - tw
+      int wq, t, n, hq;
+      divmod_u(mm, Wc, sh_w, t, wq);
+      divmod_u(t, Hc, sh_h, n, hq);
+      const int ah = hq + bh, aw = wq + bw;   // ho = ah - th, wo = aw - tw
       va[i] = (unsigned)(((((n - n_first) * d.Ho + ah) * d.Wo + aw) * d.ldy + kq * 4) * 4);
       unsigned wmask = 0, valid = 0;
       for (int tw = 0; tw < ntw; ++tw) wmask |= ((unsigned)(aw - tw) < (unsigned)d.Wo ? 1u : 0u) << tw;
@@ -443,13 +456,15 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
   if constexpr (MODE == MODE_DGRAD) {
     // row -> byte offset of the dx pixel relative to the tile's first image (or out of range), staged in LDS
     unsigned* rowoff = reinterpret_cast<unsigned*>(smem);
-    const int n_first = m0 / (Hc * Wc);
+    const int sh_w = pow2_shift(Wc), sh_h = pow2_shift(Hc);
+    const int n_first = (sh_w >= 0 && sh_h >= 0) ? (m0 >> (sh_w + sh_h)) : m0 / (Hc * Wc);
     if (tid < BM) {
       const int m = m0 + tid;
       unsigned off = 2u * COL_OOB;
       if (m < M) {
-        const int wq = m % Wc, t2 = m / Wc;
-        const int hq = t2 % Hc, n = t2 / Hc;
+        int wq, t2, hq, n;
+        divmod_u(m, Wc, sh_w, t2, wq);
+        divmod_u(t2, Hc, sh_h, n, hq);
         off = (unsigned)((((n - n_first) * d.H + hq * d.stride + ph) * d.W + (wq * d.stride + pw)) * d.ldx) * 4u;
       }
       rowoff[tid] = off;
