@@ -14,7 +14,7 @@ from oracle import contrad_oracle as O
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
-FLIP_TOL = 3e-2
+FLIP_TOL = float(__import__('os').environ.get('CONTRAD_FLIP_TOL', '1e-2'))     # ReLU slope flips in G: observed < 7e-3; see tests/test_sndcgan_gpu.py
 DEV = 'cuda'
 
 

@@ -26,14 +26,18 @@ def grad_close(got, ref, tol):
     return l2 < tol, l2
 
 
-# Gradients vs the REFERENCE-generated goldens are compared at FLIP_TOL, not 1e-3: leaky_relu's derivative is
-# discontinuous at 0, and with ~2M activations per step a pre-activation of ~1e-8 (fp32 summation-order noise)
-# lands on the other side of 0 than in the reference's BLAS in roughly every other step, changing that unit's slope
-# 1 <-> 0.1 (tests/debug/debug_dstep.py pin-points the single flipped unit of this fixture).  That is a property of the
-# maths, not of a kernel: any two fp32 conv implementations disagree the same way.  The strict 1e-3 element-wise
-# check is test_full_step_on_the_same_linear_region below, where the oracle is evaluated with the activation
-# sign pattern of the run under test; forward quantities, gradient NORMS and the u/v/Adam state are 1e-3 here.
-FLIP_TOL = 3e-2
+# Element-wise gradients vs the REFERENCE-generated goldens: relative L2 per tensor below FLIP_TOL = 1e-3 (the
+# north_star tolerance; observed worst 3.5e-4 here, < 2e-4 for the StyleGAN2 fixtures).  What it has to absorb:
+# leaky_relu's derivative is discontinuous at 0, and with ~10^6 activations per step a pre-activation of ~1e-8 (fp32
+# summation-order noise) lands on the other side of 0 than in the reference's BLAS now and then, changing that unit's
+# slope 1 <-> 0.1 (tests/debug/debug_dstep.py pin-points the single flipped unit of this fixture; it shows up as the
+# 3.5e-4 of main.4.bias).  That is a property of the maths, not of a kernel: any two fp32 conv implementations
+# disagree the same way.  The ReLU networks (SNDCGAN's generator step, SNResNet18) flip between slope 1 and 0 and are
+# compared at 1e-2 in their files (observed 5-6e-3).  The strict element-wise check independent of flips is
+# test_full_step_on_the_same_linear_region below, where the oracle is evaluated with the activation sign pattern of
+# the run under test; forward quantities, gradient NORMS and the u/v/Adam state are 1e-3 everywhere.
+# (CONTRAD_FLIP_TOL overrides the value for margin probes.)
+FLIP_TOL = float(__import__('os').environ.get('CONTRAD_FLIP_TOL', '1e-3'))
 
 
 class _P(object):

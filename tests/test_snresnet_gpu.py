@@ -12,7 +12,7 @@ from oracle import contrad_oracle as O
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
-FLIP_TOL = 3e-2
+FLIP_TOL = float(__import__('os').environ.get('CONTRAD_FLIP_TOL', '1.5e-2'))     # ReLU slope flips (1 <-> 0): observed worst 7.2e-3; see tests/test_sndcgan_gpu.py
 DEV = 'cuda'
 
 

@@ -14,7 +14,7 @@ from oracle import stylegan2_oracle as S
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
-FLIP_TOL = 3e-2      # leaky-relu sign flips vs the raw reference goldens: see tests/test_sndcgan_gpu.py
+FLIP_TOL = float(__import__('os').environ.get('CONTRAD_FLIP_TOL', '1e-3'))      # leaky-relu sign flips vs the raw reference goldens: see tests/test_sndcgan_gpu.py
 DEV = 'cuda'
 
 
