@@ -99,28 +99,34 @@ __global__ __launch_bounds__(256) void colstats_partial_vec_kernel(const float* 
   }
 }
 
-// out[s][c] = sum_b partial[b][s][c]  (optionally accumulated onto out).  Block = 64 entries x 4 partial lanes:
-// the partial index is split over the 4 waves so no thread walks more than nblocks/4 strided loads.
+// out[s][c] = sum_b partial[b][s][c]  (optionally accumulated onto out).  Block = 16 entries x 16 partial lanes: with up
+// to 512 partial rows and only 2K <= 1024 entries the launch is pure latency -- 64 entries x 4 lanes walked 128 strided
+// loads per thread (14 us, six times per step); 16 lanes walk 32, four independent chains each.  Fixed summation order.
+constexpr int CSR_E = 16, CSR_P = 16;
 __global__ __launch_bounds__(256) void colstats_reduce_kernel(const float* __restrict__ partial, int nblocks,
                                                               int nstat, int K, float* __restrict__ out,
                                                               int accumulate) {
-  __shared__ float red[4][64];
-  const int ex = threadIdx.x & 63, py = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + ex;
+  __shared__ float red[CSR_P][CSR_E + 1];
+  const int ex = threadIdx.x % CSR_E, py = threadIdx.x / CSR_E;
+  const int e = blockIdx.x * CSR_E + ex;
   const int E = nstat * K;
-  float s0 = 0.f, s1 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (e < E) {
     int b = py;
-    for (; b + 4 < nblocks; b += 8) {
+    for (; b + 3 * CSR_P < nblocks; b += 4 * CSR_P) {
       s0 += partial[(size_t)b * E + e];
-      s1 += partial[(size_t)(b + 4) * E + e];
+      s1 += partial[(size_t)(b + CSR_P) * E + e];
+      s2 += partial[(size_t)(b + 2 * CSR_P) * E + e];
+      s3 += partial[(size_t)(b + 3 * CSR_P) * E + e];
     }
-    if (b < nblocks) s0 += partial[(size_t)b * E + e];
+    for (; b < nblocks; b += CSR_P) s0 += partial[(size_t)b * E + e];
   }
-  red[py][ex] = s0 + s1;
+  red[py][ex] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (py == 0 && e < E) {
-    const float s = (red[0][ex] + red[1][ex]) + (red[2][ex] + red[3][ex]);
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < CSR_P; ++r) s += red[r][ex];
     out[e] = accumulate ? out[e] + s : s;
   }
 }
@@ -374,7 +380,7 @@ extern "C" int contrad_colstats(const float* x, long long M, int K, int ld, int 
   }
   CONTRAD_CHECK_LAUNCH();
   const int nstat = with_sq ? 2 : 1;
-  hipLaunchKernelGGL(colstats_reduce_kernel, dim3(cdiv(nstat * K, 64)), dim3(256), 0, s, workspace, nb, nstat, K,
+  hipLaunchKernelGGL(colstats_reduce_kernel, dim3(cdiv(nstat * K, CSR_E)), dim3(256), 0, s, workspace, nb, nstat, K,
                      out, accumulate);
   CONTRAD_CHECK_LAUNCH();
   return 0;
@@ -406,7 +412,7 @@ extern "C" int contrad_bn_relu_bwd_stats(const float* dy, const float* x, long l
   hipLaunchKernelGGL(bn_relu_bwd_stats_kernel, grid, dim3(256), 0, s, dy, x, M, K, ld, stats, count, gamma, beta,
                      eps, rpb, workspace);
   CONTRAD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colstats_reduce_kernel, dim3(cdiv(2 * K, 64)), dim3(256), 0, s, workspace, nb, 2, K, out2k, 0);
+  hipLaunchKernelGGL(colstats_reduce_kernel, dim3(cdiv(2 * K, CSR_E)), dim3(256), 0, s, workspace, nb, 2, K, out2k, 0);
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }
