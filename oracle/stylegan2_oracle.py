@@ -97,9 +97,10 @@ def d_param_shapes(size, small32, channel_multiplier=2, d_hidden=512, d_project=
     return s
 
 
-def det_fill_d(shapes, seed=2024):
-    """Deterministic fill: weights N(0,1) (EqualConv init), head weights N(0, 0.02), biases N(0, 0.1), blur kernels
-    exact."""
+def det_fill_d(shapes, seed=2024, head_std=0.02):
+    """Deterministic fill: weights N(0,1) (EqualConv init), head weights N(0, head_std), biases N(0, 0.1), blur kernels
+    exact.  (The R1-gradient fixtures use a larger ``head_std`` so that the penalty is O(0.1 ... 1) instead of 1e-3 ...
+    1e-5: d D / d x scales with the product of the two ``linear`` head layers.)"""
     sd = {}
     for i, (name, shape) in enumerate(shapes.items()):
         g = torch.Generator().manual_seed(seed + i)
@@ -110,7 +111,7 @@ def det_fill_d(shapes, seed=2024):
         if name.endswith('bias'):
             t = t * 0.1
         elif name.startswith(('linear', 'projection')):
-            t = t * 0.02
+            t = t * head_std
         sd[name] = t
     return sd
 

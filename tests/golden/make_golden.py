@@ -645,6 +645,88 @@ def gen_stylegan2_512():
 
 
 # ------------------------------------------------------------------------------------------------
+def _r1_fixture(D, S, size, small32, cm, wseed, head_std, aug_r1, N):
+    """The R1 penalty's gradient ALONE (train_stylegan2.py:106-113 / train_stylegan2_contraD.py:129-136 ->
+    autograd.grad(r1, parameters)): in the full-step fixtures it is 0.5-1.4 % of the weight gradients and ~1e-6 of
+    the bias gradients, so a 1e-3 check of the SUM cannot see an error in the double backward.  Here it is the whole
+    signal, with the ``linear`` head scaled (``head_std``) so that r1 is O(0.1 ... 1).  (Inside one linear region of
+    the leaky-relu network d D / d x does not depend on any bias; the bias gradients of r1 flow exclusively through the
+    minibatch-stddev channel's sqrt(var + eps) -- its double backward is what they pin.)"""
+    shapes = S.d_param_shapes(size, small32, cm)
+    sd = S.det_fill_d(shapes, seed=wseed, head_std=head_std)
+    D.load_state_dict({k: v.clone() for k, v in sd.items()})
+    D.train()
+    params = dict(D.named_parameters())
+    xa = aug_r1.detach().clone().requires_grad_()
+    d_real = D(xa)
+    grad_real, = torch.autograd.grad(outputs=d_real.sum(), inputs=xa, create_graph=True, retain_graph=True)
+    r1 = grad_real.pow(2).reshape(N, -1).sum(1).mean()
+    gs = torch.autograd.grad(r1, list(params.values()), allow_unused=True)
+    ref = {k: g for k, g in zip(params, gs)}
+
+    osd = {k: v.clone() for k, v in sd.items()}
+    for k in osd:
+        if not k.endswith('kernel'):
+            osd[k].requires_grad_()
+    or1 = S.r1_penalty(lambda t: S.d_forward(osd, t, size)[0], aug_r1)
+    names = [k for k in osd if not k.endswith('kernel')]
+    ogs = torch.autograd.grad(or1, [osd[k] for k in names], allow_unused=True)
+    check(or1, r1, 1e-5, 'r1 (%d)' % size)
+    unused = []
+    worst = 0.0
+    for k, og in zip(names, ogs):
+        if ref[k] is None or og is None:
+            # (unused by r1 on one side, an exactly-zero gradient on the other: same thing)
+            assert (og is None or og.abs().max().item() == 0) and (ref[k] is None or ref[k].abs().max().item() == 0), k
+            ref[k] = None
+            unused.append(k)
+            continue
+        e = ((og - ref[k]).norm() / ref[k].norm().clamp_min(1e-30)).item()
+        worst = max(worst, e)
+        assert e < 2e-5, ('r1 grad ' + k, e)
+    print('  r1-only gradient (%d^2, N=%d): r1 = %.4f, |grad_real| = %.4f, oracle vs reference worst rel-L2 %.2e, '
+          'no gradient: %s' % (size, N, r1.item(), grad_real.norm().item(), worst, unused))
+    out = {'N': N, 'wseed': wseed, 'head_std': head_std, 'r1': r1, 'd_r1_logits': d_real.detach(),
+           'grad_real_norm': grad_real.detach().norm(),
+           'grad_real_head': grad_real.detach().reshape(N, -1)[:, :256],
+           'grad_real_rowsum': grad_real.detach().double().sum(3)[:, :, ::max(1, size // 32)]}
+    for k, g in ref.items():
+        if g is None or g.abs().max().item() == 0:       # e.g. linear.l1.bias: d D / d x does not depend on it
+            out['r1none/' + k] = 1
+            continue
+        out['r1gradnorm/' + k] = g.norm()
+        if g.numel() <= 4096:
+            out['r1grad/' + k] = g
+        else:
+            out['r1gradhead/' + k] = g.reshape(-1)[:512]
+            # a strided sample as well: the first 512 entries of an OIHW weight all belong to output channel 0
+            out['r1gradstride/' + k] = g.reshape(-1)[::max(1, g.numel() // 512)][:512]
+    return out
+
+
+def gen_stylegan2_r1():
+    from oracle import stylegan2_oracle as S
+    from models.gan.stylegan2.discriminator import ResidualDiscriminatorP
+    # ---- 32^2 (BASELINE config 4: R1 every step) ----
+    D = ResidualDiscriminatorP(size=32, small32=True, mlp_linear=True, d_hidden=512)
+    N = 4
+    aug_r1 = torch.rand(N, 3, 32, 32, generator=torch.Generator().manual_seed(171))
+    out = _r1_fixture(D, S, 32, True, 2, 2025, 0.1, aug_r1, N)
+    out['aug_r1'] = aug_r1
+    save('stylegan2_r1', **out)
+    # ---- 512^2 (BASELINE config 5: lazy R1), inputs regenerated from the seed on both sides ----
+    from models.gan import get_architecture
+    torch.manual_seed(0)
+    _G, D = get_architecture('stylegan2_512', (512, 512, 3))
+    N = 2
+    aug_r1 = seeded_images(N, 512, 9004)
+    out = _r1_fixture(D, S, 512, False, 1.0, 513, 0.3, aug_r1, N)
+    out['seed_r1'] = 9004
+    out['sum_r1'] = aug_r1.double().sum()
+    save('stylegan2_512_r1', **out)
+
+
+# ------------------------------------------------------------------------------------------------
 def gen_stylegan2_gstep():
     """StyleGAN2 generator step (train_stylegan2.py:184-194; train_stylegan2_contraD.py:138-146 computes the same
     d_gen): G(z, style_mix) with grad, explicit noise -> loss_G_fn = softplus(-D(augment(G(z)))).mean() -> all G
@@ -829,7 +911,7 @@ def gen_snresnet():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['losses', 'augment', 'sndcgan', 'sndcgan_gstep', 'adam', 'stylegan2', 'stylegan2_g', 'stylegan2_512', 'stylegan2_gstep', 'checkpoint_manifest', 'snresnet']
+    which = sys.argv[1:] or ['losses', 'augment', 'sndcgan', 'sndcgan_gstep', 'adam', 'stylegan2', 'stylegan2_g', 'stylegan2_512', 'stylegan2_r1', 'stylegan2_gstep', 'checkpoint_manifest', 'snresnet']
     for w in which:
         globals()['gen_' + w]()
     print('golden vectors OK')

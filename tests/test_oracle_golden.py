@@ -168,3 +168,30 @@ def test_stylegan2_oracle_against_golden(golden):
     for k in g.files:
         if k.startswith('gradnorm/'):
             assert close(sd[k[len('gradnorm/'):]].grad.norm(), g[k], 2e-5), k
+
+
+def test_stylegan2_oracle_r1_gradient_alone(golden):
+    """The oracle's double backward alone (no first-order loss next to it) against autograd.grad(r1, parameters) of the
+    imported reference, 32^2 (tests/golden/make_golden.py::gen_stylegan2_r1; the 512^2 fixture is checked against the
+    oracle by the generator itself and against the HIP path on the GPU)."""
+    from oracle import stylegan2_oracle as S
+    g = golden('stylegan2_r1')
+    sd = S.det_fill_d(S.d_param_shapes(32, True), seed=int(g['wseed']), head_std=float(g['head_std']))
+    names = [k for k in sd if not k.endswith('kernel')]
+    for k in names:
+        sd[k].requires_grad_()
+    r1 = S.r1_penalty(lambda t: S.d_forward(sd, t, 32)[0], T(g['aug_r1']))
+    grads = dict(zip(names, torch.autograd.grad(r1, [sd[k] for k in names], allow_unused=True)))
+    assert close(r1, g['r1'], 1e-5) and float(g['r1']) > 0.1        # O(1): the signal is the second-order term itself
+    seen = 0
+    for k in g.files:
+        kind, _, name = k.partition('/')
+        if kind == 'r1none':
+            assert grads[name] is None or grads[name].abs().max().item() == 0
+        elif kind == 'r1grad':
+            ref = T(g[k]).double()
+            assert ((grads[name].double() - ref).norm() / ref.norm()).item() < 2e-5, name
+            seen += 1
+        elif kind == 'r1gradnorm':
+            assert abs(grads[name].norm().item() - float(g[k])) < 2e-5 * float(g[k]), name
+    assert seen >= 9        # every conv bias (they see r1 only through the minibatch-stddev channel) among them

@@ -1,0 +1,135 @@
+"""The R1 penalty's SECOND-ORDER gradient in isolation (row R1: train_stylegan2.py:106-113,
+train_stylegan2_contraD.py:129-136, op/upfirdn2d.py:62-85): ``r1.backward()`` only, against
+``autograd.grad(r1, parameters)`` of the imported reference (tests/golden/make_golden.py::gen_stylegan2_r1) at 32^2
+(N = 4) and 512^2 (N = 2), each tensor compared at 1e-3 of ITS OWN norm -- in the full-step fixtures this gradient is
+0.5-1.4 % of the weight gradients and ~1e-6 of the bias gradients, where a 1e-3 check of the sum cannot see it.
+Plus the strict element-wise variant: the oracle evaluated on the linear regions the HIP forward actually used.
+The fixtures scale the ``linear`` head so that r1 is O(1) (3.4 / 0.97)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from contrad_amd.models.gan import get_architecture
+from contrad_amd.models.gan.stylegan2.discriminator import ResidualDiscriminatorP
+from oracle import stylegan2_oracle as S
+from sg2_inputs import seeded_images
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+DEV = 'cuda'
+VERBOSE = bool(os.environ.get('CONTRAD_TEST_VERBOSE'))
+
+
+def l2(a, b):
+    a, b = torch.as_tensor(a).double().cpu().reshape(-1), torch.as_tensor(b).double().cpu().reshape(-1)
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def _case(golden, size):
+    if size == 32:
+        g = golden('stylegan2_r1')
+        D = ResidualDiscriminatorP(32, small32=True, mlp_linear=True, d_hidden=512)
+        shapes = S.d_param_shapes(32, True)
+        aug_r1 = torch.from_numpy(g['aug_r1'])
+    else:
+        g = golden('stylegan2_512_r1')
+        _G, D = get_architecture('stylegan2_512', (512, 512, 3))
+        shapes = S.d_param_shapes(512, False, 1.0)
+        aug_r1 = seeded_images(int(g['N']), 512, int(g['seed_r1']))
+        assert abs(aug_r1.double().sum().item() - float(g['sum_r1'])) < 1e-6 * float(g['sum_r1'])
+    sd = S.det_fill_d(shapes, seed=int(g['wseed']), head_std=float(g['head_std']))
+    D.load_state_dict(sd)
+    return g, D.to(DEV).train(), sd, aug_r1
+
+
+def _hip_r1(D, aug_r1):
+    """r1_loss (engine.r1_loss with the augmentation output injected) and ONLY its backward."""
+    from contrad_amd.engine import r1_loss
+    D.zero_grad()
+    aug = aug_r1.to(DEV)
+    r1 = r1_loss(D, aug, lambda t: aug)
+    r1.backward()
+    return r1
+
+
+@pytest.mark.parametrize('size', [32, 512])
+def test_r1_gradient_alone_against_reference(golden, size):
+    g, D, _sd, aug_r1 = _case(golden, size)
+    N = int(g['N'])
+    # first-order quantities of the R1 branch
+    xa = aug_r1.to(DEV).requires_grad_()
+    d_real = D(xa)
+    grad_real, = torch.autograd.grad(d_real.sum(), xa)
+    assert rel(d_real, g['d_r1_logits']) < TOL
+    assert abs(grad_real.norm().item() - float(g['grad_real_norm'])) < TOL * float(g['grad_real_norm'])
+    assert rel(grad_real.reshape(N, -1)[:, :256], g['grad_real_head']) < 5 * TOL     # single entries: vs the tensor's max
+    assert rel(grad_real.double().sum(3)[:, :, ::max(1, size // 32)], g['grad_real_rowsum']) < TOL
+
+    r1 = _hip_r1(D, aug_r1)
+    assert abs(r1.item() - float(g['r1'])) < TOL * float(g['r1'])
+    grads = {k: p.grad for k, p in D.named_parameters()}
+    report = []
+    for k in g.files:
+        kind, _, name = k.partition('/')
+        if kind == 'r1none':
+            assert grads[name] is None or grads[name].abs().max().item() == 0, name
+        elif kind == 'r1gradnorm':
+            ref = float(g[k])
+            e = abs(grads[name].norm().item() - ref) / ref
+            report.append(('norm', name, e))
+            assert e < TOL, (name, e)
+        elif kind == 'r1grad':                                   # whole tensor (every bias, the small weights)
+            e = l2(grads[name], g[k])
+            report.append(('l2', name, e))
+            assert e < TOL, (name, e)
+        elif kind in ('r1gradhead', 'r1gradstride'):
+            ref = torch.from_numpy(g[k])
+            flat = grads[name].reshape(-1)
+            got = (flat[:512] if kind == 'r1gradhead' else flat[::max(1, flat.numel() // 512)][:512]).cpu()
+            e = l2(got, ref)
+            report.append((kind[6:], name, e))
+            assert e < TOL, (name, kind, e)
+    if VERBOSE:
+        for r in sorted(report, key=lambda t: -t[2])[:12]:
+            print('r1-only %d: %-6s %-28s %.2e' % ((size,) + r))
+
+
+@pytest.mark.parametrize('size', [32, 512])
+def test_r1_gradient_alone_on_the_same_linear_region(golden, size):
+    """Element-wise: every parameter's R1 gradient vs the oracle evaluated with the leaky-relu sign patterns recorded
+    from the HIP forward of the R1 batch (max-abs error relative to the tensor's max, 1e-3)."""
+    g, D, sd, aug_r1 = _case(golden, size)
+    D._record_activations = True
+    r1 = _hip_r1(D, aug_r1)
+    rec, hl, hpq = D._recorded[0]
+    masks = [(t > 0).permute(0, 3, 1, 2).cpu() for t in rec]
+    hl, hpq = hl.reshape(hl.shape[0], -1).cpu(), hpq.reshape(hpq.shape[0], -1).cpu()
+    head_masks = (hl > 0, hpq[:, :512] > 0, hpq[:, 512:] > 0)
+    osd = {k: v.clone() for k, v in sd.items()}
+    for k in osd:
+        if not k.endswith('kernel'):
+            osd[k].requires_grad_()
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    or1 = S.r1_penalty(lambda t: S.d_forward(osd, t, size, masks=masks, head_masks=head_masks)[0], aug_r1)
+    names = [k for k in osd if not k.endswith('kernel')]
+    ogs = torch.autograd.grad(or1, [osd[k] for k in names], allow_unused=True)
+    assert abs(r1.item() - or1.item()) < TOL * or1.item()
+    grads = {k: p.grad for k, p in D.named_parameters()}
+    worst = []
+    for k, og in zip(names, ogs):
+        if og is None or og.abs().max().item() == 0:
+            assert grads[k] is None or grads[k].abs().max().item() == 0, k
+            continue
+        e = rel(grads[k], og)
+        worst.append((e, k))
+        assert e < TOL, (k, e)
+    if VERBOSE:
+        for e, k in sorted(worst)[-8:]:
+            print('r1-only same-region %d: %-28s %.2e' % (size, k, e))

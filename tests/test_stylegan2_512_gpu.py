@@ -20,6 +20,8 @@ from sg2_inputs import seeded_images
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
+FLIP_TOL = float(__import__('os').environ.get('CONTRAD_FLIP_TOL', '1e-3'))      # see tests/test_sndcgan_gpu.py
+VERBOSE = bool(__import__('os').environ.get('CONTRAD_TEST_VERBOSE'))
 DEV = 'cuda'
 
 
@@ -37,19 +39,23 @@ class _P(object):
     temp, lbd_a, distributed = 0.1, 1.0, False
 
 
-def test_discriminator_512_contrad_step_against_reference(golden):
+def _config5_step(golden, record=False):
+    """train_stylegan2_contraD.py's D-step (separate N / 2N calls, lazy-R1 step) with the augmentation outputs of the
+    fixture injected."""
     g = golden('stylegan2_512_d')
     N = int(g['N'])
     G, D = get_architecture('stylegan2_512', (512, 512, 3))
     shapes = S.d_param_shapes(512, False, 1.0)
     assert {k: tuple(v.shape) for k, v in D.state_dict().items()} == shapes and list(D.state_dict()) == list(shapes)
-    D.load_state_dict(S.det_fill_d(shapes, seed=int(g['wseed'])))
+    sd = S.det_fill_d(shapes, seed=int(g['wseed']))
+    D.load_state_dict(sd)
     D = D.to(DEV).train()
     aug_f = seeded_images(N, 512, int(g['seed_f']))
     aug_r = seeded_images(2 * N, 512, int(g['seed_r']))
     aug_r1 = seeded_images(N, 512, int(g['seed_r1']))
     for t, key in ((aug_f, 'sum_f'), (aug_r, 'sum_r'), (aug_r1, 'sum_r1')):      # same inputs as the generator run
         assert abs(t.double().sum().item() - float(g[key])) < 1e-6 * float(g[key])
+    cpu_inputs = (aug_f, aug_r, aug_r1)
     aug_f, aug_r, aug_r1 = aug_f.to(DEV), aug_r.to(DEV), aug_r1.to(DEV)
 
     # forward values of the two separate calls
@@ -71,6 +77,8 @@ def test_discriminator_512_contrad_step_against_reference(golden):
         return aug_f if len([c for c in calls if c == N]) == 1 else aug_r1
     P.augment_fn = augment_fn
     P.lbd_r1, P.d_reg_every = 0.5, 16
+    if record:
+        D._record_activations = True
     x = torch.rand(N, 3, 512, 512, device=DEV)
     d_loss, aux = loss_D_fn_separate(P, D, {'loss': 'nonsat'}, x, torch.rand(N, 3, 512, 512, device=DEV))
     r1 = r1_loss(D, x, P.augment_fn)
@@ -78,25 +86,87 @@ def test_discriminator_512_contrad_step_against_reference(golden):
     loss = d_loss + aux['penalty'] + (0.5 * P.lbd_r1) * r1 * P.d_reg_every
     D.zero_grad()
     loss.backward()
+    return g, N, D, sd, cpu_inputs, d_loss, aux, r1
+
+
+def test_discriminator_512_contrad_step_against_reference(golden):
+    """Config 5 against the RAW reference golden at the north_star tolerance: losses, r1 and every gradient norm at
+    1e-3; the stored gradient entries (first 256 of each tensor) at 1e-3 relative L2 (leaky-relu slope flips of single
+    units vs the reference's BLAS are the one thing the raw comparison cannot exclude -- the element-wise check without
+    them is test_discriminator_512_step_on_the_same_linear_region below)."""
+    g, N, D, _sd, _inp, d_loss, aux, r1 = _config5_step(golden)
     want = float(g['simclr']) + float(g['sup'])
     assert abs(d_loss.item() - want) < TOL * abs(want)
     assert abs(aux['penalty'].item() - float(g['gan'])) < TOL * float(g['gan'])
-    assert abs(r1.item() - float(g['r1'])) < 5e-3 * float(g['r1'])
+    assert abs(r1.item() - float(g['r1'])) < TOL * float(g['r1'])
     grads = {k: p.grad for k, p in D.named_parameters()}
-    worst = 0.0
+    report = []
     for k in g.files:
         if k.startswith('gradnorm/'):
             name = k[len('gradnorm/'):]
             ref = float(g[k])
             e = abs(grads[name].norm().item() - ref) / max(ref, 1e-30)
-            worst = max(worst, e)
-            assert e < 5e-3, (name, e)
+            report.append((e, 'norm', name))
+            assert e < TOL, (name, e)
         elif k.startswith('gradhead/'):
             name = k[len('gradhead/'):]
             ref = torch.from_numpy(g[k])
             got = grads[name].reshape(-1)[:ref.numel()].cpu()
-            scale = float(g['gradnorm/' + name]) / np.sqrt(grads[name].numel())      # rms of the full gradient
-            assert (got - ref).abs().max().item() < 3e-2 * max(ref.abs().max().item(), scale), name
+            e = l2(got, ref)
+            report.append((e, 'head', name))
+            assert e < FLIP_TOL, (name, e)
+    if VERBOSE:
+        for r in sorted(report)[-10:]:
+            print('config5 raw golden: %.2e %s %s' % r)
+
+
+def test_discriminator_512_step_on_the_same_linear_region(golden):
+    """Config 5, strict element-wise check of EVERY gradient entry (first and second order): the oracle evaluated on
+    the leaky-relu linear regions recorded from the HIP forwards (the merged N + 2N pass and the R1 batch); max-abs
+    error relative to the tensor's max, 1e-3.  (N = 2 at 512^2: ~1 min of oracle time on the host cores.)"""
+    import os
+    import torch.nn.functional as F
+    from oracle import contrad_oracle as O
+    g, N, D, sd, (aug_f, aug_r, aug_r1), d_loss, aux, r1 = _config5_step(golden, record=True)
+    (rec_a, hl_a, hpq_a), (rec_b, hl_b, hpq_b) = D._recorded[-2], D._recorded[-1]
+
+    def masks_of(rec, sl):
+        return [(t[sl] > 0).permute(0, 3, 1, 2).cpu() for t in rec]
+
+    def head_masks(hl, hpq, sl):
+        hl, hpq = hl.reshape(hl.shape[0], -1)[sl].cpu(), hpq.reshape(hpq.shape[0], -1)[sl].cpu()
+        return (hl > 0, hpq[:, :512] > 0, hpq[:, 512:] > 0)
+
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    osd = {k: v.clone() for k, v in sd.items()}
+    for k in osd:
+        if not k.endswith('kernel'):
+            osd[k].requires_grad_()
+    sf, sr, sall = slice(0, N), slice(N, 3 * N), slice(None)          # call_batches([fakes, real views])
+    d_gen, pf, p2f, _ = S.d_forward(osd, aug_f, 512, sg_linear=True, masks=masks_of(rec_a, sf),
+                                    head_masks=head_masks(hl_a, hpq_a, sf))
+    d_rs, pr, p2r, _ = S.d_forward(osd, aug_r, 512, sg_linear=True, masks=masks_of(rec_a, sr),
+                                   head_masks=head_masks(hl_a, hpq_a, sr))
+    views_r, reals = F.normalize(pr), F.normalize(p2r)
+    others, fakes = F.normalize(pf), F.normalize(p2f)
+    simclr = O.nt_xent(views_r[:N], views_r[N:], 0.1)
+    sup = O.supcon_fake(reals[:N], reals[N:], fakes, 0.1)
+    gan = F.softplus(d_gen).mean() + F.softplus(-d_rs[:N]).mean()
+    or1 = S.r1_penalty(lambda t: S.d_forward(osd, t, 512, masks=masks_of(rec_b, sall),
+                                             head_masks=head_masks(hl_b, hpq_b, sall))[0], aug_r1)
+    (simclr + sup + gan + (0.5 * 0.5) * or1 * 16).backward()
+    assert abs(d_loss.item() - (simclr + sup).item()) < TOL * abs((simclr + sup).item())
+    assert abs(aux['penalty'].item() - gan.item()) < TOL * gan.item()
+    assert abs(r1.item() - or1.item()) < TOL * or1.item()
+    worst = []
+    for k, prm in D.named_parameters():
+        ref = osd[k].grad
+        e = rel(prm.grad, ref)
+        worst.append((e, k))
+        assert e < TOL, (k, e)
+    if VERBOSE:
+        for e, k in sorted(worst)[-8:]:
+            print('config5 same-region: %-28s %.2e' % (k, e))
 
 
 def test_generator_512_forward_against_reference(golden):
