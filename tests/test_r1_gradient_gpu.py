@@ -3,8 +3,16 @@ train_stylegan2_contraD.py:129-136, op/upfirdn2d.py:62-85): ``r1.backward()`` on
 ``autograd.grad(r1, parameters)`` of the imported reference (tests/golden/make_golden.py::gen_stylegan2_r1) at 32^2
 (N = 4) and 512^2 (N = 2), each tensor compared at 1e-3 of ITS OWN norm -- in the full-step fixtures this gradient is
 0.5-1.4 % of the weight gradients and ~1e-6 of the bias gradients, where a 1e-3 check of the sum cannot see it.
-Plus the strict element-wise variant: the oracle evaluated on the linear regions the HIP forward actually used.
-The fixtures scale the ``linear`` head so that r1 is O(1) (3.4 / 0.97)."""
+Plus the strict element-wise variant: the oracle evaluated IN FLOAT64 on the linear regions the HIP forward actually
+used.  The fixtures scale the ``linear`` head so that r1 is O(1) (3.4 / 0.97).
+
+Tolerances: 1e-3 everywhere except the conv-BIAS gradients of the 512^2 fixture (BIAS_TOL_512).  Inside one linear
+region d D / d x does not depend on any bias, so d r1 / d bias flows exclusively through the second derivative of the
+minibatch-stddev channel, sqrt(var + 1e-8) (discriminator.py:22-33) -- at N = 2 a group of TWO samples, i.e.
+~|a - b| / 2, whose curvature eps / (var + eps)^1.5 lives where |a - b| <~ 1e-4: an fp32-ill-conditioned quantity.
+Measured (tools/dev/r1_conditioning.py): the REFERENCE's own fp32 CPU result is 0.7e-3 ... 1.5e-3 (relative L2) away
+from its float64 evaluation for exactly these tensors (weights: 1e-4); the HIP path is 0.8e-3 ... 0.9e-3 from the fp32
+reference.  At 32^2 (N = 4, groups of four) the same tensors agree to 5e-5."""
 import os
 
 import numpy as np
@@ -18,6 +26,7 @@ from sg2_inputs import seeded_images
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
+BIAS_TOL_512 = 4e-3      # conv biases of the 512^2 R1-only fixture, see the module docstring
 DEV = 'cuda'
 VERBOSE = bool(os.environ.get('CONTRAD_TEST_VERBOSE'))
 
@@ -75,7 +84,10 @@ def test_r1_gradient_alone_against_reference(golden, size):
     r1 = _hip_r1(D, aug_r1)
     assert abs(r1.item() - float(g['r1'])) < TOL * float(g['r1'])
     grads = {k: p.grad for k, p in D.named_parameters()}
-    report = []
+    report, bad = [], []
+
+    def tol_of(name):
+        return BIAS_TOL_512 if (size == 512 and name.endswith('bias')) else TOL
     for k in g.files:
         kind, _, name = k.partition('/')
         if kind == 'r1none':
@@ -84,27 +96,29 @@ def test_r1_gradient_alone_against_reference(golden, size):
             ref = float(g[k])
             e = abs(grads[name].norm().item() - ref) / ref
             report.append(('norm', name, e))
-            assert e < TOL, (name, e)
+            bad += [(name, e)] if not e < TOL else []
         elif kind == 'r1grad':                                   # whole tensor (every bias, the small weights)
             e = l2(grads[name], g[k])
             report.append(('l2', name, e))
-            assert e < TOL, (name, e)
+            bad += [(name, e)] if not e < tol_of(name) else []
         elif kind in ('r1gradhead', 'r1gradstride'):
             ref = torch.from_numpy(g[k])
             flat = grads[name].reshape(-1)
             got = (flat[:512] if kind == 'r1gradhead' else flat[::max(1, flat.numel() // 512)][:512]).cpu()
             e = l2(got, ref)
             report.append((kind[6:], name, e))
-            assert e < TOL, (name, kind, e)
+            bad += [(name, kind, e)] if not e < TOL else []
     if VERBOSE:
         for r in sorted(report, key=lambda t: -t[2])[:12]:
             print('r1-only %d: %-6s %-28s %.2e' % ((size,) + r))
+    assert not bad, bad
 
 
 @pytest.mark.parametrize('size', [32, 512])
 def test_r1_gradient_alone_on_the_same_linear_region(golden, size):
-    """Element-wise: every parameter's R1 gradient vs the oracle evaluated with the leaky-relu sign patterns recorded
-    from the HIP forward of the R1 batch (max-abs error relative to the tensor's max, 1e-3)."""
+    """Element-wise: every parameter's R1 gradient vs the oracle evaluated in float64 with the leaky-relu sign patterns
+    recorded from the HIP forward of the R1 batch (max-abs error relative to the tensor's max, 1e-3; the 512^2 conv
+    biases: BIAS_TOL_512, module docstring)."""
     g, D, sd, aug_r1 = _case(golden, size)
     D._record_activations = True
     r1 = _hip_r1(D, aug_r1)
@@ -112,24 +126,25 @@ def test_r1_gradient_alone_on_the_same_linear_region(golden, size):
     masks = [(t > 0).permute(0, 3, 1, 2).cpu() for t in rec]
     hl, hpq = hl.reshape(hl.shape[0], -1).cpu(), hpq.reshape(hpq.shape[0], -1).cpu()
     head_masks = (hl > 0, hpq[:, :512] > 0, hpq[:, 512:] > 0)
-    osd = {k: v.clone() for k, v in sd.items()}
+    osd = {k: v.clone().double() for k, v in sd.items()}
     for k in osd:
         if not k.endswith('kernel'):
             osd[k].requires_grad_()
     torch.set_num_threads(min(32, os.cpu_count() or 8))
-    or1 = S.r1_penalty(lambda t: S.d_forward(osd, t, size, masks=masks, head_masks=head_masks)[0], aug_r1)
+    or1 = S.r1_penalty(lambda t: S.d_forward(osd, t, size, masks=masks, head_masks=head_masks)[0], aug_r1.double())
     names = [k for k in osd if not k.endswith('kernel')]
     ogs = torch.autograd.grad(or1, [osd[k] for k in names], allow_unused=True)
     assert abs(r1.item() - or1.item()) < TOL * or1.item()
     grads = {k: p.grad for k, p in D.named_parameters()}
-    worst = []
+    worst, bad = [], []
     for k, og in zip(names, ogs):
         if og is None or og.abs().max().item() == 0:
             assert grads[k] is None or grads[k].abs().max().item() == 0, k
             continue
         e = rel(grads[k], og)
         worst.append((e, k))
-        assert e < TOL, (k, e)
+        bad += [(k, e)] if not e < (BIAS_TOL_512 if (size == 512 and k.endswith('bias')) else TOL) else []
     if VERBOSE:
         for e, k in sorted(worst)[-8:]:
             print('r1-only same-region %d: %-28s %.2e' % (size, k, e))
+    assert not bad, bad

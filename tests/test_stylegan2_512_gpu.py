@@ -100,24 +100,25 @@ def test_discriminator_512_contrad_step_against_reference(golden):
     assert abs(aux['penalty'].item() - float(g['gan'])) < TOL * float(g['gan'])
     assert abs(r1.item() - float(g['r1'])) < TOL * float(g['r1'])
     grads = {k: p.grad for k, p in D.named_parameters()}
-    report = []
+    report, bad = [], []
     for k in g.files:
         if k.startswith('gradnorm/'):
             name = k[len('gradnorm/'):]
             ref = float(g[k])
             e = abs(grads[name].norm().item() - ref) / max(ref, 1e-30)
             report.append((e, 'norm', name))
-            assert e < TOL, (name, e)
+            bad += [(name, e)] if not e < TOL else []
         elif k.startswith('gradhead/'):
             name = k[len('gradhead/'):]
             ref = torch.from_numpy(g[k])
             got = grads[name].reshape(-1)[:ref.numel()].cpu()
             e = l2(got, ref)
             report.append((e, 'head', name))
-            assert e < FLIP_TOL, (name, e)
+            bad += [(name, e)] if not e < FLIP_TOL else []
     if VERBOSE:
         for r in sorted(report)[-10:]:
             print('config5 raw golden: %.2e %s %s' % r)
+    assert not bad, bad
 
 
 def test_discriminator_512_step_on_the_same_linear_region(golden):
@@ -158,15 +159,16 @@ def test_discriminator_512_step_on_the_same_linear_region(golden):
     assert abs(d_loss.item() - (simclr + sup).item()) < TOL * abs((simclr + sup).item())
     assert abs(aux['penalty'].item() - gan.item()) < TOL * gan.item()
     assert abs(r1.item() - or1.item()) < TOL * or1.item()
-    worst = []
+    worst, bad = [], []
     for k, prm in D.named_parameters():
         ref = osd[k].grad
         e = rel(prm.grad, ref)
         worst.append((e, k))
-        assert e < TOL, (k, e)
+        bad += [(k, e)] if not e < TOL else []
     if VERBOSE:
         for e, k in sorted(worst)[-8:]:
             print('config5 same-region: %-28s %.2e' % (k, e))
+    assert not bad, bad
 
 
 def test_generator_512_forward_against_reference(golden):
