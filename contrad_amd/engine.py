@@ -10,6 +10,7 @@ so the exchange is two large collectives over xGMI instead of DDP's 25 MB bucket
 import torch
 import torch.distributed as dist
 
+from . import ops as _ops
 from .hostio import THROTTLE
 
 
@@ -236,7 +237,8 @@ class GraphedDStep(object):
         torch.cuda.synchronize()          # (capture records launches, it does not run them: the inputs stay untouched)
         G.invalidate_cache()              # the step re-packs G's weights itself: G moves between D-steps in training
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        self._scratch = {}           # this graph's own conv scratch (ops.private_workspace)
+        with _ops.private_workspace(self._scratch), torch.cuda.graph(self.graph):
             self.d_loss, self.aux = self._body()
         G.invalidate_cache()              # (what the capture allocated is filled by the first replay, not now)
         torch.cuda.synchronize()
@@ -385,7 +387,8 @@ class GraphedSG2DStep(object):
         torch.cuda.synchronize()
         G.invalidate_cache()              # as GraphedDStep: the packed tables are rebuilt inside the step
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        self._scratch = {}           # this graph's own conv scratch (ops.private_workspace)
+        with _ops.private_workspace(self._scratch), torch.cuda.graph(self.graph):
             self.d_loss, self.aux = self._body()
         G.invalidate_cache()
         torch.cuda.synchronize()
@@ -462,7 +465,8 @@ class GraphedGStep(object):
         torch.cuda.synchronize()
         G.invalidate_cache()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        self._scratch = {}           # this graph's own conv scratch (ops.private_workspace)
+        with _ops.private_workspace(self._scratch), torch.cuda.graph(self.graph):
             self.g_loss = self._body()
         G.invalidate_cache()
         torch.cuda.synchronize()
@@ -504,7 +508,8 @@ class GraphedSG2GStep(object):
         self.hyper = torch.ones(3, device=dev)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        self._scratch = {}           # this graph's own conv scratch (ops.private_workspace)
+        with _ops.private_workspace(self._scratch), torch.cuda.graph(self.graph):
             self.g_loss = self._body()
         G.invalidate_cache()
         torch.cuda.synchronize()

@@ -159,6 +159,27 @@ def conv2d_dgrad(gy, wp, x_shape, KH, KW, stride, pad, act_ref=None, slope=1.0, 
 _ws_cache = {}
 
 
+class private_workspace(object):
+    """Scratch buffers allocated inside this scope belong to ``owner_dict`` (held by the caller) instead of the
+    process-wide cache.  A captured hipGraph bakes raw scratch pointers into its nodes, and every ``torch.cuda.graph``
+    capture runs on the same capture stream: without this, a second captured graph would reuse -- or, when it needs
+    more, REPLACE and thereby free -- the buffer the first graph still writes to.  Each Graphed*Step wraps its capture
+    in one of these and keeps ``owner_dict`` alive as long as its graph."""
+
+    def __init__(self, owner_dict):
+        self.mine = owner_dict
+
+    def __enter__(self):
+        global _ws_cache
+        self.saved, _ws_cache = _ws_cache, self.mine
+        return self
+
+    def __exit__(self, *exc):
+        global _ws_cache
+        _ws_cache = self.saved
+        return False
+
+
 def _workspace(nbytes, device):
     """Grow-only per-device scratch (reused across calls on the same stream; torch owns the memory)."""
     key = (device.index, _stream_handle())

@@ -41,8 +41,10 @@ class FusedAdam(torch.optim.Optimizer):
 
     # ---- hipGraph support: the launch sequence is captured once, the step-dependent scalars live in device memory ----
     def hyper_values(self, grad_scale=1.0):
-        """Advance every parameter's step count by one and return [lr / bc1, 1 / sqrt(bc2), grad_scale] of the (single)
-        param group for THAT step -- what ``step_captured`` reads from its device tensor."""
+        """Advance the step count of the parameters the captured update touches (those that had a gradient when
+        ``step_captured`` was recorded -- the same set the eager ``step()`` advances; all parameters with state before
+        any capture) by one and return [lr / bc1, 1 / sqrt(bc2), grad_scale] of the (single) param group for THAT step
+        -- what ``step_captured`` reads from its device tensor."""
         import math
         import struct
         group = self.param_groups[0]
@@ -50,7 +52,8 @@ class FusedAdam(torch.optim.Optimizer):
         f32 = lambda v: struct.unpack('f', struct.pack('f', v))[0]
         beta1, beta2 = (f32(b) for b in group['betas'])
         step = None
-        for p in group['params']:
+        captured = getattr(self, '_captured_params', None)
+        for p in (captured if captured is not None else group['params']):
             st = self.state.get(p)
             if not st:                       # never received a gradient: no optimizer state, not part of the update
                 continue
@@ -73,6 +76,11 @@ class FusedAdam(torch.optim.Optimizer):
         steps = {int(self.state[p]['step']) for p in ps}
         if len(steps) != 1:
             raise RuntimeError('step_captured: parameters at different step counts')
+        if getattr(self, '_captured_params', None) is not None and \
+                [id(p) for p in self._captured_params] != [id(p) for p in ps]:
+            raise RuntimeError('step_captured: a second capture over a different parameter set (the step counts of the '
+                               'two replays would drift apart)')
+        self._captured_params = ps
         beta1, beta2 = group['betas']
         ops.adam_step_dev([p.data for p in ps], [p.grad.data for p in ps], [self.state[p]['exp_avg'] for p in ps],
                           [self.state[p]['exp_avg_sq'] for p in ps], hyper, beta1, beta2, group['eps'])

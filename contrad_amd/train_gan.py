@@ -111,20 +111,31 @@ class GraphedCritic(object):
     def __init__(self):
         self.step = None
         self.gstep = None
+        self.eager_d = self.eager_g = 0       # eager steps seen IN THIS PROCESS (see _may_capture)
+
+    @staticmethod
+    def _may_capture(seen, optimizer):
+        """Capture only after one eager step has run in this process AND the optimizer holds state.  The state alone is
+        not enough: after ``--resume`` it is non-empty at once, but the first step of a fresh process still does
+        first-use host work that must not land inside a stream capture (blocking host -> device copies of cached
+        constants, first-time workspace allocations, kernel module loads)."""
+        return seen >= 1 and len(optimizer.state) > 0
 
     def generator(self, P, opt, G, D, opt_G, images):
         """The generator step of the iteration from its own captured graph (engine.GraphedGStep); None while it has to
-        run eagerly (first iteration)."""
+        run eagerly (first iteration of the process)."""
         if self.gstep is None:
-            if not len(opt_G.state):
+            if not self._may_capture(self.eager_g, opt_G):
+                self.eager_g += 1
                 return None
             self.gstep = GraphedGStep(P, G, D, opt_G, opt, images.size(0), images.size(2), images.size(3))
         return self.gstep()
 
     def __call__(self, P, opt, G, D, opt_D, images):
         if self.step is None:
-            if not len(opt_D.state):
-                return None                       # first iteration: eager (Adam state does not exist yet)
+            if not self._may_capture(self.eager_d, opt_D):
+                self.eager_d += 1
+                return None                       # first iteration of this process: eager
             if P.mode != 'contrad':
                 raise NotImplementedError("--graph captures the ContraD critic iteration (--mode contrad), not '%s'"
                                           % P.mode)
@@ -257,6 +268,8 @@ def main(argv=None):
     if P.graph:
         if world > 1:
             log('--graph: single process only (RCCL inside a captured graph is not validated here) -> eager')
+        elif P.mode != 'contrad':
+            log("--graph captures the ContraD critic iteration (--mode contrad), not '%s' -> eager" % P.mode)
         else:
             graphed = GraphedCritic()
     t0 = time.time()

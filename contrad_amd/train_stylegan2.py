@@ -143,6 +143,11 @@ def _opt_step(opt, reducer):
     opt.step(grad_scale=1.0 / world) if world > 1 else opt.step()
 
 
+# train_stylegan2_contraD.py calls G_D.forward WITHOUT its style_mix argument (:207,218 -> the default 0.9 of :128): the
+# ``--style_mix`` flag only names the log directory there (:349).  Reproduced as is.
+CONTRAD_SCRIPT_STYLE_MIX = 0.9
+
+
 class GraphedCritic(object):
     """``--graph`` for train_stylegan2_contraD.py: its D-step (fresh fakes, two D calls, lazy R1) is exactly
     engine.d_step_stylegan2_contrad, so it is replayed from engine.GraphedSG2DStep -- captured at the first D-step after
@@ -151,23 +156,33 @@ class GraphedCritic(object):
     def __init__(self):
         self.step = None
         self.gstep = None
+        self.eager_d = self.eager_g = 0       # eager steps seen IN THIS PROCESS
+
+    @staticmethod
+    def _may_capture(seen, optimizer):
+        """One eager step in this process AND optimizer state (after ``--resume`` the state exists at once, but a fresh
+        process's first step does first-use host work -- constant uploads, workspace allocation, module loads -- that
+        must not fall inside a stream capture)."""
+        return seen >= 1 and len(optimizer.state) > 0
 
     def generator(self, P, opt, G, D, opt_G, images):
         """The generator step from its own captured graph (engine.GraphedSG2GStep); None while it runs eagerly."""
         if self.gstep is None:
-            if not len(opt_G.state):
+            if not self._may_capture(self.eager_g, opt_G):
+                self.eager_g += 1
                 return None
             self.gstep = GraphedSG2GStep(P, G, D, opt_G, opt, images.size(0), images.size(2), images.size(3),
-                                         style_mix=P.style_mix)
+                                         style_mix=CONTRAD_SCRIPT_STYLE_MIX)
         return self.gstep()
 
     def __call__(self, P, opt, G, D, opt_D, images, step):
         if self.step is None:
-            if not len(opt_D.state):
+            if not self._may_capture(self.eager_d, opt_D):
+                self.eager_d += 1
                 return None
             if P.mode != 'contrad':
                 raise NotImplementedError("--graph captures the ContraD D-step (--mode contrad), not '%s'" % P.mode)
-            self.step = GraphedSG2DStep(P, G, D, opt_D, opt, images, contrad_script=True, style_mix=P.style_mix,
+            self.step = GraphedSG2DStep(P, G, D, opt_D, opt, images, contrad_script=True, style_mix=CONTRAD_SCRIPT_STYLE_MIX,
                                         warmup=0)
         self.step.load_images(images)
         return self.step(step)
@@ -178,6 +193,7 @@ def train_iteration(P, opt, G, D, g_ema, opt_G, opt_D, loader, step, reducers, c
     Returns the loss tensors (no host sync)."""
     THROTTLE.begin()
     red_G, red_D = reducers
+    style_mix = CONTRAD_SCRIPT_STYLE_MIX if contrad_script else P.style_mix
     d_regularize = (step % P.d_reg_every == 0) and (P.lbd_r1 > 0)
     if P.use_warmup:
         _update_warmup(opt_G, step, opt["warmup"], opt["lr"])
@@ -200,7 +216,7 @@ def train_iteration(P, opt, G, D, g_ema, opt_G, opt_D, loader, step, reducers, c
     set_grad(G, True); set_grad(D, False)
     g_loss = graphed.generator(P, opt, G, D, opt_G, images) if graphed is not None else None
     if g_loss is None:
-        gen_images = sample_generator(G, N, style_mix=P.style_mix, enable_grad=True)
+        gen_images = sample_generator(G, N, style_mix=style_mix, enable_grad=True)
         if contrad_script:      # G_D.forward(train_G=True): D(augment(G(z)), sg_linear=False, ...) -> d_gen
             d_gen, _aux = D(P.augment_fn(gen_images), sg_linear=False, projection=True, projection2=True)
             g_loss = loss_G_nonsat(d_gen)
@@ -226,7 +242,7 @@ def train_iteration(P, opt, G, D, g_ema, opt_G, opt_D, loader, step, reducers, c
             out['D_r1'] = aux['r1'].detach()
     else:
         if contrad_script:
-            gen_images = sample_generator(G, N, style_mix=P.style_mix, enable_grad=False)
+            gen_images = sample_generator(G, N, style_mix=style_mix, enable_grad=False)
         d_loss, aux = d_loss_of(images, gen_images.detach())
         loss = d_loss + aux['penalty']
         if d_regularize:
@@ -238,7 +254,7 @@ def train_iteration(P, opt, G, D, g_ema, opt_G, opt_D, loader, step, reducers, c
         _opt_step(opt_D, red_D)
     for _ in range(opt['n_critic'] - 1):
         images, _labels = next(loader)
-        gen_images = sample_generator(G, images.size(0), style_mix=P.style_mix, enable_grad=False)
+        gen_images = sample_generator(G, images.size(0), style_mix=style_mix, enable_grad=False)
         d_loss, aux = d_loss_of(images, gen_images)
         opt_D.zero_grad()
         (d_loss + aux['penalty']).backward()
@@ -389,6 +405,8 @@ def main(argv=None, contrad_script=False):
         if world > 1 or not contrad_script:
             log('--graph: single-process train_stylegan2_contraD.py only (train_stylegan2.py feeds the D-step the '
                 'G-step\'s fakes) -> eager')
+        elif P.mode != 'contrad':
+            log("--graph captures the ContraD D-step (--mode contrad), not '%s' -> eager" % P.mode)
         else:
             graphed = GraphedCritic()
     t0 = time.time()

@@ -159,3 +159,40 @@ def test_train_stylegan2_contrad_with_graph_writes_the_eager_runs_checkpoints(tm
               '--max_steps', '6', '--evaluate_every', '6', '--seed', '5', '--logdir', logdir] + extra)
         runs.append(_state(logdir, ('gen.pt', 'dis.pt', 'gen_ema.pt', 'optim.pt')))
     _assert_same(runs[0], runs[1])
+
+
+def _fresh_process(script, args):
+    """Run a launcher in a NEW interpreter: cold caches (device constants, workspaces, kernel modules not loaded) --
+    the conditions under which a capture in the very first iteration used to fail."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, script)] + args, cwd=root, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize('family', ['sndcgan', 'stylegan2'])
+def test_resume_with_graph_in_a_fresh_process(tmp_path, family):
+    """--resume + --graph: the optimizer state exists from the first iteration, the process is cold.  The capture has to
+    wait for one eager iteration of THIS process (GraphedCritic._may_capture); the resumed run with --graph writes
+    bitwise the checkpoints of the resumed eager run."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if family == 'sndcgan':
+        script, names = 'train_gan.py', ('gen.pt', 'dis.pt', 'optim.pt')
+        base = [os.path.join(root, 'configs', 'gan', 'cifar10', 'c10_b64.gin'), 'sndcgan', '--mode=contrad',
+                '--aug=simclr', '--synthetic', '--print_every', '2', '--seed', '5']
+    else:
+        script, names = 'train_stylegan2_contraD.py', ('gen.pt', 'dis.pt', 'gen_ema.pt', 'optim.pt')
+        base = [os.path.join(root, 'configs', 'gan', 'stylegan2', 'c10_style64.gin'), 'stylegan2', '--mode=contrad',
+                '--aug=simclr', '--lbd_r1', '0.1', '--d_reg_every', '2', '--synthetic', '--batch_size', '8',
+                '--halflife_k', '1', '--ema_start_k', '0', '--print_every', '2', '--seed', '5']
+    first = str(tmp_path / 'first')
+    _fresh_process(script, base + ['--max_steps', '3', '--evaluate_every', '3', '--logdir', first])
+    runs = []
+    for tag, extra in (('eager', []), ('graph', ['--graph'])):
+        logdir = str(tmp_path / tag)
+        _fresh_process(script, base + ['--max_steps', '8', '--evaluate_every', '8', '--resume', first, '--logdir', logdir]
+                       + extra)
+        runs.append(_state(logdir, names))
+    _assert_same(runs[0], runs[1])
