@@ -53,6 +53,7 @@ CONFIGS = {
                             "Adam(2e-3,(0,0.99)), random-init weights"),
     'sg2_512': dict(arch='stylegan2_512', size=512, batch=16, batch_is_global=False, aug='simclr_hq',
                     gin=('gan', 'stylegan2', 'afhq_dog_style64.gin'), flop_per_image=388.7e9 + 235e9 / 16,
+                    flop_plain=388.7e9, flop_r1=235e9,
                     d_reg_every=16, lbd_r1=0.5, steps=16, warmup=2,
                     workload="StyleGAN2_512 (channel multiplier 1) + ContraD D-step, AFHQ-shaped 512x512, batch %d per "
                              "GPU, simclr_hq aug (crop 0.08-1, jitter 0.8/0.8/0.8/0.2, gaussian blur k=51), lazy R1 every "
@@ -196,10 +197,64 @@ def _pmc_traffic(config, kernel):
             pmc = json.load(open(os.path.join(prof, f)))
             ent = pmc.get('kernels', {}).get(kernel)
             if ent is not None:
+                if pmc.get('csrc_fingerprint') != _csrc_fingerprint():
+                    # counters cannot be read inside the timed process; a summary collected on OTHER kernel sources is
+                    # not this build's traffic -> null, and say why
+                    return None, 'stale: profiles/%s was collected on kernel sources %s, this build is %s' % (
+                        f, pmc.get('csrc_fingerprint'), _csrc_fingerprint())
                 return ent['traffic_bytes_per_launch'], 'profiles/' + f
         except (OSError, ValueError, KeyError):
             pass
     return None, None
+
+
+def _write_shape_table(path, name, cfg, warm_prof, marks, n_local):
+    """One row per (kernel instance, layer shape) of the conv engine, from the event-bracketed eager warm-up steps:
+    launches per step, algorithmic GFLOP per launch (2*N*Ho*Wo*K*C*KH*KW), workgroups of the main launch -- the key
+    tools/rocpd_rows.py joins a rocprofv3 kernel trace on (the trace names only the template instance).  With lazy R1 the
+    first warm-up step is the R1 step: its launches go into their own section."""
+    nsteps = len(marks) - 1
+    if nsteps <= 0:
+        return
+    lazy = cfg['d_reg_every'] > 1
+    sections = {}
+    for i in range(nsteps):
+        sec = 'r1_step' if (lazy and i == 0) else 'plain_step'
+        if not lazy and nsteps > 1 and i == 0:
+            continue                                   # first eager step: cold caches
+        d = sections.setdefault(sec, {'steps': 0, 'rows': {}})
+        d['steps'] += 1
+        for kname, flops, e0, e1, shape, blocks in warm_prof[marks[i]:marks[i + 1]]:
+            r = d['rows'].setdefault((kname, shape, blocks), [0, 0.0, flops])
+            r[0] += 1
+            r[1] += e0.elapsed_time(e1)
+    out = {'config': name, 'per_gpu_batch': n_local, 'flop_rule': '2*N*Ho*Wo*K*C*KH*KW per launch',
+           'shape_fields': ['N', 'H', 'W', 'C', 'K', 'KH', 'KW', 'stride', 'pad'],
+           'note': 'bracket_us = HIP events around the C-ABI call in eager warm-up steps (a WGRAD bracket spans the '
+                   'main kernel and its reduce kernel); grid_blocks = workgroups of the main igemm launch', 'sections': {}}
+    for sec, d in sections.items():
+        rows = []
+        for (kname, shape, blocks), (cnt, ms, flops) in d['rows'].items():
+            rows.append({'kernel': kname, 'shape': list(shape), 'grid_blocks': blocks,
+                         'launches_per_step': cnt / d['steps'], 'gflop_per_launch': round(flops / 1e9, 4),
+                         'bracket_us': round(ms / cnt * 1e3, 2), 'bracket_tflops': round(flops * cnt / (ms * 1e-3) / 1e12, 2)})
+        rows.sort(key=lambda r: -r['gflop_per_launch'] * r['launches_per_step'])
+        out['sections'][sec] = {'steps_sampled': d['steps'], 'rows': rows}
+    with open(path, 'w') as f:
+        json.dump(out, f, indent=1)
+
+
+def _csrc_fingerprint():
+    """sha256 over the kernel sources: a committed PMC summary names the fingerprint it was collected with, so a summary
+    that predates a kernel change is recognised as stale instead of being quoted."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'contrad_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def run_config(name, args, world, rank, dev, multi):
@@ -284,11 +339,13 @@ def run_config(name, args, world, rank, dev, multi):
     ops.PROFILE = []
     wsteps = max(1, warmup // 2)                                     # the later half of the warm-up (clocks ramped)
     wagg = {}
-    for kname, flops, e0, e1 in warm_prof[marks[max(0, warmup - wsteps)]:]:
+    for kname, flops, e0, e1 in (q[:4] for q in warm_prof[marks[max(0, warmup - wsteps)]:]):
         a = wagg.setdefault(kname, [0.0, 0.0, 0])
         a[0] += e0.elapsed_time(e1) * 1e-3
         a[1] += flops
         a[2] += 1
+    if args.shape_table and rank == 0:
+        _write_shape_table(args.shape_table, name, cfg, warm_prof, marks, n_local)
     del warm_prof
     ops.PROFILE_ONLY = max(wagg.items(), key=lambda kv: kv[1][0])[0] if wagg else None
     if use_graph:
@@ -387,19 +444,21 @@ def run_config(name, args, world, rank, dev, multi):
         # steps); its launches in the timed region are the `achieved` figure
         if dom_name is None:                                        # --warmup 0: everything was bracketed
             tagg = {}
-            for n_, f_, e0, e1 in prof:
+            for n_, f_, e0, e1 in (q[:4] for q in prof):
                 a = tagg.setdefault(n_, [0.0, 0.0, 0])
                 a[0] += e0.elapsed_time(e1) * 1e-3; a[1] += f_; a[2] += 1
             dom_name = max(tagg.items(), key=lambda kv: kv[1][0])[0]
             wagg, wsteps = tagg, steps
             prof = [q for q in prof if q[0] == dom_name]
-        tsum = sum(e0.elapsed_time(e1) for _, _, e0, e1 in prof) * 1e-3
-        fsum = sum(f for _, f, _, _ in prof)
+        tsum = sum(q[2].elapsed_time(q[3]) for q in prof) * 1e-3
+        fsum = sum(q[1] for q in prof)
         cnt = max(len(prof), 1)
         achieved = fsum / max(tsum, 1e-12) / 1e12
         conv_time_per_step = sum(a[0] for a in wagg.values()) / wsteps
         traffic, traffic_src = _pmc_traffic(name, dom_name) if world == 1 else (None, None)
         fpi = cfg['flop_per_image']
+        if cfg['d_reg_every'] > 1:      # lazy R1: price the R1 steps actually inside the timed window, not 1 / period
+            fpi = cfg['flop_plain'] + cfg['flop_r1'] * (steps // cfg['d_reg_every']) / steps
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic,
                     "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
@@ -447,6 +506,8 @@ def main():
     ap.add_argument('--config', default='all', choices=sorted(CONFIGS) + ['all'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-g-step', action='store_true', help='skip the separately reported generator-step timing')
+    ap.add_argument('--shape-table', default=None,
+                    help='write the per-(kernel, layer shape) table of the conv engine (from the bracketed warm-up) here')
     ap.add_argument('--graph', default='on', choices=['on', 'off'],
                     help='single process: replay the D-step as one captured hipGraph (engine.GraphedDStep / GraphedSG2DStep)')
     ap.add_argument('--force-dist', action='store_true',

@@ -1143,6 +1143,29 @@ extern "C" int contrad_conv2d_path(const contrad_conv_desc* d, int mode) {
   return lean_ok(d, mode, pps) ? 2 : 1;
 }
 
+extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int mode, int with_workspace) {
+  if (check_desc(d) || mode < 0 || mode > 2) return -22;
+  if (mode == MODE_FWD) {
+    const FwdPlan p = fwd_plan(d);
+    const long long M = (long long)d->N * d->Ho * d->Wo;
+    return cdivll(M, p.bm) * cdiv(d->K, p.bn) * (with_workspace ? p.splits : 1);
+  }
+  if (mode == MODE_DGRAD) {
+    const int s = d->stride;
+    const long long Mc = (long long)d->N * cdiv(d->H, s) * cdiv(d->W, s);
+    const FwdPlan p = dgrad_plan(d, with_workspace != 0);
+    const int tiles_m = cdiv((int)Mc, p.bm), tiles_n = cdiv(d->C, p.bn);
+    if (p.splits > 1) return (long long)tiles_m * tiles_n * p.splits;
+    static const int g = []() { const char* e = getenv("CONTRAD_DGRAD_CGROUP"); return e ? atoi(e) : 8; }();
+    const int cgroup = (s > 1) ? (g < tiles_m ? g : tiles_m) : 0;
+    const int tm_pad = cgroup > 0 ? cdiv(tiles_m, cgroup) * cgroup : tiles_m;
+    return (long long)tm_pad * tiles_n * s * s;
+  }
+  int bm, bn, tm, tn, splits, pps;
+  wgrad_plan(d, &bm, &bn, &tm, &tn, &splits, &pps);
+  return (long long)tm * tn * splits;
+}
+
 extern "C" long long contrad_conv2d_wgrad_workspace_bytes(const contrad_conv_desc* d) {
   if (check_desc(d)) return -22;
   int bm, bn, tm, tn, splits, pps;

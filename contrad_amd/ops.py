@@ -63,7 +63,7 @@ def out_size(h, k, stride, pad):
 
 
 # Optional per-launch profiler (bench.py): when set to a list, conv-engine launches are bracketed by events on the
-# launch stream and appended as (kernel_name, algorithmic_flops, start_event, end_event).  kernel_name is the device
+# launch stream and appended as (kernel_name, algorithmic_flops, start_event, end_event, layer shape, workgroups of the main launch).  kernel_name is the device
 # kernel's name as rocprofv3 prints it.  PROFILE_ONLY (a kernel name) restricts the bracketing to that kernel: every
 # event pair costs ~10 us of stream time, so the timed region of bench.py instruments the dominant kernel only.
 # (A WGRAD bracket spans the split-K main kernel and its wgrad_reduce_kernel: one C-ABI call launches both.)
@@ -95,7 +95,9 @@ def _conv_call(mode, d, name, *args):
     e1.record(st)
     # algorithmic flops; for a strided dgrad this equals the forward count (only contributing taps are multiplied)
     flops = 2.0 * d.N * d.Ho * d.Wo * d.K * d.C * d.KH * d.KW
-    PROFILE.append((kname, flops, e0, e1))
+    shape = (d.N, d.H, d.W, d.C, d.K, d.KH, d.KW, d.stride, d.pad)
+    blocks = lib().raw('contrad_conv2d_grid_blocks')(ctypes.byref(d), mode, 1)
+    PROFILE.append((kname, flops, e0, e1, shape, int(blocks)))
 
 
 def make_desc(N, H, W, C, K, KH, KW, stride, pad, ldx, ldy, ldw):

@@ -81,6 +81,10 @@ int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm, int* bn);
 /* Which kernel family serves this shape: 0 = general scalar-gather (igemm_kernel<..., false>), 1 = general float4
  * (igemm_kernel<..., true>), 2 = lean loop (igemm_lean_kernel); negative = bad descriptor.  Profiling aid. */
 int contrad_conv2d_path(const contrad_conv_desc* d, int mode);
+/* Workgroups (256 threads each) of the main igemm launch this geometry gets for `mode` (with_workspace != 0: the plan the
+ * *_ws entry points use, i.e. split-K allowed).  Profiling aid: lets a rocprofv3 kernel trace, which names only the
+ * template instance, be joined to the layer shape a dispatch served (tools/rocpd_rows.py); negative = bad descriptor. */
+long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int mode, int with_workspace);
 int contrad_conv2d_wgrad(const contrad_conv_desc* d, const float* x, const float* gy, float* dwp,
                          float* dbias, float* workspace, long long workspace_bytes, contrad_stream_t stream);
 

@@ -68,7 +68,10 @@ def main(d, prefix, command):
              parsed['fetch'][k]['avg_dur_us'] > 10.0 and not k.startswith('at::')]
     ents = {k: entry(k) for k in names}
     dom = max(ents.values(), key=lambda e: e['avg_dur_us'] * e['dispatches'] if 'igemm' in e['kernel'] else 0)['kernel']
+    sys.path.insert(0, ROOT)
+    from bench import _csrc_fingerprint
     js = {
+        "csrc_fingerprint": _csrc_fingerprint(),        # bench.py quotes `traffic` only for the sources it was collected on
         "command": command + " (under rocprofv3 --kernel-trace --pmc <counter set>, one pass per counter set)",
         "correction": "gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM): bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
         "kernel": dom,
