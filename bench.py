@@ -224,6 +224,8 @@ def _write_shape_table(path, name, cfg, warm_prof, marks, n_local):
             continue                                   # first eager step: cold caches
         d = sections.setdefault(sec, {'steps': 0, 'rows': {}})
         d['steps'] += 1
+        # the launch ORDER of one step: rocpd_rows.py aligns the trace's igemm dispatches of a step with it
+        d['sequence'] = [[q[0], list(q[4]), q[5], round(q[1] / 1e9, 4)] for q in warm_prof[marks[i]:marks[i + 1]]]
         for kname, flops, e0, e1, shape, blocks in warm_prof[marks[i]:marks[i + 1]]:
             r = d['rows'].setdefault((kname, shape, blocks), [0, 0.0, flops])
             r[0] += 1
@@ -239,7 +241,8 @@ def _write_shape_table(path, name, cfg, warm_prof, marks, n_local):
                          'launches_per_step': cnt / d['steps'], 'gflop_per_launch': round(flops / 1e9, 4),
                          'bracket_us': round(ms / cnt * 1e3, 2), 'bracket_tflops': round(flops * cnt / (ms * 1e-3) / 1e12, 2)})
         rows.sort(key=lambda r: -r['gflop_per_launch'] * r['launches_per_step'])
-        out['sections'][sec] = {'steps_sampled': d['steps'], 'rows': rows}
+        out['sections'][sec] = {'steps_sampled': d['steps'], 'rows': rows, 'sequence': d['sequence'],
+                                'sequence_fields': ['kernel', 'shape', 'grid_blocks', 'gflop']}
     with open(path, 'w') as f:
         json.dump(out, f, indent=1)
 
@@ -305,7 +308,8 @@ def run_config(name, args, world, rank, dev, multi):
     # allocator before the timed window (a cold hipMalloc of that size inside the window cost up to 0.5 s on a busy box)
     counter = [cfg['d_reg_every'] - 1 if cfg['d_reg_every'] > 1 else 0]
     graphed = [None]
-    use_graph = not multi and args.graph != 'off'
+    # hipGraph replay also with a process group: the collectives are captured with the step (engine.GraphedDStep)
+    use_graph = args.graph != 'off'
     if name == 'c10_b512':
         def one_step():
             if graphed[0] is not None:
@@ -509,7 +513,8 @@ def main():
     ap.add_argument('--shape-table', default=None,
                     help='write the per-(kernel, layer shape) table of the conv engine (from the bracketed warm-up) here')
     ap.add_argument('--graph', default='on', choices=['on', 'off'],
-                    help='single process: replay the D-step as one captured hipGraph (engine.GraphedDStep / GraphedSG2DStep)')
+                    help='replay the D-step as one captured hipGraph (engine.GraphedDStep / GraphedSG2DStep; with a process group the '
+                         'RCCL collectives are captured with it)')
     ap.add_argument('--force-dist', action='store_true',
                     help='dev: run all collective code paths on a 1-rank RCCL group (single GPU)')
     ap.add_argument('--dev-local-batch', type=int, default=0,

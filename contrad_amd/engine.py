@@ -214,8 +214,15 @@ class GraphedDStep(object):
     parameters -- on the host, in the reference's RNG order, exactly as the eager path), hands them over into STATIC
     device tensors, refreshes three Adam scalars, and launches the graph.  What had to move from launch arguments into
     device memory for that: the colour-op order of the augmentation (column 15 of the parameter block) and Adam's
-    step-dependent scalars (``contrad_adam_step_dev``).  Single process; with a process group the eager path stays
-    (RCCL inside a captured graph is not validated on this stack).
+    step-dependent scalars (``contrad_adam_step_dev``).
+
+    With a process group (one rank of a data-parallel job, train_gan.py:230-318) the collectives are captured WITH the
+    step: G's SyncBN statistics all-reduce, the packed embedding all-gather inside the loss and the per-layer gradient
+    all-reduces the fused backward overlaps with itself (OverlappedGradReducer: RCCL's own stream forks from and joins the
+    capture stream through events, which a stream capture records as graph edges); Adam's 1/W travels in the device
+    scalars.  A per-rank batch of 64 is ~3.4 ms of GPU work against ~2.8 ms of Python launch time in the eager path
+     -- this is what takes the host off that critical path.  Every rank must replay the same graph
+    the same number of times (as every rank must issue the same eager collectives).
     """
 
     def __init__(self, P, G, D, opt_D, options, images, warmup=3):
@@ -223,14 +230,18 @@ class GraphedDStep(object):
         from . import ops
         self.P, self.G, self.D, self.opt, self.options = P, G, D, opt_D, options
         self.aug = P.augment_fn
-        if not isinstance(self.aug, SimCLRAugment) or self.aug.p_blur is not None or dist_on():
-            raise NotImplementedError('GraphedDStep: single-process simclr pipeline')
+        if not isinstance(self.aug, SimCLRAugment) or self.aug.p_blur is not None:
+            raise NotImplementedError('GraphedDStep: the simclr pipeline')
+        self.dist = dist_on()
+        self.reducer = None
+        if self.dist and getattr(D, '_grad_comm', None) is None:
+            self.reducer = GradAllReducer(D.parameters())       # flat collectives after the backward
         self.images = images.clone()                    # static input: load_images() hands over a new real batch
         N = images.size(0)
         dev = images.device
         self.N = N
         for _ in range(warmup if len(opt_D.state) else max(warmup, 1)):     # optimizer state, workspaces, pools
-            d_step(P, G, D, opt_D, options, images)
+            d_step(P, G, D, opt_D, options, images, self.reducer)
         self.z = torch.zeros(N, G.nz, device=dev)
         self.params = torch.zeros(3 * N, ops.AUG_NPARAM, device=dev)
         self.hyper = torch.ones(3, device=dev)
@@ -255,7 +266,8 @@ class GraphedDStep(object):
         Pm[:, 15] = float(cf)
         self.z.copy_(upload(z, dev))
         self.params.copy_(upload(Pm, dev))
-        self.hyper.copy_(upload(torch.tensor([self.opt.hyper_values()], dtype=torch.float32), dev).view(3))
+        world = dist.get_world_size() if self.dist else 1
+        self.hyper.copy_(upload(torch.tensor([self.opt.hyper_values(1.0 / world)], dtype=torch.float32), dev).view(3))
 
     def _body(self):
         from . import ops
@@ -266,11 +278,14 @@ class GraphedDStep(object):
             cat = torch.cat([self.images, self.images, gen], dim=0)
             aug = ops.simclr_augment(cat, self.params, -1, self.aug.r_c is not None)
         d_all, aux = D(aug, sg_linear=True, projection=True, projection2=True)
-        simclr, sup = _ContraDContrastive.apply(aux['projection'], aux['projection2'], N, P.temp, False)
+        simclr, sup = _ContraDContrastive.apply(aux['projection'], aux['projection2'], N, P.temp,
+                                                bool(P.distributed) and self.dist)
         gan, d_real, d_gen = _GanDLoss.apply(d_all, N, self.options['loss'])
         d_loss = simclr + P.lbd_a * sup
         self.opt.zero_grad(set_to_none=True)
         (d_loss + gan).backward()
+        if self.reducer is not None:
+            self.reducer()                      # (the overlapped reducer exchanged inside the backward already)
         self.opt.step_captured(self.hyper)
         # detached: the step's autograd graph must not outlive the capture (its AccumulateGrad nodes are tied to the
         # capture stream; an eager backward later on would have to synchronise with it)
@@ -367,8 +382,8 @@ class GraphedSG2DStep(object):
 
     def __init__(self, P, G, D, opt_D, options, images, contrad_script, style_mix=0.9, warmup=2):
         import argparse
-        if dist_on():
-            raise NotImplementedError('GraphedSG2DStep: single process')
+        self.dist = dist_on()       # one rank of a data-parallel job: the embedding all-gather (inside the loss) and the
+        self.reducer = GradAllReducer(D.parameters()) if self.dist else None      # flat gradient all-reduces are captured
         self.P, self.G, self.D, self.opt, self.options, self.images = P, G, D, opt_D, options, images.clone()
         self.contrad_script, self.style_mix = contrad_script, style_mix
         self.eager = d_step_stylegan2_contrad if contrad_script else d_step_stylegan2
@@ -376,7 +391,7 @@ class GraphedSG2DStep(object):
         self.N = N
         self.r1_in_graph = P.lbd_r1 > 0 and P.d_reg_every == 1
         for s in range(1, (warmup if len(opt_D.state) else max(warmup, 1)) + 1):     # optimizer state, workspaces
-            self.eager(P, G, D, opt_D, options, images, s if P.d_reg_every == 1 else 1, None, style_mix)
+            self.eager(P, G, D, opt_D, options, images, s if P.d_reg_every == 1 else 1, self.reducer, style_mix)
         H, W = images.shape[2], images.shape[3]
         sizes = ([N, 2 * N] if contrad_script else [3 * N]) + ([N] if self.r1_in_graph else [])
         self.saug = _StaticAugment(P.augment_fn, sizes, H, W, dev)
@@ -401,7 +416,8 @@ class GraphedSG2DStep(object):
         dev = self.images.device
         self.gin.refresh()
         self.saug.refresh()
-        self.hyper.copy_(upload(torch.tensor([self.opt.hyper_values()], dtype=torch.float32), dev).view(3))
+        world = dist.get_world_size() if self.dist else 1
+        self.hyper.copy_(upload(torch.tensor([self.opt.hyper_values(1.0 / world)], dtype=torch.float32), dev).view(3))
 
     def _body(self):
         P, G, D = self.Pg, self.G, self.D
@@ -419,13 +435,15 @@ class GraphedSG2DStep(object):
             aux['r1'] = r1
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
+        if self.reducer is not None:
+            self.reducer()
         self.opt.step_captured(self.hyper)
         return d_loss.detach(), {k: v.detach() for k, v in aux.items()}     # (see GraphedDStep._body)
 
     def __call__(self, step):
         P = self.P
         if P.lbd_r1 > 0 and P.d_reg_every > 1 and step % P.d_reg_every == 0:      # lazy-R1 step: eager
-            return self.eager(P, self.G, self.D, self.opt, self.options, self.images, step, None, self.style_mix)
+            return self.eager(P, self.G, self.D, self.opt, self.options, self.images, step, self.reducer, self.style_mix)
         THROTTLE.begin()
         self._refresh()
         self.graph.replay()
@@ -438,7 +456,8 @@ class GraphedSG2DStep(object):
 # ----------------------------------------------------------------------------------------------------------
 def _hyper_upload(opt, hyper):
     from .hostio import upload
-    hyper.copy_(upload(torch.tensor([opt.hyper_values()], dtype=torch.float32), hyper.device).view(3))
+    world = dist.get_world_size() if dist_on() else 1              # Adam's 1/W of the data-parallel mean
+    hyper.copy_(upload(torch.tensor([opt.hyper_values(1.0 / world)], dtype=torch.float32), hyper.device).view(3))
 
 
 class GraphedGStep(object):
@@ -451,8 +470,10 @@ class GraphedGStep(object):
         import argparse
         from . import ops
         from .augment import SimCLRAugment
-        if not isinstance(P.augment_fn, SimCLRAugment) or dist_on():
-            raise NotImplementedError('GraphedGStep: single-process simclr-family pipeline')
+        if not isinstance(P.augment_fn, SimCLRAugment):
+            raise NotImplementedError('GraphedGStep: simclr-family pipeline')
+        self.dist = dist_on()      # data-parallel rank: SyncBN's statistics exchange and G's gradient all-reduce are captured
+        self.reducer = GradAllReducer(G.parameters()) if self.dist else None
         if not len(opt_G.state):
             raise RuntimeError('GraphedGStep: capture after the first eager generator step (Adam state)')
         self.P, self.G, self.D, self.opt, self.options, self.N = P, G, D, opt_G, options, N
@@ -477,6 +498,8 @@ class GraphedGStep(object):
         g_loss = self.Pg.train_fn["G"](self.Pg, self.D, self.options, None, gen)
         self.opt.zero_grad(set_to_none=True)
         g_loss.backward()
+        if self.reducer is not None:
+            self.reducer()
         self.opt.step_captured(self.hyper)
         return g_loss.detach()
 
@@ -497,8 +520,8 @@ class GraphedSG2GStep(object):
     projections on the augmented fakes, non-saturating loss) as one captured hipGraph; same contract as GraphedGStep."""
 
     def __init__(self, P, G, D, opt_G, options, N, H, W, style_mix=0.9):
-        if dist_on():
-            raise NotImplementedError('GraphedSG2GStep: single process')
+        self.dist = dist_on()
+        self.reducer = GradAllReducer(G.parameters()) if self.dist else None
         if not len(opt_G.state):
             raise RuntimeError('GraphedSG2GStep: capture after the first eager generator step (Adam state)')
         self.P, self.G, self.D, self.opt, self.options, self.N = P, G, D, opt_G, options, N
@@ -522,6 +545,8 @@ class GraphedSG2GStep(object):
         g_loss = _GanGLoss.apply(d_gen, 'nonsat')
         self.opt.zero_grad(set_to_none=True)
         g_loss.backward()
+        if self.reducer is not None:
+            self.reducer()
         self.opt.step_captured(self.hyper)
         return g_loss.detach()
 

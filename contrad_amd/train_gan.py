@@ -53,7 +53,7 @@ def parse_args(argv=None):
     parser.add_argument('--logdir', default=None, type=str)
     parser.add_argument('--seed', default=0, type=int)
     parser.add_argument('--graph', action='store_true',
-                        help='replay the D-step from a captured hipGraph (single process, simclr pipeline)')
+                        help='replay the D- and G-step from captured hipGraphs (simclr pipeline; with several ranks the RCCL collectives are captured too)')
     return parser.parse_args(argv)
 
 
@@ -266,9 +266,7 @@ def main(argv=None):
 
     graphed = None
     if P.graph:
-        if world > 1:
-            log('--graph: single process only (RCCL inside a captured graph is not validated here) -> eager')
-        elif P.mode != 'contrad':
+        if P.mode != 'contrad':
             log("--graph captures the ContraD critic iteration (--mode contrad), not '%s' -> eager" % P.mode)
         else:
             graphed = GraphedCritic()

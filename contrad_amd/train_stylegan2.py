@@ -78,7 +78,7 @@ def parse_args(argv=None, contrad_script=False):
     parser.add_argument('--logdir', default=None, type=str)
     parser.add_argument('--seed', default=0, type=int)
     parser.add_argument('--graph', action='store_true',
-                        help='replay the D-step from a captured hipGraph (single process; the ContraD script, whose '
+                        help='replay the D- and G-step from captured hipGraphs (collectives included; the ContraD script, whose '
                              'D-step draws its own fakes)')
     return parser.parse_args(argv)
 
@@ -402,9 +402,9 @@ def main(argv=None, contrad_script=False):
 
     graphed = None
     if P.graph:
-        if world > 1 or not contrad_script:
-            log('--graph: single-process train_stylegan2_contraD.py only (train_stylegan2.py feeds the D-step the '
-                'G-step\'s fakes) -> eager')
+        if not contrad_script:
+            log('--graph: train_stylegan2_contraD.py only (train_stylegan2.py feeds the D-step the G-step\'s fakes) '
+                '-> eager')
         elif P.mode != 'contrad':
             log("--graph captures the ContraD D-step (--mode contrad), not '%s' -> eager" % P.mode)
         else:

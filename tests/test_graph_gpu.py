@@ -196,3 +196,18 @@ def test_resume_with_graph_in_a_fresh_process(tmp_path, family):
                        + extra)
         runs.append(_state(logdir, names))
     _assert_same(runs[0], runs[1])
+
+
+def test_graph_with_collectives_on_one_rank_rccl():
+    """The multi-process launch path without Python on the critical step (train_gan.py:230-318 as one process per GPU):
+    the D-step (overlapped and flat gradient exchange), the G-step and the StyleGAN2 D-step are captured WITH their RCCL
+    collectives on a 1-rank group and must reproduce the eager steps bitwise (tests/dist_graph_worker.py, own process)."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', NCCL_DEBUG_FILE='/dev/stderr')
+    r = subprocess.run([sys.executable, os.path.join(here, 'dist_graph_worker.py'), str(port)], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0 and 'ALL OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

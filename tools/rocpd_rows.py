@@ -2,12 +2,14 @@
 instance, layer shape) with the rocprof launch count, the rocprof average duration, the algorithmic GFLOP per launch
 and the TF/s that follows -- so every `roofline` figure of a workload can be recomputed from profiles/ alone.
 
-usage: python tools/rocpd_rows.py <results.db> <shape_table.json> [--steps K]
+usage: python tools/rocpd_rows.py <results.db> <shape_table.json>
 
-The trace names only the template instance (igemm_lean_kernel<2,128,128>); the join key is (instance, workgroups of the
-launch): bench.py records the workgroup count of every conv call from the C ABI (contrad_conv2d_grid_blocks).  Shapes
-that share a key are merged into one row (their FLOPs and launch counts add up).  Dispatches of an instance whose grid
-matches no row of the table are listed as 'unmatched' (e.g. the generator forward's transposed convs)."""
+The trace names only the template instance (igemm_lean_kernel<2,128,128>).  bench.py records, for one eager step per
+section (plain step / lazy-R1 step), the ORDER of its conv-engine calls with kernel instance, layer shape and workgroup
+count (C ABI: contrad_conv2d_grid_blocks).  The trace is cut into steps at the optimizer kernel; a step whose igemm
+dispatches agree with a section's sequence in number, instance and workgroup count, one by one, is attributed dispatch
+by dispatch (eager steps and hipGraph replays alike -- a replay preserves the stream order).  Steps that agree with no
+section (the cold first step of a process, whose plans may differ) are reported as unmatched."""
 import json
 import re
 import sqlite3
@@ -25,7 +27,7 @@ def norm(k):
     return re.sub(r'\s+', '', k)
 
 
-def main(db_path, table_path, steps=None):
+def main(db_path, table_path):
     db = sqlite3.connect(db_path)
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
@@ -33,61 +35,67 @@ def main(db_path, table_path, steps=None):
         raise SystemExit('kernel trace without grid sizes: %s' % cols)
     rows = cur.execute("select name, start, end, grid_x, grid_y, grid_z, workgroup_x, workgroup_y, workgroup_z "
                        "from kernels order by start").fetchall()
-    disp = {}
+    # cut into steps at the Adam launch that ends a D-step
+    steps, cur_step = [], []
     for name, t0, t1, gx, gy, gz, wx, wy, wz in rows:
         k = norm(short(name))
-        if 'igemm' not in k:
-            continue
-        threads = gx * max(gy, 1) * max(gz, 1)
-        wg = max(wx, 1) * max(wy, 1) * max(wz, 1)
-        blocks = threads // wg if threads % wg == 0 and threads >= wg else threads     # (grid in work-items)
-        a = disp.setdefault((k, blocks), [0, 0.0])
-        a[0] += 1
-        a[1] += (t1 - t0) * 1e-3
+        if 'igemm' in k:
+            threads = gx * max(gy, 1) * max(gz, 1)
+            wg = max(wx, 1) * max(wy, 1) * max(wz, 1)
+            blocks = threads // wg if threads % wg == 0 and threads >= wg else threads     # (grid in work-items)
+            cur_step.append((k, blocks, (t1 - t0) * 1e-3))
+        elif k.startswith('adam_kernel') or k.startswith('adam_dev_kernel') or 'adam' in k:
+            if cur_step:
+                steps.append(cur_step)
+            cur_step = []
     table = json.load(open(table_path))
     print('# %s: rocprofv3 kernel trace joined with the shape table of `bench.py --config %s` (per-GPU batch %d)' % (
         db_path.split('/')[-1], table['config'], table['per_gpu_batch']))
     print('# TF/s = GFLOP per launch / rocprof average duration of the igemm dispatch alone (a WGRAD call\'s '
-          'wgrad_reduce_kernel is a separate trace row); FLOP rule: %s' % table['flop_rule'])
-    used = set()
+          'wgrad_reduce_kernel is a separate trace row); FLOP rule: %s; frac = TF/s / 157.3' % table['flop_rule'])
+    print('# %d steps in the trace (cut at the optimizer launch)' % len(steps))
+    matched_steps = set()
     for sec, d in table['sections'].items():
-        merged = {}
-        for r in d['rows']:
-            key = (norm(r['kernel']), r['grid_blocks'])
-            m = merged.setdefault(key, {'shapes': [], 'lps': 0.0, 'gflop_step': 0.0, 'bracket_us_step': 0.0})
-            m['shapes'].append(r['shape'])
-            m['lps'] += r['launches_per_step']
-            m['gflop_step'] += r['gflop_per_launch'] * r['launches_per_step']
-            m['bracket_us_step'] += r['bracket_us'] * r['launches_per_step']
-        print('\n== section %s (%d eager step(s) sampled for the table) ==' % (sec, d['steps_sampled']))
-        print('%-34s %8s %7s %9s %10s %10s %8s %8s  %s' % ('kernel', 'blocks', 'n/step', 'calls', 'avg_us', 'GFLOP/call',
-                                                          'TF/s', 'frac', 'shape(s) N,H,W,C,K,KH,KW,s,p'))
-        tot_f = tot_t = 0.0
-        for (k, blocks), m in sorted(merged.items(), key=lambda kv: -kv[1]['gflop_step']):
-            dsp = disp.get((k, blocks))
-            gpl = m['gflop_step'] / m['lps']
-            if dsp is None:
-                print('%-34s %8d %7.1f %9s %10s %10.3f %8s %8s  %s' % (k, blocks, m['lps'], '-', '-', gpl, '-', '-', m['shapes']))
+        seq = d.get('sequence') or []
+        keyseq = [(norm(q[0]), q[2]) for q in seq]
+        agg = {}
+        nmatch = 0
+        for si, st in enumerate(steps):
+            if len(st) != len(keyseq) or any((a[0], a[1]) != b for a, b in zip(st, keyseq)):
                 continue
-            used.add((k, blocks))
-            avg = dsp[1] / dsp[0]
-            tf = gpl / avg * 1e-3
-            tot_f += m['gflop_step']
-            tot_t += avg * m['lps']
-            print('%-34s %8d %7.1f %9d %10.2f %10.3f %8.1f %8.3f  %s' % (k, blocks, m['lps'], dsp[0], avg, gpl, tf, tf / 157.3,
-                                                                        ' '.join(','.join(map(str, s)) for s in m['shapes'])))
-        if tot_t > 0:
-            print('-- conv engine, this section: %.1f GFLOP per step in %.1f us of igemm dispatches -> %.1f TF/s (%.3f of 157.3)'
-                  % (tot_f, tot_t, tot_f / tot_t * 1e-3, tot_f / tot_t * 1e-3 / 157.3))
-    rest = [(k, v) for k, v in disp.items() if k not in used]
-    if rest:
-        print('\n== igemm dispatches not in the table (generator forward, first cold step, ...) ==')
-        for (k, blocks), (c, t) in sorted(rest, key=lambda kv: -kv[1][1]):
-            print('%-34s %8d calls %6d  avg_us %10.2f' % (k, blocks, c, t / c))
+            nmatch += 1
+            matched_steps.add(si)
+            for (k, blocks, us), q in zip(st, seq):
+                a = agg.setdefault((norm(q[0]), tuple(q[1]), q[2]), [0, 0.0, q[3]])
+                a[0] += 1
+                a[1] += us
+        print('\n== section %s: %d conv-engine launches per step, %d trace step(s) matched ==' % (sec, len(seq), nmatch))
+        if not nmatch:
+            continue
+        print('%-30s %-34s %7s %7s %8s %10s %11s %7s %6s' % ('kernel', 'shape N,H,W,C,K,KH,KW,s,p', 'blocks', 'n/step',
+                                                            'calls', 'avg_us', 'GFLOP/call', 'TF/s', 'frac'))
+        tot_f = tot_t = 0.0
+        per_kernel = {}
+        for (k, shape, blocks), (c, us, gf) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            avg = us / c
+            tf = gf / avg * 1e3 if avg > 0 else 0.0
+            tot_f += gf * c / nmatch
+            tot_t += us / nmatch
+            pk = per_kernel.setdefault(k, [0.0, 0.0, 0])
+            pk[0] += gf * c / nmatch; pk[1] += us / nmatch; pk[2] += c / nmatch
+            print('%-30s %-34s %7d %7.1f %8d %10.2f %11.4f %7.1f %6.3f' % (k, ','.join(map(str, shape)), blocks, c / nmatch, c,
+                                                                           avg, gf, tf, tf / 157.3))
+        print('-- per kernel instance (this section, per step):')
+        for k, (gf, us, n) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1]):
+            print('   %-30s %5.1f launches %9.1f us %10.2f GFLOP -> %6.1f TF/s (%.3f)' % (k, n, us, gf, gf / us * 1e3 if us else 0,
+                                                                                           gf / us * 1e3 / 157.3 if us else 0))
+        print('-- conv engine, %s: %.1f GFLOP per step in %.1f us of igemm dispatches -> %.1f TF/s (%.3f of 157.3)'
+              % (sec, tot_f, tot_t, tot_f / tot_t * 1e3, tot_f / tot_t * 1e3 / 157.3))
+    un = [i for i in range(len(steps)) if i not in matched_steps]
+    if un:
+        print('\n== %d trace step(s) matched no section (cold first step / generator-only segments): %s ==' % (
+            len(un), ', '.join('step %d: %d igemm launches' % (i, len(steps[i])) for i in un[:8])))
 
 
 if __name__ == '__main__':
-    st = None
-    if '--steps' in sys.argv:
-        st = int(sys.argv[sys.argv.index('--steps') + 1])
-    main(sys.argv[1], sys.argv[2], st)
+    main(sys.argv[1], sys.argv[2])
