@@ -43,6 +43,7 @@ struct IgemmArgs {
   const float* B;
   float* C;
   const float* bias;     // FWD
+  const float* addend;   // FWD: tensor of y's shape / ldy added AFTER the activation (residual merge), or NULL
   const float* act_ref;  // DGRAD
   float* bias_ws;        // WGRAD: [splits][Ncol] partial column sums of gy (bias gradient), or NULL
   contrad_conv_desc d;
@@ -656,6 +657,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(const IgemmArgs p) {
               if (p.bias) v += p.bias[c];
               v = (v > 0.f) ? v : v * p.slope;
               v *= p.gain;
+              if (p.addend) v += p.addend[(size_t)m * d.ldy + c];
               p.C[(size_t)m * d.ldy + c] = v;
             } else {
               p.C[((size_t)blockIdx.y * M + m) * Ncol + c] = v;
@@ -904,7 +906,7 @@ int wgrad_plan(const contrad_conv_desc* d, int* bm, int* bn, int* tiles_m, int* 
 // y[m][c] = gain * lrelu(sum_s ws[s][m][c] + bias[c])   (fixed summation order)
 __global__ void fwd_reduce_kernel(const float* __restrict__ ws, int splits, long long M, int Ncol,
                                   const float* __restrict__ bias, float slope, float gain, float* __restrict__ y,
-                                  int ldy) {
+                                  int ldy, const float* __restrict__ addend) {
   const long long total = M * Ncol;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
@@ -914,7 +916,9 @@ __global__ void fwd_reduce_kernel(const float* __restrict__ ws, int splits, long
     const int c = (int)(e - m * Ncol);
     if (bias) v += bias[c];
     v = (v > 0.f) ? v : v * slope;
-    y[m * ldy + c] = v * gain;
+    v *= gain;
+    if (addend) v += addend[m * ldy + c];
+    y[m * ldy + c] = v;
   }
 }
 
@@ -1017,15 +1021,15 @@ extern "C" long long contrad_conv2d_fwd_workspace_bytes(const contrad_conv_desc*
   return (long long)p.splits * d->N * d->Ho * d->Wo * d->K * (long long)sizeof(float);
 }
 
-extern "C" int contrad_conv2d_fwd(const contrad_conv_desc* d, const float* x, const float* wp,
-                                  const float* bias, float* y, float slope, float gain, float* workspace,
-                                  long long workspace_bytes, contrad_stream_t stream) {
+extern "C" int contrad_conv2d_fwd_add(const contrad_conv_desc* d, const float* x, const float* wp,
+                                      const float* bias, const float* addend, float* y, float slope, float gain,
+                                      float* workspace, long long workspace_bytes, contrad_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   CONTRAD_ARG(x && wp && y);
   if (vec_ok(d, MODE_FWD)) CONTRAD_ARG(aligned16(x, wp, y));
   IgemmArgs a{};
-  a.A = x; a.B = wp; a.C = y; a.bias = bias; a.d = *d; a.slope = slope; a.gain = gain;
+  a.A = x; a.B = wp; a.C = y; a.bias = bias; a.addend = addend; a.d = *d; a.slope = slope; a.gain = gain;
   const long long M = (long long)d->N * d->Ho * d->Wo;
   CONTRAD_ARG(M < (1ll << 31));
   a.M = (int)M; a.Ncol = d->K; a.Kg = d->KH * d->KW * d->C;
@@ -1043,9 +1047,15 @@ extern "C" int contrad_conv2d_fwd(const contrad_conv_desc* d, const float* x, co
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(fwd_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, workspace, p.splits, M,
-                     d->K, bias, slope, gain, y, d->ldy);
+                     d->K, bias, slope, gain, y, d->ldy, addend);
   CONTRAD_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int contrad_conv2d_fwd(const contrad_conv_desc* d, const float* x, const float* wp,
+                                  const float* bias, float* y, float slope, float gain, float* workspace,
+                                  long long workspace_bytes, contrad_stream_t stream) {
+  return contrad_conv2d_fwd_add(d, x, wp, bias, nullptr, y, slope, gain, workspace, workspace_bytes, stream);
 }
 
 extern "C" long long contrad_conv2d_dgrad_workspace_bytes(const contrad_conv_desc* d) {

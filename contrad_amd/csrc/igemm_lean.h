@@ -500,6 +500,10 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(outp, 0, rows_here * pitch * 4, 0x00020000);
     const int wave_row = __builtin_amdgcn_readfirstlane(wm * WM);
     const float g1 = p.gain, g0 = p.gain * p.slope;
+    // FWD residual merge: y = act(conv + bias) + addend, addend in y's own layout (same descriptor geometry)
+    const bool has_add = (MODE == MODE_FWD) && !slab && p.addend != nullptr;                 // uniform
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_add ? p.addend + (size_t)m0 * pitch : outp), 0, has_add ? rows_here * pitch * 4 : 0, 0x00020000);
     unsigned lanepart[TN];
     float bj[TN];
 #pragma unroll
@@ -519,6 +523,8 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
           if (MODE == MODE_FWD && !slab) {
             v += bj[j];
             v *= (v > 0.f) ? g1 : g0;
+            if (has_add)
+              v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, (int)(lanepart[j] + rowpart), 0, 0));
           }
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)(lanepart[j] + rowpart), 0, 0);
         }

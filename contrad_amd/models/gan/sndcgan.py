@@ -359,7 +359,9 @@ class _WB(nn.Module):
 
 class G_SNDCGAN(nn.Module):
     """Drop-in for the reference's G_SNDCGAN (sndcgan.py:13-66): same state-dict, sample_latent on the CPU
-    generator; forward under no_grad on the HIP path (the discriminator step's fake batch)."""
+    generator; forward under no_grad on the HIP path (the discriminator step's fake batch in train mode; in eval mode
+    the running statistics normalise -- sampling from a ``gen.pt`` checkpoint, train_gan.py:181); with gradients
+    enabled (generator step, train mode) the same network out of differentiable HIP nodes."""
 
     _CONVT = [(512, 256, 4, 2, 1), (256, 128, 4, 2, 1), (128, 64, 4, 2, 1), (64, 3, 3, 1, 1)]
 
@@ -413,6 +415,14 @@ class G_SNDCGAN(nn.Module):
         return self._packed
 
     def _bn(self, x2d, bn, conv_bias, out2d, perm_hw=1):
+        if not self.training:
+            # eval mode (sampling from a checkpoint, train_gan.py:181): the running statistics normalise.  Same apply
+            # kernel, fed with "one sample" whose sum / sum of squares reproduce mean = running_mean - conv bias (x2d is
+            # the transposed conv WITHOUT its bias) and biased variance = running_var
+            mean = bn.running_mean if conv_bias is None else bn.running_mean - conv_bias
+            stats = torch.stack([mean, bn.running_var + mean * mean]).contiguous()
+            ops.bn_relu_apply(x2d, out2d, stats, 1.0, bn.weight, bn.bias, bn.eps, perm_hw)
+            return
         stats = ops.colstats(x2d, with_sq=True)
         count = float(x2d.shape[0])
         if _sync_on(self.sync_bn):
@@ -460,10 +470,6 @@ class G_SNDCGAN(nn.Module):
             if not self.training:
                 raise NotImplementedError('eval-mode BatchNorm (running statistics) is not on the training path')
             return self._forward_with_grad(z)
-        if not self.training:
-            raise NotImplementedError('eval-mode BatchNorm (running statistics) is not on the D-step path')
-        if not z.is_cuda:
-            raise RuntimeError('contrad_amd.G_SNDCGAN runs on the MI355X HIP path only (no CPU fallback)')
         wps = self._weights()
         N = z.shape[0]
         hb, wb = self.s_hb, self.s_wb

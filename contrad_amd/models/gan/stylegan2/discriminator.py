@@ -125,8 +125,8 @@ class _TrunkFn(torch.autograd.Function):
             y2 = ops.conv2d_fwd(ob, wp2, b2, co, 3, 3, 2, 0, _SLOPE, 1.0)         # gain sqrt2 * (1/sqrt2 of the merge)
             q0, q1 = blk.skip[0].pad
             sb = ops.upfirdn2d(x, kernel, 1, 2, (q0, q1, q0, q1))
-            sk = ops.conv2d_fwd(sb, wps, None, co, 1, 1, 1, 0)                    # skip weights carry the 1/sqrt2
-            xn = ops.lincomb(y2, sk, 1.0, 1.0)
+            # skip weights carry the 1/sqrt2; the merge y2 + skip is the skip conv's epilogue (no lincomb pass)
+            xn = ops.conv2d_fwd(sb, wps, None, co, 1, 1, 1, 0, addend=y2)
             saved += [x, o, ob, y2, sb]
             geo.append((ci, co, (p0, p1), (q0, q1)))
             x = xn
@@ -145,7 +145,7 @@ class _TrunkFn(torch.autograd.Function):
         saved = t[2 + ctx.n_wb:]
         r0 = saved[0]
         nb = len(ctx.geo)
-        gk = torch.flip(kernel, [0, 1]).contiguous()
+        gk = A.flipped_kernel(kernel)
         grads = [None] * ctx.n_wb
         g = g.contiguous()
         gm = None                                   # g * act'(y2 of the current block)
@@ -242,8 +242,10 @@ class ResidualDiscriminatorP(BaseDiscriminator):
         return list(torch.split(out, sizes, dim=0))
 
     # ---- weight packing plan -------------------------------------------------------------------------
-    def _pack(self, fused=False):
-        """``fused``: layout for _TrunkFn -- the skip weights carry the residual merge's 1/sqrt2."""
+    def _pack(self, fused=True):
+        """``fused`` (both graph constructions use it): the skip weights carry the residual merge's 1/sqrt2 -- together
+        with conv2's activation gain sqrt2 / sqrt2 = 1 the merge (out + skip) / sqrt2 (discriminator.py:72-74) becomes a
+        plain sum, whose backward is the identity on both branches (no scaling pass, forward or backward)."""
         ws, entries, groups = [], [], []
 
         def add(w, K, C, T, scale, group=None, col=0):
@@ -303,7 +305,6 @@ class ResidualDiscriminatorP(BaseDiscriminator):
         x = A.RgbConvBiasActFn.apply(images, wp[idx['rgb']], rgb[1].bias, K0, (1, 2.0, -1.0), _SLOPE, _GAIN)
         if rec is not None:
             rec.append(x)
-        inv = 1.0 / math.sqrt(2.0)
         for bi, blk in enumerate(list(self.layers)[1:]):
             ci, co = blk.cin, blk.cout
             o = A.ConvBiasActFn.apply(x, wp[idx[(bi, 'conv1')]], blk.conv1[1].bias, (ci, 3, 3, 1, 1), _SLOPE, _GAIN)
@@ -311,7 +312,8 @@ class ResidualDiscriminatorP(BaseDiscriminator):
                 rec.append(o)
             p0, p1 = blk.conv2[0].pad
             o = A.UpFirDn2dFn.apply(o, blk.conv2[0].kernel, 1, 1, (p0, p1, p0, p1))
-            o = A.ConvBiasActFn.apply(o, wp[idx[(bi, 'conv2')]], blk.conv2[2].bias, (co, 3, 3, 2, 0), _SLOPE, _GAIN)
+            # gain sqrt2 * (1/sqrt2 of the merge) = 1; the packed skip weights carry the other 1/sqrt2 (_pack)
+            o = A.ConvBiasActFn.apply(o, wp[idx[(bi, 'conv2')]], blk.conv2[2].bias, (co, 3, 3, 2, 0), _SLOPE, 1.0)
             if rec is not None:
                 rec.append(o)
             p0, p1 = blk.skip[0].pad
@@ -320,7 +322,7 @@ class ResidualDiscriminatorP(BaseDiscriminator):
             # the outputs, a quarter of the bytes written and re-read) and the conv runs at stride 1 -- the same sums.
             s = A.UpFirDn2dFn.apply(x, blk.skip[0].kernel, 1, 2, (p0, p1, p0, p1))
             s = A.Conv2dFn.apply(s, wp[idx[(bi, 'skip')]], (co, 1, 1, 1, 0))
-            x = A.LinCombFn.apply(o, s, inv, inv)
+            x = A.LinCombFn.apply(o, s, 1.0, 1.0)
         x = minibatch_stddev_batches(x, self._batch_splits)
         x = A.ConvBiasActFn.apply(x, wp[idx['last']], self.last_conv[1].bias,
                                   (self.last_conv[0].weight.shape[0], 3, 3, 1, 1), _SLOPE, _GAIN)
@@ -334,7 +336,7 @@ class ResidualDiscriminatorP(BaseDiscriminator):
         # constant images (every ContraD discriminator call): one fused first-order node; images that need a gradient
         # (R1's create_graph, the generator step): the any-order node family
         fused = self.fuse_trunk and not (inputs.requires_grad and torch.is_grad_enabled()) and len(self.layers) > 1
-        wp, idx = self._pack(fused)
+        wp, idx = self._pack(True)
         images = inputs.contiguous().float()
         rec = [] if getattr(self, '_record_activations', False) else None     # test hook (linear regions used)
         trunk = self._trunk_fused if fused else self._trunk

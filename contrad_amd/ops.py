@@ -122,9 +122,9 @@ def unpack_weight(wp, K, C, KH, KW):
 # --------------------------------------------------------------------------------------------------
 # convolution engine
 # --------------------------------------------------------------------------------------------------
-def conv2d_fwd(x, wp, bias, K, KH, KW, stride, pad, slope=1.0, gain=1.0, out=None):
-    """x: (N,H,W,C) NHWC; wp packed (KH*KW*C, ldw); returns y (N,Ho,Wo,K)."""
-    _chk(x, 'x'); _chk(wp, 'wp'); _chk(bias, 'bias')
+def conv2d_fwd(x, wp, bias, K, KH, KW, stride, pad, slope=1.0, gain=1.0, out=None, addend=None):
+    """x: (N,H,W,C) NHWC; wp packed (KH*KW*C, ldw); returns y (N,Ho,Wo,K) = gain * lrelu(conv + bias) [+ addend]."""
+    _chk(x, 'x'); _chk(wp, 'wp'); _chk(bias, 'bias'); _chk(addend, 'addend')
     N, H, W, C = x.shape
     Ho, Wo = out_size(H, KH, stride, pad), out_size(W, KW, stride, pad)
     if out is None:
@@ -133,7 +133,9 @@ def conv2d_fwd(x, wp, bias, K, KH, KW, stride, pad, slope=1.0, gain=1.0, out=Non
     d = make_desc(N, H, W, C, K, KH, KW, stride, pad, _ld(x), _ld(out), wp.stride(0))
     nbytes = lib().raw('contrad_conv2d_fwd_workspace_bytes')(ctypes.byref(d))
     ws = _workspace(nbytes, x.device) if nbytes > 0 else None
-    _conv_call(0, d, 'contrad_conv2d_fwd', ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(out),
+    if addend is not None and (tuple(addend.shape) != tuple(out.shape) or _ld(addend) != _ld(out)):
+        raise RuntimeError('contrad_hip: addend must match y in shape and leading dimension')
+    _conv_call(0, d, 'contrad_conv2d_fwd_add', ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(addend), _p(out),
                float(slope), float(gain), _p(ws), nbytes, _stream())
     return out
 

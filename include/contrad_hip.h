@@ -52,6 +52,12 @@ typedef struct {
 int contrad_conv2d_fwd(const contrad_conv_desc* d, const float* x, const float* wp, const float* bias,
                        float* y, float slope, float gain, float* workspace, long long workspace_bytes,
                        contrad_stream_t stream);
+/* Same with a residual addend: y = gain * lrelu_slope(conv + bias) + addend, `addend` (may be NULL) a tensor of y's
+ * shape and leading dimension (may alias nothing).  The ResBlock merge (out + skip) of the StyleGAN2 discriminator
+ * (models/gan/stylegan2/discriminator.py:72-74) is the epilogue of its 1x1 skip convolution this way. */
+int contrad_conv2d_fwd_add(const contrad_conv_desc* d, const float* x, const float* wp, const float* bias,
+                           const float* addend, float* y, float slope, float gain, float* workspace,
+                           long long workspace_bytes, contrad_stream_t stream);
 /* Scratch for the split-K partial slabs of small-M / deep-K shapes (the merged head GEMM); 0 for most shapes, in
  * which case workspace may be NULL. */
 long long contrad_conv2d_fwd_workspace_bytes(const contrad_conv_desc* d);

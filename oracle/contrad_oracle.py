@@ -517,25 +517,26 @@ def sndcgan_g_param_shapes(image_hw=32, nz=128):
     return shapes
 
 
-def _bn_train(sd, prefix, x, momentum=0.1, eps=1e-5):
+def _bn_train(sd, prefix, x, momentum=0.1, eps=1e-5, training=True):
     """nn.BatchNorm2d in train mode: biased batch variance to normalise, running stats updated with
-    the unbiased one (torch semantics; G stays in .train() during the D-step, train_gan.py:142)."""
+    the unbiased one (torch semantics; G stays in .train() during the D-step, train_gan.py:142).
+    ``training=False``: eval mode, the running statistics normalise (sampling from a checkpoint, train_gan.py:181)."""
     return F.batch_norm(x, sd[prefix + '.running_mean'], sd[prefix + '.running_var'],
-                        sd[prefix + '.weight'], sd[prefix + '.bias'], True, momentum, eps)
+                        sd[prefix + '.weight'], sd[prefix + '.bias'], training, momentum, eps)
 
 
-def sndcgan_g_forward(sd, z, image_hw=32):
-    """G_SNDCGAN.forward (sndcgan.py:41-48)."""
+def sndcgan_g_forward(sd, z, image_hw=32, training=True):
+    """G_SNDCGAN.forward (sndcgan.py:41-48); ``training=False`` = G.eval()."""
     hb = image_hw // 8
     h = F.linear(z, sd['linear.weight'], sd['linear.bias'])
     h = h.view(h.size(0), h.size(1), 1, 1)
-    h = F.relu(_bn_train(sd, 'norm_init', h))
+    h = F.relu(_bn_train(sd, 'norm_init', h, training=training))
     h = h.view(-1, 512, hb, hb)
     for j, (ci, co, k, s, p) in enumerate(SNDCGAN_G_CONVT):
         h = F.conv_transpose2d(h, sd['main.%d.weight' % (3 * j)], sd['main.%d.bias' % (3 * j)],
                                stride=s, padding=p)
         if j < 3:
-            h = F.relu(_bn_train(sd, 'main.%d' % (3 * j + 1), h))
+            h = F.relu(_bn_train(sd, 'main.%d' % (3 * j + 1), h, training=training))
     return 0.5 * torch.tanh(h) + 0.5
 
 

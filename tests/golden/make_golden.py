@@ -319,6 +319,27 @@ def gen_sndcgan():
 
 
 # ------------------------------------------------------------------------------------------------
+def gen_sndcgan_eval():
+    """G_SNDCGAN in eval mode (running statistics; what ``gen.pt`` is sampled with, train_gan.py:181, sndcgan.py:41-52)."""
+    from models.gan import get_architecture
+    G, _D = get_architecture('sndcgan', (32, 32, 3))
+    gshapes = O.sndcgan_g_param_shapes()
+    gsd = O.det_fill(gshapes, seed=4321)
+    gfull = dict(G.state_dict())
+    gfull.update({k: v.clone() for k, v in gsd.items()})
+    G.load_state_dict(gfull)
+    G.eval()
+    z = torch.rand(5, 128, generator=torch.Generator().manual_seed(98)) * 2 - 1
+    with torch.no_grad():
+        img = G(z)
+        check(O.sndcgan_g_forward({k: v.clone() for k, v in gsd.items()}, z, training=False), img, 1e-6, 'G eval forward')
+    for k, v in G.state_dict().items():                      # eval mode leaves every buffer alone
+        if k in gsd:
+            assert torch.equal(v, gsd[k]), k
+    save('sndcgan_eval', z=z, img=img, wseed=4321)
+
+
+# ------------------------------------------------------------------------------------------------
 def gen_sndcgan_gstep():
     """Generator step (train_gan.py:170-177): G(z) with grad -> loss_G_fn = softplus(-D(augment(G(z)))) -> G grads."""
     import augment as A
@@ -911,7 +932,7 @@ def gen_snresnet():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['losses', 'augment', 'sndcgan', 'sndcgan_gstep', 'adam', 'stylegan2', 'stylegan2_g', 'stylegan2_512', 'stylegan2_r1', 'stylegan2_gstep', 'checkpoint_manifest', 'snresnet']
+    which = sys.argv[1:] or ['losses', 'augment', 'sndcgan', 'sndcgan_eval', 'sndcgan_gstep', 'adam', 'stylegan2', 'stylegan2_g', 'stylegan2_512', 'stylegan2_r1', 'stylegan2_gstep', 'checkpoint_manifest', 'snresnet']
     for w in which:
         globals()['gen_' + w]()
     print('golden vectors OK')

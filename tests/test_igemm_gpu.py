@@ -73,6 +73,14 @@ def test_conv_fwd_dgrad_wgrad(case):
     wp = ops.pack_weight(w).to(dev)
     y = ops.conv2d_fwd(x_nhwc, wp, b.to(dev), K, k, k, s, p, slope, gain)
     assert rel(y.permute(0, 3, 1, 2).cpu(), y_ref.detach()) < TOL
+    # residual addend in the epilogue (contrad_conv2d_fwd_add): y = gain * lrelu(conv + bias) + addend, on whichever
+    # path the shape takes (lean loop, general float4 / scalar kernel, split-K reduce); the plain result stays bitwise
+    addend = torch.randn(y_ref.shape, generator=g)
+    ya = ops.conv2d_fwd(x_nhwc, wp, b.to(dev), K, k, k, s, p, slope, gain,
+                        addend=addend.permute(0, 2, 3, 1).contiguous().to(dev))
+    assert rel(ya.permute(0, 3, 1, 2).cpu(), y_ref.detach() + addend) < TOL
+    assert torch.equal((ya - addend.permute(0, 2, 3, 1).to(dev)).sub(y).abs().max() < 1e-5 * y.abs().max(),
+                       torch.tensor(True, device=dev))
 
     gy_nhwc = gy.permute(0, 2, 3, 1).contiguous().to(dev)
     dx = ops.conv2d_dgrad(gy_nhwc, wp, (N, H, W, C), k, k, s, p)

@@ -294,3 +294,25 @@ def test_full_size_step_is_bitwise_deterministic():
         assert len(a[k]) == len(b[k]) and all(torch.equal(x, y) for x, y in zip(a[k], b[k]))
     assert torch.isfinite(a[0]).item() and all(torch.isfinite(g).all().item() for g in a[2])
     assert abs(a[1].item() - 2 * np.log(2)) < 0.05        # sigmoid(0) on both sides: softplus(0) * 2
+
+
+def test_generator_eval_mode_forward_matches_reference(golden):
+    """G_SNDCGAN.eval() (running statistics, sndcgan.py:41-52 / train_gan.py:181: what a round-tripped gen.pt is sampled
+    with) against the imported reference; eval mode leaves every buffer untouched."""
+    g = golden('sndcgan_eval')
+    G, _ = build()
+    gsd = O.det_fill(O.sndcgan_g_param_shapes(), seed=int(g['wseed']))
+    full = dict(G.state_dict())
+    full.update({k: v.clone() for k, v in gsd.items()})
+    G.load_state_dict(full)
+    G = G.to(DEV).eval()
+    before = {k: v.clone() for k, v in G.state_dict().items()}
+    with torch.no_grad():
+        img = G(torch.from_numpy(g['z']).to(DEV))
+    assert rel(img, g['img']) < TOL
+    for k, v in G.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    G.train()
+    with torch.no_grad():
+        img_t = G(torch.from_numpy(g['z']).to(DEV))
+    assert rel(img_t, g['img']) > 1e-2                       # (batch statistics give a different image)
