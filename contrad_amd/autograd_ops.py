@@ -26,6 +26,28 @@ def _cont(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# ``input_grad_only()``: inside it, the backward of every conv / RGB node of this family returns the gradient w.r.t. its
+# ACTIVATION input only.  A custom Function cannot see which of its input gradients an ``autograd.grad(outputs, inputs)``
+# call actually asked for (``ctx.needs_input_grad`` is static), so the first backward of the R1 penalty --
+# ``autograd.grad(d_real.sum(), images, create_graph=True)``, train_stylegan2.py:108-111 -- also computed every weight
+# and bias gradient of the discriminator and threw them away: 17 weight-gradient GEMMs + their split-K reduces per
+# StyleGAN2-32 step.  engine.r1_loss wraps exactly that call.  (A module global, not a thread-local: the backward runs
+# on the autograd engine's device thread while the caller blocks in autograd.grad.)
+_INPUT_GRAD_ONLY = False
+
+
+class input_grad_only(object):
+    def __enter__(self):
+        global _INPUT_GRAD_ONLY
+        self.saved, _INPUT_GRAD_ONLY = _INPUT_GRAD_ONLY, True
+        return self
+
+    def __exit__(self, *exc):
+        global _INPUT_GRAD_ONLY
+        _INPUT_GRAD_ONLY = self.saved
+        return False
+
+
 _CONSTS = {}
 
 
@@ -63,7 +85,8 @@ class Conv2dFn(Function):
     def backward(ctx, gy):
         x, wp = ctx.saved_tensors
         gx = ConvDgradFn.apply(gy, wp, tuple(x.shape), ctx.geom) if ctx.needs_input_grad[0] else None
-        gw = ConvWgradFn.apply(x, gy, ctx.geom, tuple(wp.shape)) if ctx.needs_input_grad[1] else None
+        gw = ConvWgradFn.apply(x, gy, ctx.geom, tuple(wp.shape)) if (ctx.needs_input_grad[1]
+                                                                      and not _INPUT_GRAD_ONLY) else None
         return gx, gw, None
 
 
@@ -205,7 +228,9 @@ class ConvBiasActFn(Function):
         g_pre = gy if (slope == 1.0 and gain == 1.0) else ActBwdFn.apply(gy, y, slope, gain)
         gx = ConvDgradFn.apply(g_pre, wp, tuple(x.shape), geom) if ctx.needs_input_grad[0] else None
         gw = gb = None
-        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and _fused_bias_ok(x, geom[0]):
+        if _INPUT_GRAD_ONLY:
+            pass
+        elif ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and _fused_bias_ok(x, geom[0]):
             gw, gb = ConvWgradBiasFn.apply(x, g_pre, geom, tuple(wp.shape))
         else:
             gw = ConvWgradFn.apply(x, g_pre, geom, tuple(wp.shape)) if ctx.needs_input_grad[1] else None
@@ -230,7 +255,8 @@ class RgbConvFn(Function):
         img, wp = ctx.saved_tensors
         K, (k, a, b) = ctx.cfg
         g_img = RgbDgradFn.apply(gy, wp, img.shape[1], (k, a)) if ctx.needs_input_grad[0] else None
-        g_wp = RgbWgradFn.apply(img, gy, (k, a, b), tuple(wp.shape)) if ctx.needs_input_grad[1] else None
+        g_wp = RgbWgradFn.apply(img, gy, (k, a, b), tuple(wp.shape)) if (ctx.needs_input_grad[1]
+                                                                          and not _INPUT_GRAD_ONLY) else None
         return g_img, g_wp, None, None
 
 
@@ -293,8 +319,9 @@ class RgbConvBiasActFn(Function):
         K, (k, a, b), slope, gain = ctx.cfg
         g_pre = ActBwdFn.apply(gy, y, slope, gain)
         g_img = RgbDgradFn.apply(g_pre, wp, img.shape[1], (k, a)) if ctx.needs_input_grad[0] else None
-        g_wp = RgbWgradFn.apply(img, g_pre, (k, a, b), tuple(wp.shape)) if ctx.needs_input_grad[1] else None
-        g_b = ColSumFn.apply(g_pre) if ctx.needs_input_grad[2] else None
+        only_in = _INPUT_GRAD_ONLY
+        g_wp = RgbWgradFn.apply(img, g_pre, (k, a, b), tuple(wp.shape)) if (ctx.needs_input_grad[1] and not only_in) else None
+        g_b = ColSumFn.apply(g_pre) if (ctx.needs_input_grad[2] and not only_in) else None
         return g_img, g_wp, g_b, None, None, None, None
 
 

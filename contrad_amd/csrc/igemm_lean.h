@@ -366,6 +366,12 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
   }
   __syncthreads();
 
+  // does this wave hold any row of the matrix at all (wave-uniform)?  Only the narrow WGRAD instances test it: the
+  // 128 x 128 tiles sit at the 128-VGPR limit of 4 waves per SIMD and extra control flow around the accumulators made
+  // the register allocator spill (per-32-row-group tests: 500 ... 2200 spilled values, -Rpass-analysis=kernel-resource-usage)
+  constexpr bool RAGGED_SKIP = (MODE == MODE_WGRAD) && BN <= 64;
+  const bool wave_on = !RAGGED_SKIP || __builtin_amdgcn_readfirstlane((m0 + wm * WM < M) ? 1 : 0) != 0;
+
   // Main loop: 8 k-steps of TM x TN MFMAs per tile; the next tile's global loads ride between the first k-steps,
   // its LDS stores (other buffer) between the last ones; fragments of the whole tile are fetched at the top.
   constexpr int KS = BK / 2;
@@ -424,11 +430,15 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
       if (ks == B_LD0 + PB - 1) end_tile();
 #endif
       __builtin_amdgcn_sched_barrier(0);
+      // ragged last M-tile (WGRAD with Kg = 288 = 2.25 x 128: the 32-channel 3x3 layers): a wave whose rows all lie
+      // past M holds zero fills only -- its MFMAs are skipped, the matrix pipe goes to the other blocks' waves on this SIMD
+      if (!RAGGED_SKIP || wave_on) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int jj = 0; jj < TN; ++jj)
-          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][i][j], fb[h][jj][j], acc[i][jj], 0, 0, 0);
+          for (int jj = 0; jj < TN; ++jj)
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][i][j], fb[h][jj][j], acc[i][jj], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #if !defined(LEAN_ABLATE_STORES)
       if (ks >= A_ST0 && ks < A_ST0 + PA) store_a_piece(nxt, ks - A_ST0);

@@ -131,10 +131,12 @@ def d_step(P, G, D, opt_D, options, images, reducer=None):
 def r1_loss(D, images, augment_fn):
     """r1_loss (train_stylegan2.py:106-113): mean_n sum_chw (d D(aug(x)) / d aug(x))^2, differentiable in D's
     parameters (double backward through the HIP op family of contrad_amd.autograd_ops)."""
+    from . import autograd_ops as A
     images_aug = augment_fn(images).detach()
     images_aug.requires_grad = True
     d_real = D(images_aug)
-    grad_real, = torch.autograd.grad(outputs=d_real.sum(), inputs=images_aug, create_graph=True, retain_graph=True)
+    with A.input_grad_only():        # this backward is asked for d / d images only: skip the parameter gradients
+        grad_real, = torch.autograd.grad(outputs=d_real.sum(), inputs=images_aug, create_graph=True, retain_graph=True)
     return grad_real.pow(2).reshape(grad_real.shape[0], -1).sum(1).mean()
 
 

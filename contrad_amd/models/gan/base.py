@@ -96,7 +96,11 @@ class BaseDiscriminator(nn.Module):
                 finetuning=False, sg_linear=False):
         if y is not None:
             raise NotImplementedError('class-conditional heads (n_classes > 1) are not used by get_architecture')
-        output, project, project2, features = self._run(inputs, sg_linear, finetuning, penultimate)
+        if getattr(self, '_lazy_projections', False):       # (networks whose heads are separate launches)
+            output, project, project2, features = self._run(inputs, sg_linear, finetuning, penultimate,
+                                                            want_proj=(projection or projection2))
+        else:
+            output, project, project2, features = self._run(inputs, sg_linear, finetuning, penultimate)
         aux = {}
         if penultimate:
             aux['penultimate'] = features

@@ -330,7 +330,13 @@ class ResidualDiscriminatorP(BaseDiscriminator):
             rec.append(x)
         return x                                                                     # (B,4,4,512) NHWC
 
-    def _run(self, inputs, sg_linear, finetuning, want_features):
+    # BaseDiscriminator.forward: call _run(..., want_proj=projection or projection2).  The reference evaluates both
+    # projection heads in every call and adds 0 * their means to the logits (base.py:139-141, so that DDP sees every
+    # parameter used); here a call that does not ask for them (R1's D(x), the generator step of train_stylegan2.py)
+    # skips their GEMMs -- the parameters then receive no gradient from that call instead of an exact zero.
+    _lazy_projections = True
+
+    def _run(self, inputs, sg_linear, finetuning, want_features, want_proj=True):
         if not inputs.is_cuda:
             raise RuntimeError('contrad_amd.ResidualDiscriminatorP runs on the MI355X HIP path only (no CPU fallback)')
         # constant images (every ContraD discriminator call): one fused first-order node; images that need a gradient
@@ -352,13 +358,15 @@ class ResidualDiscriminatorP(BaseDiscriminator):
         feat_d = feat.detach() if sg_linear else feat
         g1 = (1, 1, 1, 1, 0)
         h_l = A.ConvBiasActFn.apply(feat_d, wp[idx['l1']], self.linear.l1.bias, (dh,) + g1[1:], _HEAD_SLOPE, 1.0)
-        bias_pq = torch.cat([self.projection[0].bias, self.projection2[0].bias])
-        h_pq = A.ConvBiasActFn.apply(feat, wp[idx['p0q0']], bias_pq, (2 * dh,) + g1[1:], _HEAD_SLOPE, 1.0)
         out = A.ConvBiasActFn.apply(h_l, wp[idx['l2']], self.linear.l2.bias, (1,) + g1[1:], 1.0, 1.0).view(B, 1)
-        proj = A.ConvBiasActFn.apply(h_pq[..., :dh], wp[idx['p2']], self.projection[2].bias, (dp,) + g1[1:], 1.0,
-                                     1.0).view(B, dp)
-        proj2 = A.ConvBiasActFn.apply(h_pq[..., dh:], wp[idx['q2']], self.projection2[2].bias, (dp,) + g1[1:], 1.0,
-                                      1.0).view(B, dp)
+        h_pq = proj = proj2 = None
+        if want_proj or rec is not None:
+            bias_pq = torch.cat([self.projection[0].bias, self.projection2[0].bias])
+            h_pq = A.ConvBiasActFn.apply(feat, wp[idx['p0q0']], bias_pq, (2 * dh,) + g1[1:], _HEAD_SLOPE, 1.0)
+            proj = A.ConvBiasActFn.apply(h_pq[..., :dh], wp[idx['p2']], self.projection[2].bias, (dp,) + g1[1:], 1.0,
+                                         1.0).view(B, dp)
+            proj2 = A.ConvBiasActFn.apply(h_pq[..., dh:], wp[idx['q2']], self.projection2[2].bias, (dp,) + g1[1:], 1.0,
+                                          1.0).view(B, dp)
         if rec is not None:
             if not hasattr(self, '_recorded'):
                 self._recorded = []

@@ -96,7 +96,7 @@ def test_r1_gradient_alone_against_reference(golden, size):
             ref = float(g[k])
             e = abs(grads[name].norm().item() - ref) / ref
             report.append(('norm', name, e))
-            bad += [(name, e)] if not e < TOL else []
+            bad += [(name, e)] if not e < tol_of(name) else []
         elif kind == 'r1grad':                                   # whole tensor (every bias, the small weights)
             e = l2(grads[name], g[k])
             report.append(('l2', name, e))
