@@ -54,7 +54,7 @@ CONFIGS = {
     'sg2_512': dict(arch='stylegan2_512', size=512, batch=16, batch_is_global=False, aug='simclr_hq',
                     gin=('gan', 'stylegan2', 'afhq_dog_style64.gin'), flop_per_image=388.7e9 + 235e9 / 16,
                     flop_plain=388.7e9, flop_r1=235e9,
-                    d_reg_every=16, lbd_r1=0.5, steps=16, warmup=2,
+                    d_reg_every=16, lbd_r1=0.5, steps=16, warmup=3,
                     workload="StyleGAN2_512 (channel multiplier 1) + ContraD D-step, AFHQ-shaped 512x512, batch %d per "
                              "GPU, simclr_hq aug (crop 0.08-1, jitter 0.8/0.8/0.8/0.2, gaussian blur k=51), lazy R1 every "
                              "16th step (lbd_r1 0.5), separate N and 2N discriminator calls "
@@ -506,7 +506,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=None, help='timed steps (default: 20 / 10 / 16 for c10_b512 / sg2_32 / sg2_512)')
-    ap.add_argument('--warmup', type=int, default=None, help='untimed warm-up steps (default: 5 / 3 / 2)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed warm-up steps (default: 5 / 3 / 3)')
     ap.add_argument('--config', default='all', choices=sorted(CONFIGS) + ['all'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-g-step', action='store_true', help='skip the separately reported generator-step timing')

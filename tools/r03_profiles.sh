@@ -1,16 +1,13 @@
-# Round-3 evidence run (on the GPU box, via gpurun): default bench (all configs + CPU baselines), then per config a
+# Round-3 evidence run (on the GPU box, via gpurun): per config a
 # rocprofv3 kernel trace of `bench.py --config <c> --no-g-step` (D-step launches only: the generator-step side
 # measurement would mix other shapes into the same kernel names) joined with the bench's own shape table
 # (tools/rocpd_rows.py -> one row per (kernel, layer shape) with GFLOP per launch), and the PMC passes (own runs,
-# --kernel-trace only beside the counters).  Usage: PMC_CONFIGS="c10_b512 sg2_32 sg2_512" bash tools/r03_profiles.sh [tag]
+# --kernel-trace only beside the counters), then the default bench (all configs + CPU baselines).  Usage: PMC_CONFIGS="c10_b512 sg2_32 sg2_512" bash tools/r03_profiles.sh [tag]
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r03}
 O=$R/gpurun_out/${TAG}p
 rm -rf $O; mkdir -p $O
 cd $R
-if [ -z "$SKIP_BENCH" ]; then
-  timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?"
-fi
 cd /tmp && export TMPDIR=/tmp
 for c in ${KT_CONFIGS-c10_b512 sg2_32 sg2_512}; do
   case $c in c10_b512) S="--steps 5 --warmup 3";; sg2_32) S="--steps 5 --warmup 3";; sg2_512) S="--steps 16 --warmup 2";; esac
@@ -32,6 +29,9 @@ for c in ${PMC_CONFIGS-c10_b512 sg2_32 sg2_512}; do       # PMC_CONFIGS="" skips
   rm -f $P/*.db
 done
 cd $R
+if [ -z "$SKIP_BENCH" ]; then     # after the counter passes: its roofline.traffic then comes from THIS run's PMC summaries
+  timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?"
+fi
 mkdir -p $O/profiles
 for c in ${KT_CONFIGS-c10_b512 sg2_32 sg2_512}; do
   cp $O/${c}_kernel_trace.txt $O/profiles/${TAG}_${c}_n1_kernel_trace.txt
