@@ -297,10 +297,10 @@ def run_config(name, args, world, rank, dev, multi):
     opt_D = FusedAdam(D.parameters(), lr=opt['lr'], betas=tuple(opt['beta']))
     reducer = None
     if multi:
-        if os.environ.get('CONTRAD_NO_OVERLAP') or not hasattr(D, 'enable_grad_overlap'):
-            reducer = GradAllReducer(D.parameters())          # flat collectives after the backward
-        else:
-            D.enable_grad_overlap(OverlappedGradReducer())      # per-layer collectives hidden behind the backward
+        from contrad_amd.engine import setup_grad_exchange
+        # per-layer collectives hidden behind the backward (D_SNDCGAN: everything; ResidualDiscriminatorP: the packed
+        # weight gradients, the biases in one packed collective afterwards); CONTRAD_NO_OVERLAP: flat collectives after it
+        reducer = setup_grad_exchange(D, overlap=not os.environ.get('CONTRAD_NO_OVERLAP'))
     set_grad(G, False); set_grad(D, True)
     images = torch.rand(n_local, 3, size, size, device=dev)     # synthetic batch, resident in HBM
 

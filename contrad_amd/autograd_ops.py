@@ -210,15 +210,18 @@ class ColSumFn(Function):
 
 class ConvBiasActFn(Function):
     """y = gain * lrelu_slope(conv(x, wp) + bias): conv + FusedLeakyReLU (stylegan2/layers.py:174-198,
-    op/fused_act.py:74-92) / nn.Linear + LeakyReLU in ONE kernel (bias + activation in the GEMM epilogue)."""
+    op/fused_act.py:74-92) / nn.Linear + LeakyReLU in ONE kernel (bias + activation in the GEMM epilogue).
+    Optional 7th argument ``xch = (comm, meta, group)``: in a first-order backward the packed weight gradient is
+    all-reduced the moment it is produced (data-parallel exchange overlapped with the backward, PackWeightsFn.backward)."""
 
     @staticmethod
-    def forward(ctx, x, wp, bias, geom, slope, gain):
+    def forward(ctx, x, wp, bias, geom, slope, gain, xch=None):
         K, KH, KW, s, p = geom
         x = _cont(x)
         y = ops.conv2d_fwd(x, wp, bias, K, KH, KW, s, p, slope, gain)
         ctx.save_for_backward(x, wp, y)
         ctx.cfg = (geom, slope, gain)
+        ctx.xch = xch
         return y
 
     @staticmethod
@@ -235,7 +238,17 @@ class ConvBiasActFn(Function):
         else:
             gw = ConvWgradFn.apply(x, g_pre, geom, tuple(wp.shape)) if ctx.needs_input_grad[1] else None
             gb = ColSumFn.apply(g_pre) if ctx.needs_input_grad[2] else None
-        return gx, gw, gb, None, None, None
+        if ctx.xch is not None and gw is not None and not torch.is_grad_enabled():
+            exchange_packed(ctx.xch, gw)
+        return (gx, gw, gb, None, None, None) + ((None,) if ctx.xch is not None else ())
+
+
+def exchange_packed(xch, gw):
+    """All-reduce a packed weight gradient at its production site and tell its PackWeightsFn node (which waits for the
+    collective before it unpacks, and reduces whatever nobody reduced before)."""
+    comm, meta, group = xch
+    comm.reduce_async(gw)
+    meta.reduced.add(group)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -412,6 +425,8 @@ class PackMeta(object):
 
     def __init__(self, entries, groups):
         self.entries, self.groups = entries, groups
+        self.comm = None            # engine.OverlappedGradReducer when the gradient exchange happens at the packed level
+        self.reduced = set()        # groups whose packed gradient a producer has already all-reduced in this backward
 
 
 def _specs_from(meta, ws):
@@ -443,6 +458,16 @@ class PackWeightsFn(Function):
     def backward(ctx, *gouts):
         meta = ctx.meta
         gouts = [g if g is not None else None for g in gouts]
+        comm = getattr(meta, 'comm', None)
+        if comm is not None and not torch.is_grad_enabled():
+            # data-parallel exchange at the packed level (the fixed EqualConv scale is the same on every rank, so reducing
+            # the packed gradient is reducing the parameter gradient): groups a first-order producer already all-reduced
+            # while the backward went on (meta.reduced) are only waited for, everything else -- the any-order graph of
+            # an R1 call, where a packed weight collects several contributions -- is reduced here
+            for gi, g in enumerate(gouts):
+                if g is not None and gi not in meta.reduced:
+                    comm.reduce_async(g)
+            comm.wait()
         gws = UnpackWeightsFn.apply(meta, ctx.shapes, *gouts)
         return (None,) + tuple(gws)
 

@@ -28,7 +28,12 @@ _dist_on = dist_on
 
 class GradAllReducer(object):
     """Sum-all-reduce ``p.grad`` for all params, coalescing gradients that are views of one storage into a single
-    collective over the covering span (the HIP discriminator returns exactly two such storages)."""
+    collective over the covering span (the HIP discriminators return their weight gradients as views of one flat
+    buffer).  Gradients that stay separate small tensors (the ~40 FusedLeakyReLU / head biases of the StyleGAN2
+    discriminator: a latency-bound collective each) are packed into ONE staging buffer, reduced together and copied
+    back (``torch._foreach_copy_``: two launches instead of 40 collectives)."""
+
+    SMALL = 1 << 18          # floats: spans below 1 MB are packed
 
     def __init__(self, params):
         self.params = [p for p in params]
@@ -57,9 +62,28 @@ class GradAllReducer(object):
     def __call__(self):
         if not _dist_on():
             return 1
-        for flat in self.spans():
+        spans = self.spans()
+        small = [t for t in spans if t.numel() < self.SMALL]
+        if len(small) > 1:
+            stage = torch.cat([t.reshape(-1) for t in small])
+            dist.all_reduce(stage)
+            torch._foreach_copy_(small, list(torch.split(stage, [t.numel() for t in small])))
+            spans = [t for t in spans if t.numel() >= self.SMALL]
+        for flat in spans:
             dist.all_reduce(flat)          # SUM; the mean's 1/W goes into Adam's grad_scale
         return dist.get_world_size()
+
+
+def setup_grad_exchange(D, overlap=True):
+    """The data-parallel gradient exchange of a discriminator: returns the reducer to call after the backward, or None
+    when the network exchanges everything inside its backward.  ``D_SNDCGAN``: per-layer collectives inside the fused
+    backward (all parameters).  ``ResidualDiscriminatorP``: the packed weight gradients are all-reduced from autograd hooks
+    as they are produced (heads and the deep levels first -- their exchange hides behind the long high-resolution part of
+    the backward), the bias gradients in one packed collective afterwards."""
+    if overlap and hasattr(D, 'enable_grad_overlap'):
+        rest = D.enable_grad_overlap(OverlappedGradReducer())
+        return GradAllReducer(rest) if rest else None
+    return GradAllReducer(D.parameters())
 
 
 class OverlappedGradReducer(object):
@@ -385,7 +409,10 @@ class GraphedSG2DStep(object):
     def __init__(self, P, G, D, opt_D, options, images, contrad_script, style_mix=0.9, warmup=2):
         import argparse
         self.dist = dist_on()       # one rank of a data-parallel job: the embedding all-gather (inside the loss) and the
-        self.reducer = GradAllReducer(D.parameters()) if self.dist else None      # flat gradient all-reduces are captured
+        self.reducer = None         # gradient all-reduces (from the backward's hooks and / or after it) are captured
+        if self.dist:
+            rest = D.overlap_rest() if getattr(D, '_pack_comm', None) is not None else None
+            self.reducer = GradAllReducer(rest if rest is not None else D.parameters())
         self.P, self.G, self.D, self.opt, self.options, self.images = P, G, D, opt_D, options, images.clone()
         self.contrad_script, self.style_mix = contrad_script, style_mix
         self.eager = d_step_stylegan2_contrad if contrad_script else d_step_stylegan2

@@ -134,6 +134,7 @@ class _TrunkFn(torch.autograd.Function):
             D._trunk_rec = [r0] + [t for bi in range(len(blocks)) for t in (saved[2 + 5 * bi], saved[4 + 5 * bi])]
         ctx.save_for_backward(images, kernel, *wb, *saved)
         ctx.n_wb, ctx.geo = len(wb), geo
+        ctx.xch = getattr(D, '_trunk_xch', None)      # (comm, meta, group ids): all-reduce each weight gradient as produced
         return x
 
     @staticmethod
@@ -182,8 +183,14 @@ class _TrunkFn(torch.autograd.Function):
                                             want_out=False, want_out2=True)
             del g_sb, g_x1
             grads[2 + 5 * bi: 7 + 5 * bi] = [gw1, gb1, gw2, gb2, gws]
+            if ctx.xch is not None:       # data parallel: these three slabs are final -- start their all-reduce now
+                comm, meta, gids = ctx.xch
+                for k_, gw_ in ((2, gw1), (4, gw2), (6, gws)):
+                    A.exchange_packed((comm, meta, gids[5 * bi + k_]), gw_)
         gw0 = A._packed_buffer(wb[0].shape, wb[1].numel(), wb[0].device); gb0 = torch.empty_like(wb[1])
         ops.rgb_conv_wgrad(images, gm, 1, 2.0, -1.0, gw0, gb0)
+        if ctx.xch is not None:
+            A.exchange_packed((ctx.xch[0], ctx.xch[1], ctx.xch[2][0]), gw0)
         grads[0], grads[1] = gw0, gb0
         return (None, None, None) + tuple(grads)
 
@@ -221,6 +228,18 @@ class ResidualDiscriminatorP(BaseDiscriminator):
         self.c_last_in = in_channel
         self.fuse_trunk = True          # (tests switch it off to compare the two graph constructions)
         self._batch_splits = None
+        self._pack_comm = None          # engine.OverlappedGradReducer: exchange the packed weight gradients in-backward
+        self._cur_meta = None
+
+    def enable_grad_overlap(self, comm):
+        """Exchange the weight gradients inside the backward (engine.setup_grad_exchange); returns the parameters that
+        are NOT covered -- the biases, which the caller reduces afterwards.  Pass None to disable."""
+        self._pack_comm = comm
+        return self.overlap_rest() if comm is not None else list(self.parameters())
+
+    def overlap_rest(self):
+        packed_ids = {id(m.weight) for m in self.modules() if isinstance(m, (_EqualConvParams, PlainParams))}
+        return [p for p in self.parameters() if id(p) not in packed_ids]
 
     def call_batches(self, batches, **flags):
         """Several discriminator calls with the same flags as ONE pass: every layer of this network acts per sample
@@ -279,7 +298,12 @@ class ResidualDiscriminatorP(BaseDiscriminator):
         idx['l2'] = add(self.linear.l2.weight, 1, dh, 1, 1.0)
         idx['p2'] = add(self.projection[2].weight, dp, dh, 1, 1.0)
         idx['q2'] = add(self.projection2[2].weight, dp, dh, 1, 1.0)
-        packed = A.PackWeightsFn.apply(A.PackMeta(entries, groups), *ws)
+        meta = A.PackMeta(entries, groups)
+        comm = self._pack_comm if (self._pack_comm is not None and self._pack_comm.active()
+                                   and torch.is_grad_enabled()) else None
+        meta.comm = comm            # PackWeightsFn.backward then exchanges the packed gradients (data parallel)
+        packed = A.PackWeightsFn.apply(meta, *ws)
+        self._cur_meta = meta
         return packed, idx
 
     # ---- forward ---------------------------------------------------------------------------------------
@@ -289,15 +313,26 @@ class ResidualDiscriminatorP(BaseDiscriminator):
             wb += [wp[idx[(bi, 'conv1')]], blk.conv1[1].bias, wp[idx[(bi, 'conv2')]], blk.conv2[2].bias,
                    wp[idx[(bi, 'skip')]]]
         blur = list(self.layers)[1].conv2[0].kernel
+        # exchange handles for the backward: group index of every packed weight among ``wb`` (None for the biases)
+        gids = [idx['rgb'], None]
+        for bi in range(len(self.layers) - 1):
+            gids += [idx[(bi, 'conv1')], None, idx[(bi, 'conv2')], None, idx[(bi, 'skip')]]
+        self._trunk_xch = (self._cur_meta.comm, self._cur_meta, gids) if self._cur_meta.comm is not None else None
         x = _TrunkFn.apply(self, images, blur, *wb)
         if rec is not None:
             rec.extend(self._trunk_rec)
         x = minibatch_stddev_batches(x, self._batch_splits)
         x = A.ConvBiasActFn.apply(x, wp[idx['last']], self.last_conv[1].bias,
-                                  (self.last_conv[0].weight.shape[0], 3, 3, 1, 1), _SLOPE, _GAIN)
+                                  (self.last_conv[0].weight.shape[0], 3, 3, 1, 1), _SLOPE, _GAIN, *self._xch(idx['last']))
         if rec is not None:
             rec.append(x)
         return x
+
+    def _xch(self, group, first_order=True):
+        """Exchange handle of a packed weight for a node whose backward is its ONLY gradient producer (the first-order
+        call: fused trunk, constant images); () otherwise."""
+        m = self._cur_meta
+        return ((m.comm, m, group),) if (first_order and m is not None and m.comm is not None) else ()
 
     def _trunk(self, images, wp, idx, rec=None):
         rgb = self.layers[0]
@@ -357,16 +392,21 @@ class ResidualDiscriminatorP(BaseDiscriminator):
         feat = x.reshape(B, 1, 1, self.n_features)
         feat_d = feat.detach() if sg_linear else feat
         g1 = (1, 1, 1, 1, 0)
-        h_l = A.ConvBiasActFn.apply(feat_d, wp[idx['l1']], self.linear.l1.bias, (dh,) + g1[1:], _HEAD_SLOPE, 1.0)
-        out = A.ConvBiasActFn.apply(h_l, wp[idx['l2']], self.linear.l2.bias, (1,) + g1[1:], 1.0, 1.0).view(B, 1)
+        # (first-order call: each head weight has exactly one gradient producer -> it may start the data-parallel
+        # exchange of its packed gradient itself, _xch)
+        h_l = A.ConvBiasActFn.apply(feat_d, wp[idx['l1']], self.linear.l1.bias, (dh,) + g1[1:], _HEAD_SLOPE, 1.0,
+                                    *self._xch(idx['l1'], fused))
+        out = A.ConvBiasActFn.apply(h_l, wp[idx['l2']], self.linear.l2.bias, (1,) + g1[1:], 1.0, 1.0,
+                                    *self._xch(idx['l2'], fused)).view(B, 1)
         h_pq = proj = proj2 = None
         if want_proj or rec is not None:
             bias_pq = torch.cat([self.projection[0].bias, self.projection2[0].bias])
-            h_pq = A.ConvBiasActFn.apply(feat, wp[idx['p0q0']], bias_pq, (2 * dh,) + g1[1:], _HEAD_SLOPE, 1.0)
+            h_pq = A.ConvBiasActFn.apply(feat, wp[idx['p0q0']], bias_pq, (2 * dh,) + g1[1:], _HEAD_SLOPE, 1.0,
+                                         *self._xch(idx['p0q0'], fused))
             proj = A.ConvBiasActFn.apply(h_pq[..., :dh], wp[idx['p2']], self.projection[2].bias, (dp,) + g1[1:], 1.0,
-                                         1.0).view(B, dp)
+                                         1.0, *self._xch(idx['p2'], fused)).view(B, dp)
             proj2 = A.ConvBiasActFn.apply(h_pq[..., dh:], wp[idx['q2']], self.projection2[2].bias, (dp,) + g1[1:], 1.0,
-                                          1.0).view(B, dp)
+                                          1.0, *self._xch(idx['q2'], fused)).view(B, dp)
         if rec is not None:
             if not hasattr(self, '_recorded'):
                 self._recorded = []

@@ -28,7 +28,8 @@ import torch.distributed as dist
 
 from . import config, ops
 from .augment import get_augment
-from .engine import GradAllReducer, GraphedSG2DStep, GraphedSG2GStep, loss_D_fn_separate, r1_loss, set_grad
+from .engine import (GradAllReducer, GraphedSG2DStep, GraphedSG2GStep, loss_D_fn_separate, r1_loss, set_grad,
+                     setup_grad_exchange)
 from .hostio import THROTTLE
 from .models.gan import get_architecture
 from .optim import FusedAdam
@@ -386,7 +387,7 @@ def main(argv=None, contrad_script=False):
 
     reducers = (None, None)
     if world > 1:
-        reducers = (GradAllReducer(G.parameters()), GradAllReducer(D.parameters()))
+        reducers = (GradAllReducer(G.parameters()), setup_grad_exchange(D))      # D: weights exchanged inside the backward
     use_synth = P.synthetic
     if not use_synth:
         try:

@@ -96,9 +96,9 @@ def sndcgan_g():
     assert torch.equal(outs[0][2], outs[1][2])
 
 
-def stylegan2_d():
+def stylegan2_d(overlap=False):
     from contrad_amd.augment import SimCLRAugment
-    from contrad_amd.engine import GradAllReducer, GraphedSG2DStep, d_step_stylegan2, set_grad
+    from contrad_amd.engine import (GradAllReducer, GraphedSG2DStep, d_step_stylegan2, set_grad, setup_grad_exchange)
     from contrad_amd.models.gan import get_architecture
     from contrad_amd.optim import FusedAdam
     from contrad_amd.training.gan import setup
@@ -119,7 +119,9 @@ def stylegan2_d():
     def seed():
         torch.manual_seed(7); np.random.seed(7); torch.cuda.manual_seed(7)
     P, G, D, opt, x = build()
-    red = GradAllReducer(D.parameters())
+    # overlap: packed weight gradients all-reduced at their production sites inside the backward, biases afterwards
+    red = setup_grad_exchange(D) if overlap else GradAllReducer(D.parameters())
+    assert (D._pack_comm is not None) == overlap
     seed()
     le = []
     for s in range(1, W + K + 1):
@@ -127,9 +129,12 @@ def stylegan2_d():
         le.append((dl.item(), aux['penalty'].item(), aux['r1'].item()))
     want = [p.detach().clone() for p in D.parameters()]
     P, G, D, opt, x = build()
+    if overlap:
+        setup_grad_exchange(D)
     seed()
     g = GraphedSG2DStep(P, G, D, opt, {'loss': 'nonsat'}, x, contrad_script=False, warmup=W)
     assert g.dist and g.reducer is not None
+    assert len(g.reducer.params) == (len(D.overlap_rest()) if overlap else len(list(D.parameters())))
     lg = []
     for s in range(1, K + 1):
         dl, aux = g(s)
@@ -148,7 +153,8 @@ if __name__ == '__main__':
     try:
         for name, fn in (('sndcgan D-step, overlapped exchange', lambda: sndcgan_d(True)),
                          ('sndcgan D-step, flat exchange', lambda: sndcgan_d(False)),
-                         ('sndcgan G-step', sndcgan_g), ('stylegan2 D-step + R1', stylegan2_d)):
+                         ('sndcgan G-step', sndcgan_g), ('stylegan2 D-step + R1', stylegan2_d),
+                         ('stylegan2 D-step + R1, weight gradients exchanged inside the backward', lambda: stylegan2_d(True))):
             fn()
             print('OK', name, flush=True)
     finally:

@@ -78,13 +78,13 @@ def _namespace(setup, aug, distributed):
     return P
 
 
-def _worker(rank, world, port, path):
+def _worker(rank, world, port, path, overlap=False):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        from contrad_amd.engine import GradAllReducer, d_step_stylegan2_contrad
+        from contrad_amd.engine import GradAllReducer, d_step_stylegan2_contrad, setup_grad_exchange
         from contrad_amd.optim import FusedAdam
         from contrad_amd.training.gan import setup
         import contrad_amd.third_party.gather_layer as gl
@@ -106,8 +106,11 @@ def _worker(rank, world, port, path):
         _inject(aug, [Pf[sl], Pr[rows2], P1[sl]], cf)
         P = _namespace(setup, aug, True)
         opt = FusedAdam(D.parameters(), lr=2e-3, betas=(0.0, 0.99))
+        # overlap: the packed weight gradients are all-reduced at their production sites inside the backward (fused call)
+        # or in PackWeightsFn.backward (the R1 call's any-order graph), the biases in one packed collective afterwards
+        reducer = setup_grad_exchange(D) if overlap else GradAllReducer(D.parameters())
         d_loss, aux = d_step_stylegan2_contrad(P, _FixedG(fakes[sl].to(dev)), D, opt, {'loss': 'nonsat'},
-                                               images[sl].to(dev), 1, GradAllReducer(D.parameters()))
+                                               images[sl].to(dev), 1, reducer)
         torch.cuda.synchronize()
         torch.save({'d_loss': d_loss.detach().cpu(), 'gan': aux['penalty'].detach().cpu(), 'r1': aux['r1'].detach().cpu(),
                     'grads': [p.grad.detach().cpu().clone() for p in D.parameters()],
@@ -116,13 +119,14 @@ def _worker(rank, world, port, path):
         dist.destroy_process_group()
 
 
-def test_two_rank_stylegan2_contrad_step_equals_the_hand_assembled_global_step(tmp_path):
+@pytest.mark.parametrize('overlap', [False, True])
+def test_two_rank_stylegan2_contrad_step_equals_the_hand_assembled_global_step(tmp_path, overlap):
     import torch.multiprocessing as mp
     from contrad_amd.engine import r1_loss
     from contrad_amd.training.gan import setup
     from contrad_amd.training.gan.contrad import _ContraDContrastive, _GanDLoss
     path = str(tmp_path / 'dp2')
-    mp.spawn(_worker, args=(WORLD, 29551, path), nprocs=WORLD, join=True)
+    mp.spawn(_worker, args=(WORLD, 29551 + int(overlap), path, overlap), nprocs=WORLD, join=True)
     res = [torch.load('%s.rank%d' % (path, r)) for r in range(WORLD)]
 
     dev = torch.device('cuda', 0)
