@@ -52,6 +52,23 @@ def _worker(rank, world, port, ret):
     ok = ok and len(spans) == 1 and spans[0].numel() == 10
     wsize = red()
     ok = ok and wsize == world and torch.equal(p2.grad, torch.arange(6, 10, dtype=torch.float32) * 3)
+    # many small separate gradients (the StyleGAN2 discriminator's ~40 bias tensors): staged into ONE buffer, one
+    # collective, copied back -- each still receives its own sum; a big span keeps its own collective
+    smalls = [torch.nn.Parameter(torch.zeros(k + 1)) for k in range(5)]
+    for k, q in enumerate(smalls):
+        q.grad = torch.full((k + 1,), float((k + 1) * (rank + 1)))
+    big = torch.nn.Parameter(torch.zeros(GradAllReducer.SMALL + 8))
+    big.grad = torch.full((GradAllReducer.SMALL + 8,), float(rank + 1))
+    calls = []
+    real_all_reduce = dist.all_reduce
+    dist.all_reduce = lambda t, *a, **k: (calls.append(t.numel()), real_all_reduce(t, *a, **k))[1]
+    try:
+        wsize = GradAllReducer(smalls + [big])()
+    finally:
+        dist.all_reduce = real_all_reduce
+    ok = ok and wsize == world and sorted(calls) == [15, GradAllReducer.SMALL + 8]
+    ok = ok and all(torch.equal(q.grad, torch.full((k + 1,), float((k + 1) * 3))) for k, q in enumerate(smalls))
+    ok = ok and torch.equal(big.grad, torch.full((GradAllReducer.SMALL + 8,), 3.0))
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 
