@@ -247,6 +247,8 @@ def exchange_packed(xch, gw):
     """All-reduce a packed weight gradient at its production site and tell its PackWeightsFn node (which waits for the
     collective before it unpacks, and reduces whatever nobody reduced before)."""
     comm, meta, group = xch
+    if meta.shared:             # other calls contribute to the same packed gradient: the pack node reduces the total
+        return
     comm.reduce_async(gw)
     meta.reduced.add(group)
 
@@ -427,6 +429,9 @@ class PackMeta(object):
         self.entries, self.groups = entries, groups
         self.comm = None            # engine.OverlappedGradReducer when the gradient exchange happens at the packed level
         self.reduced = set()        # groups whose packed gradient a producer has already all-reduced in this backward
+        self.shared = False         # several discriminator calls use this pack: no production-site exchange
+        self.dead = False           # its backward has run (the graph may be freed): do not reuse
+        self.on_backward = None     # callback of the owner (drops its cached reference)
 
 
 def _specs_from(meta, ws):
@@ -457,6 +462,9 @@ class PackWeightsFn(Function):
     @staticmethod
     def backward(ctx, *gouts):
         meta = ctx.meta
+        meta.dead = True
+        if meta.on_backward is not None:
+            meta.on_backward()
         gouts = [g if g is not None else None for g in gouts]
         comm = getattr(meta, 'comm', None)
         if comm is not None and not torch.is_grad_enabled():

@@ -18,6 +18,9 @@ from .... import ops
 from ..base import BaseDiscriminator, PlainParams, TinyHead, _Act, make_projection
 
 _SLOPE, _GAIN = 0.2, math.sqrt(2.0)
+# per-discriminator pack of the current step (ResidualDiscriminatorP._pack); outside the module so that deepcopy / pickling
+# of a discriminator never meets autograd-graph tensors
+_PACK_CACHE = __import__('weakref').WeakKeyDictionary()
 _HEAD_SLOPE = 0.1
 
 
@@ -141,58 +144,185 @@ class _TrunkFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         t = ctx.saved_tensors
-        images, kernel = t[0], t[1]
-        wb = t[2:2 + ctx.n_wb]
-        saved = t[2 + ctx.n_wb:]
-        r0 = saved[0]
-        nb = len(ctx.geo)
-        gk = A.flipped_kernel(kernel)
-        grads = [None] * ctx.n_wb
-        g = g.contiguous()
-        gm = None                                   # g * act'(y2 of the current block)
-        for bi in range(nb - 1, -1, -1):
-            x, o, ob, y2, sb = saved[1 + 5 * bi: 6 + 5 * bi]
-            wp1, b1, wp2, b2, wps = wb[2 + 5 * bi: 7 + 5 * bi]
-            ci, co, (p0, p1), (q0, q1) = ctx.geo[bi]
-            if gm is None:
-                gm = ops.fused_bias_act(g, None, y2, 3, 1, _SLOPE, 1.0)
-            # conv2 (3x3 stride 2 on the blurred map)
+        grads, _ = _trunk_backward_chain(t[0], t[1], t[2:2 + ctx.n_wb], t[2 + ctx.n_wb:], ctx.geo, g, True, False, ctx.xch)
+        return (None, None, None) + tuple(grads)
+
+
+def _trunk_backward_chain(images, kernel, wb, saved, geo, g, want_w, want_img, xch=None, keep=None, img_c=3):
+    """The trunk's vector-Jacobian product from the gradient ``g`` at its output: every packed weight / bias gradient
+    (``want_w``) and / or the gradient w.r.t. the images (``want_img``).  ``keep`` (a dict) receives, per block, the
+    signals the double backward needs: the gradient at the block output, plain (``g``) and masked by act'(y2) (``gm``),
+    and the gradient at conv1's pre-activation (``g_o``); key -1: the gradient at FromRGB's pre-activation."""
+    n_wb = len(wb)
+    r0 = saved[0]
+    nb = len(geo)
+    gk = A.flipped_kernel(kernel)
+    grads = [None] * n_wb
+    g = g.contiguous()
+    gm = None                                   # g * act'(y2 of the current block)
+    for bi in range(nb - 1, -1, -1):
+        x, o, ob, y2, sb = saved[1 + 5 * bi: 6 + 5 * bi]
+        wp1, b1, wp2, b2, wps = wb[2 + 5 * bi: 7 + 5 * bi]
+        ci, co, (p0, p1), (q0, q1) = geo[bi]
+        if gm is None:
+            gm = ops.fused_bias_act(g, None, y2, 3, 1, _SLOPE, 1.0)
+        # conv2 (3x3 stride 2 on the blurred map)
+        if want_w:
             gw2 = A._packed_buffer(wp2.shape, co, wp2.device); gb2 = torch.empty_like(b2)
             ops.conv2d_wgrad(ob, gm, 3, 3, 2, 0, out=gw2, dbias=gb2)
-            g_ob = ops.conv2d_dgrad(gm, wp2, tuple(ob.shape), 3, 3, 2, 0)
-            # blur^T, times act'(o) * sqrt2
-            gp = (4 - p0 - 1, o.shape[2] - ob.shape[2] + p0, 4 - p0 - 1, o.shape[1] - ob.shape[1] + p0)
-            _, g_o = ops.upfirdn2d_fused(g_ob, gk, 1, 1, gp, act_ref=o, slope=_SLOPE, gain=_GAIN, want_out=False,
-                                         want_out2=True)
-            del g_ob
+        g_ob = ops.conv2d_dgrad(gm, wp2, tuple(ob.shape), 3, 3, 2, 0)
+        # blur^T, times act'(o) * sqrt2
+        gp = (4 - p0 - 1, o.shape[2] - ob.shape[2] + p0, 4 - p0 - 1, o.shape[1] - ob.shape[1] + p0)
+        _, g_o = ops.upfirdn2d_fused(g_ob, gk, 1, 1, gp, act_ref=o, slope=_SLOPE, gain=_GAIN, want_out=False,
+                                     want_out2=True)
+        del g_ob
+        if want_w:
             gw1 = A._packed_buffer(wp1.shape, ci, wp1.device); gb1 = torch.empty_like(b1)
             ops.conv2d_wgrad(x, g_o, 3, 3, 1, 1, out=gw1, dbias=gb1)
-            g_x1 = ops.conv2d_dgrad(g_o, wp1, tuple(x.shape), 3, 3, 1, 1)
-            del g_o
-            # skip branch (1x1 conv on the blurred + decimated map), driven by the un-masked g
+        g_x1 = ops.conv2d_dgrad(g_o, wp1, tuple(x.shape), 3, 3, 1, 1)
+        # skip branch (1x1 conv on the blurred + decimated map), driven by the un-masked g
+        if want_w:
             gws = A._packed_buffer(wps.shape, co, wps.device)
             ops.conv2d_wgrad(sb, g, 1, 1, 1, 0, out=gws)
-            g_sb = ops.conv2d_dgrad(g, wps, tuple(sb.shape), 1, 1, 1, 0)
-            gq = (4 - q0 - 1, x.shape[2] - sb.shape[2] * 2 + q0, 4 - q0 - 1, x.shape[1] - sb.shape[1] * 2 + q0)
-            if bi > 0:      # gradient of this block's input = previous block's output: plain sum + masked sum
-                y2_prev = saved[1 + 5 * (bi - 1) + 3]
-                g, gm = ops.upfirdn2d_fused(g_sb, gk, 2, 1, gq, addend=g_x1, act_ref=y2_prev, slope=_SLOPE, gain=1.0,
-                                            want_out=True, want_out2=True)
-            else:           # FromRGB output: only the masked sum is needed
-                _, gm = ops.upfirdn2d_fused(g_sb, gk, 2, 1, gq, addend=g_x1, act_ref=r0, slope=_SLOPE, gain=_GAIN,
-                                            want_out=False, want_out2=True)
-            del g_sb, g_x1
+        g_sb = ops.conv2d_dgrad(g, wps, tuple(sb.shape), 1, 1, 1, 0)
+        if keep is not None:
+            keep[bi] = (g, gm, g_o)
+        del g_o
+        gq = (4 - q0 - 1, x.shape[2] - sb.shape[2] * 2 + q0, 4 - q0 - 1, x.shape[1] - sb.shape[1] * 2 + q0)
+        if bi > 0:      # gradient of this block's input = previous block's output: plain sum + masked sum
+            y2_prev = saved[1 + 5 * (bi - 1) + 3]
+            g, gm = ops.upfirdn2d_fused(g_sb, gk, 2, 1, gq, addend=g_x1, act_ref=y2_prev, slope=_SLOPE, gain=1.0,
+                                        want_out=True, want_out2=True)
+        else:           # FromRGB output: only the masked sum is needed
+            _, gm = ops.upfirdn2d_fused(g_sb, gk, 2, 1, gq, addend=g_x1, act_ref=r0, slope=_SLOPE, gain=_GAIN,
+                                        want_out=False, want_out2=True)
+        del g_sb, g_x1
+        if want_w:
             grads[2 + 5 * bi: 7 + 5 * bi] = [gw1, gb1, gw2, gb2, gws]
-            if ctx.xch is not None:       # data parallel: these three slabs are final -- start their all-reduce now
-                comm, meta, gids = ctx.xch
+            if xch is not None:       # data parallel: these three slabs are final -- start their all-reduce now
+                comm, meta, gids = xch
                 for k_, gw_ in ((2, gw1), (4, gw2), (6, gws)):
                     A.exchange_packed((comm, meta, gids[5 * bi + k_]), gw_)
+    if keep is not None:
+        keep[-1] = gm
+    if want_w:
         gw0 = A._packed_buffer(wb[0].shape, wb[1].numel(), wb[0].device); gb0 = torch.empty_like(wb[1])
         ops.rgb_conv_wgrad(images, gm, 1, 2.0, -1.0, gw0, gb0)
-        if ctx.xch is not None:
-            A.exchange_packed((ctx.xch[0], ctx.xch[1], ctx.xch[2][0]), gw0)
+        if xch is not None:
+            A.exchange_packed((xch[0], xch[1], xch[2][0]), gw0)
         grads[0], grads[1] = gw0, gb0
-        return (None, None, None) + tuple(grads)
+    g_img = ops.rgb_conv_dgrad(gm, wb[0], None, img_c, 1, act=0, out_scale=2.0) if want_img else None
+    return grads, g_img
+
+
+class _TrunkR1Fn(torch.autograd.Function):
+    """The trunk for images that NEED a gradient: the R1 penalty's D(x) (train_stylegan2.py:106-113) and the generator
+    step.  Same forward kernels as _TrunkFn; what differs is the backward:
+      * first-order (generator step, and the final backward of an R1 step -- the path through the minibatch-stddev
+        curvature, which is where the bias gradients of r1 come from): the fused chain of _TrunkFn plus FromRGB's data
+        gradient (d / d images);
+      * under ``create_graph`` (R1's ``autograd.grad(d_real.sum(), images, create_graph=True)``): d / d images is
+        returned by a second node, _TrunkVJPFn, so that ``r1 = |d D / d x|^2`` can be differentiated again.
+    Until round 3 this call ran on the any-order node family: ~100 autograd nodes per direction, every residual fan-out an
+    ATen ``add`` pass, every LeakyReLU derivative its own pass (55 adds, 19 muls, ~20 mask passes per StyleGAN2-32 step).
+    The packed weights are inputs of both nodes, so autograd sums their two contributions (term (i): through the
+    Jacobian's dependence on the weights, from _TrunkVJPFn.backward; term (ii): through the head's curvature, from this
+    node's first-order backward)."""
+
+    @staticmethod
+    def forward(ctx, D, images, kernel, *wb):
+        return _TrunkFn.forward(ctx, D, images, kernel, *wb)
+
+    @staticmethod
+    def backward(ctx, g):
+        t = ctx.saved_tensors
+        images, kernel = t[0], t[1]
+        wb, saved = t[2:2 + ctx.n_wb], t[2 + ctx.n_wb:]
+        need_img = ctx.needs_input_grad[1]
+        need_w = any(ctx.needs_input_grad[3:]) and not A._INPUT_GRAD_ONLY
+        if torch.is_grad_enabled():
+            # create_graph: the image gradient must stay differentiable.  (Parameter gradients of THIS backward are not
+            # differentiable here -- nothing on the path differentiates them -- and are skipped when the caller asked
+            # for d / d images only, autograd_ops.input_grad_only.)
+            g_img = _TrunkVJPFn.apply(g, ctx.n_wb, ctx.geo, tuple(images.shape), kernel, *wb, *saved) if need_img else None
+            grads = [None] * ctx.n_wb
+            if need_w:
+                with torch.no_grad():
+                    grads, _ = _trunk_backward_chain(images, kernel, [w.detach() for w in wb], saved, ctx.geo, g.detach(),
+                                                     True, False)
+            return (None, g_img, None) + tuple(grads)
+        grads, g_img = _trunk_backward_chain(images, kernel, wb, saved, ctx.geo, g, need_w, need_img, None, None,
+                                             images.shape[1])
+        return (None, g_img, None) + tuple(grads)
+
+
+class _TrunkVJPFn(torch.autograd.Function):
+    """g_top (gradient at the trunk output) -> d / d images, as a differentiable node: the forward IS the trunk's
+    backward chain.  Its backward, given h = d r1 / d (d D / d images), is the forward-mode (tangent) pass of the
+    linearised trunk -- the same convolutions and blurs as the forward, with the LeakyReLU regions of the forward pass as
+    fixed masks -- which yields  d / d g_top = J h  (continues into the head's double backward)  and, layer by layer, the
+    weight gradient of term (i):  wgrad(tangent at the layer input, gradient signal at its pre-activation output)."""
+
+    @staticmethod
+    def forward(ctx, g_top, n_wb, geo, img_shape, kernel, *rest):
+        wb, saved = rest[:n_wb], rest[n_wb:]
+        keep = {}
+        _, g_img = _trunk_backward_chain(None, kernel, wb, saved, geo, g_top, False, True, None, keep, img_shape[1])
+        nb = len(geo)
+        flat = [keep[-1]]
+        for bi in range(nb):
+            flat += list(keep[bi])
+        ctx.save_for_backward(kernel, *wb, *saved, *flat)
+        ctx.cfg = (n_wb, geo, len(saved))
+        return g_img
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, h):
+        n_wb, geo, n_saved = ctx.cfg
+        t = ctx.saved_tensors
+        kernel = t[0]
+        wb, saved, flat = t[1:1 + n_wb], t[1 + n_wb:1 + n_wb + n_saved], t[1 + n_wb + n_saved:]
+        nb = len(geo)
+        r0, gm0 = saved[0], flat[0]
+        h = h.contiguous()
+        need_w = any(ctx.needs_input_grad[5:5 + n_wb])
+        gws_out = [None] * n_wb
+        K0 = r0.shape[3]
+        if need_w:
+            gw0 = A._packed_buffer(wb[0].shape, K0, wb[0].device)
+            ops.rgb_conv_wgrad(h, gm0, 1, 2.0, 0.0, gw0)
+            gws_out[0] = gw0
+        U = ops.rgb_conv_fwd(h, wb[0], None, K0, 1, 2.0, 0.0, 1.0, 1.0)             # tangent at FromRGB's pre-activation
+        U = ops.fused_bias_act(U, None, r0, 3, 1, _SLOPE, _GAIN)                     # ... at its output
+        for bi in range(nb):
+            x, o, ob, y2, sb = saved[1 + 5 * bi: 6 + 5 * bi]
+            wp1, b1, wp2, b2, wps = wb[2 + 5 * bi: 7 + 5 * bi]
+            ci, co, (p0, p1), (q0, q1) = geo[bi]
+            g, gm, g_o = flat[1 + 3 * bi: 4 + 3 * bi]
+            if need_w:
+                gw1 = A._packed_buffer(wp1.shape, ci, wp1.device)
+                ops.conv2d_wgrad(U, g_o, 3, 3, 1, 1, out=gw1)
+                gws_out[2 + 5 * bi] = gw1
+            t1 = ops.conv2d_fwd(U, wp1, None, ci, 3, 3, 1, 1)
+            t1 = ops.fused_bias_act(t1, None, o, 3, 1, _SLOPE, _GAIN)
+            tb = ops.upfirdn2d(t1, kernel, 1, 1, (p0, p1, p0, p1))
+            del t1
+            if need_w:
+                gw2 = A._packed_buffer(wp2.shape, co, wp2.device)
+                ops.conv2d_wgrad(tb, gm, 3, 3, 2, 0, out=gw2)
+                gws_out[4 + 5 * bi] = gw2
+            t2 = ops.conv2d_fwd(tb, wp2, None, co, 3, 3, 2, 0)
+            del tb
+            t2 = ops.fused_bias_act(t2, None, y2, 3, 1, _SLOPE, 1.0)
+            usb = ops.upfirdn2d(U, kernel, 1, 2, (q0, q1, q0, q1))
+            if need_w:
+                gws = A._packed_buffer(wps.shape, co, wps.device)
+                ops.conv2d_wgrad(usb, g, 1, 1, 1, 0, out=gws)
+                gws_out[6 + 5 * bi] = gws
+            U = ops.conv2d_fwd(usb, wps, None, co, 1, 1, 1, 0, addend=t2)
+            del t2, usb
+        return (U, None, None, None, None) + tuple(gws_out) + (None,) * n_saved
 
 
 class ResidualDiscriminatorP(BaseDiscriminator):
@@ -227,6 +357,7 @@ class ResidualDiscriminatorP(BaseDiscriminator):
         self.last_conv = _conv_layer(in_channel + 1, channels[4], 3)
         self.c_last_in = in_channel
         self.fuse_trunk = True          # (tests switch it off to compare the two graph constructions)
+        self.fuse_r1 = True             # images with a gradient (R1, generator step): _TrunkR1Fn instead of the node family
         self._batch_splits = None
         self._pack_comm = None          # engine.OverlappedGradReducer: exchange the packed weight gradients in-backward
         self._cur_meta = None
@@ -236,6 +367,10 @@ class ResidualDiscriminatorP(BaseDiscriminator):
         are NOT covered -- the biases, which the caller reduces afterwards.  Pass None to disable."""
         self._pack_comm = comm
         return self.overlap_rest() if comm is not None else list(self.parameters())
+
+    def drop_pack_cache(self):
+        """Forget the shared weight pack of the current step (engine: before a stream capture)."""
+        _PACK_CACHE.pop(self, None)
 
     def overlap_rest(self):
         packed_ids = {id(m.weight) for m in self.modules() if isinstance(m, (_EqualConvParams, PlainParams))}
@@ -264,7 +399,19 @@ class ResidualDiscriminatorP(BaseDiscriminator):
     def _pack(self, fused=True):
         """``fused`` (both graph constructions use it): the skip weights carry the residual merge's 1/sqrt2 -- together
         with conv2's activation gain sqrt2 / sqrt2 = 1 the merge (out + skip) / sqrt2 (discriminator.py:72-74) becomes a
-        plain sum, whose backward is the identity on both branches (no scaling pass, forward or backward)."""
+        plain sum, whose backward is the identity on both branches (no scaling pass, forward or backward).
+        Two discriminator calls on the SAME weights inside one step (the ContraD call and the R1 call) share one pack:
+        keyed on the parameters' version counters, dropped as soon as its backward has run."""
+        comm = self._pack_comm if (self._pack_comm is not None and self._pack_comm.active()
+                                   and torch.is_grad_enabled()) else None
+        plist = list(self.parameters())
+        key = (tuple(p._version for p in plist), sum(1 for p in plist if p.requires_grad), torch.is_grad_enabled(),
+               id(comm), plist[0].device)
+        c = _PACK_CACHE.get(self)
+        if c is not None and c[0] == key and not c[1].dead:
+            c[1].shared = True          # (its gradients are then exchanged in PackWeightsFn.backward, not by the producers)
+            self._cur_meta = c[1]
+            return c[2], c[3]
         ws, entries, groups = [], [], []
 
         def add(w, K, C, T, scale, group=None, col=0):
@@ -299,15 +446,18 @@ class ResidualDiscriminatorP(BaseDiscriminator):
         idx['p2'] = add(self.projection[2].weight, dp, dh, 1, 1.0)
         idx['q2'] = add(self.projection2[2].weight, dp, dh, 1, 1.0)
         meta = A.PackMeta(entries, groups)
-        comm = self._pack_comm if (self._pack_comm is not None and self._pack_comm.active()
-                                   and torch.is_grad_enabled()) else None
         meta.comm = comm            # PackWeightsFn.backward then exchanges the packed gradients (data parallel)
+        owner = __import__('weakref').ref(self)
+        # once its backward has run the pack must not be referenced any more: a graph kept alive across a hipGraph capture
+        # (its AccumulateGrad nodes are tied to the stream it ran on) crashes hipStreamEndCapture
+        meta.on_backward = lambda: (_PACK_CACHE.pop(owner(), None) if owner() is not None else None)
         packed = A.PackWeightsFn.apply(meta, *ws)
         self._cur_meta = meta
+        _PACK_CACHE[self] = (key, meta, packed, idx)
         return packed, idx
 
     # ---- forward ---------------------------------------------------------------------------------------
-    def _trunk_fused(self, images, wp, idx, rec=None):
+    def _trunk_fused(self, images, wp, idx, rec=None, r1=False):
         wb = [wp[idx['rgb']], self.layers[0][1].bias]
         for bi, blk in enumerate(list(self.layers)[1:]):
             wb += [wp[idx[(bi, 'conv1')]], blk.conv1[1].bias, wp[idx[(bi, 'conv2')]], blk.conv2[2].bias,
@@ -317,13 +467,15 @@ class ResidualDiscriminatorP(BaseDiscriminator):
         gids = [idx['rgb'], None]
         for bi in range(len(self.layers) - 1):
             gids += [idx[(bi, 'conv1')], None, idx[(bi, 'conv2')], None, idx[(bi, 'skip')]]
-        self._trunk_xch = (self._cur_meta.comm, self._cur_meta, gids) if self._cur_meta.comm is not None else None
-        x = _TrunkFn.apply(self, images, blur, *wb)
+        self._trunk_xch = (self._cur_meta.comm, self._cur_meta, gids) if (self._cur_meta.comm is not None
+                                                                             and not r1) else None
+        x = (_TrunkR1Fn if r1 else _TrunkFn).apply(self, images, blur, *wb)
         if rec is not None:
             rec.extend(self._trunk_rec)
         x = minibatch_stddev_batches(x, self._batch_splits)
         x = A.ConvBiasActFn.apply(x, wp[idx['last']], self.last_conv[1].bias,
-                                  (self.last_conv[0].weight.shape[0], 3, 3, 1, 1), _SLOPE, _GAIN, *self._xch(idx['last']))
+                                  (self.last_conv[0].weight.shape[0], 3, 3, 1, 1), _SLOPE, _GAIN,
+                                  *self._xch(idx['last'], not r1))
         if rec is not None:
             rec.append(x)
         return x
@@ -376,11 +528,15 @@ class ResidualDiscriminatorP(BaseDiscriminator):
             raise RuntimeError('contrad_amd.ResidualDiscriminatorP runs on the MI355X HIP path only (no CPU fallback)')
         # constant images (every ContraD discriminator call): one fused first-order node; images that need a gradient
         # (R1's create_graph, the generator step): the any-order node family
-        fused = self.fuse_trunk and not (inputs.requires_grad and torch.is_grad_enabled()) and len(self.layers) > 1
+        needs_img = inputs.requires_grad and torch.is_grad_enabled()
+        fused = self.fuse_trunk and not needs_img and len(self.layers) > 1
+        # images that need a gradient: _TrunkR1Fn (whose d / d images is differentiable again), round 3; the any-order
+        # node family remains as the cross-check (fuse_r1 = False, tests)
+        fused_r1 = self.fuse_trunk and self.fuse_r1 and needs_img and len(self.layers) > 1
         wp, idx = self._pack(True)
         images = inputs.contiguous().float()
         rec = [] if getattr(self, '_record_activations', False) else None     # test hook (linear regions used)
-        trunk = self._trunk_fused if fused else self._trunk
+        trunk = (lambda *a: self._trunk_fused(*a, r1=True)) if fused_r1 else (self._trunk_fused if fused else self._trunk)
         if finetuning:
             with torch.no_grad():
                 x = trunk(images, wp, idx, rec)
