@@ -142,6 +142,7 @@ class Generator(nn.Module):
             in_channel = out_channel
         self.n_latent = self.log_size * 2 - 2
         self._cache_key, self._cache = None, None
+        self._gather_key, self._gather_idx = None, None      # flat gather index of _all_styles (per batch size)
 
     @property
     def device(self):
@@ -229,12 +230,16 @@ class Generator(nn.Module):
         return c
 
     def _all_styles(self, latents, c):
-        """{modconv: (B, C_in) style} for the forward-only path: one GEMM over the B * n_latent latent rows, then the row
-        block of each layer's latent index."""
+        """Forward-only path: ({modconv: (B, C_in) style}, {modconv: (B, C_out) demodulation factor}).  One GEMM over the
+        B * n_latent latent rows gives every layer's style; ONE gather (a cached flat index) lays the row block of each
+        layer's latent index out contiguously, layer after layer (was: one strided-slice copy per layer); the
+        demodulation factors rsqrt(sum_c s^2 Wsq + 1e-8) (generator.py:62-64) of all layers then take one squaring pass,
+        one small GEMM per layer into ONE buffer and one add + rsqrt over that buffer (was: 3 elementwise launches per
+        layer)."""
         B, L, D = latents.shape
         wp = c['packed'][c['mod_all']]
-        out = ops.conv2d_fwd(latents.contiguous().view(B * L, 1, 1, D), wp, c['mod_bias_all'], wp.shape[1], 1, 1, 1, 0)
-        out = out.view(B, L, wp.shape[1])
+        cols = wp.shape[1]
+        out = ops.conv2d_fwd(latents.contiguous().view(B * L, 1, 1, D), wp, c['mod_bias_all'], cols, 1, 1, 1, 0)
         lat_idx = {self.conv1.conv: 0, self.to_rgb1.conv: 1}
         idx = 1
         for j in range(len(self.to_rgbs)):
@@ -242,7 +247,34 @@ class Generator(nn.Module):
             lat_idx[self.layers[2 * j + 1].conv] = idx + 1
             lat_idx[self.to_rgbs[j].conv] = idx + 2
             idx += 2
-        return {mc: out[:, lat_idx[mc], o:o + n].contiguous() for mc, (o, n) in c['mod_cols'].items()}
+        order = list(c['mod_cols'].items())
+        key = (B, L, cols, str(out.device))
+        if self._gather_key != key:
+            rows = torch.arange(B, dtype=torch.int64).view(B, 1)
+            pieces = [((rows * L + lat_idx[mc]) * cols + o + torch.arange(n, dtype=torch.int64).view(1, n)).reshape(-1)
+                      for mc, (o, n) in order]
+            self._gather_idx, self._gather_key = torch.cat(pieces).to(out.device), key
+        flat = out.view(-1).index_select(0, self._gather_idx)
+        styles, off = {}, 0
+        for mc, (o, n) in order:
+            styles[mc] = flat[off:off + B * n].view(B, n)
+            off += B * n
+        sq = flat * flat
+        dem = [mc for mc, _ in order if mc.demodulate]
+        dbuf = torch.empty(B * sum(mc.out_channel for mc in dem), device=out.device, dtype=torch.float32)
+        demods, doff, off = {}, 0, 0
+        offs = {}
+        for mc, (o, n) in order:
+            offs[mc] = off
+            off += B * n
+        for mc in dem:
+            n_in, K = c['mod_cols'][mc][1], mc.out_channel
+            d = dbuf[doff:doff + B * K].view(B, 1, 1, K)
+            ops.conv2d_fwd(sq[offs[mc]:offs[mc] + B * n_in].view(B, 1, 1, n_in), c['wsq'][mc], None, K, 1, 1, 1, 0, out=d)
+            demods[mc] = d.view(B, K)
+            doff += B * K
+        torch.rsqrt_(dbuf.add_(1e-8))
+        return styles, demods
 
     # ---- pieces ----------------------------------------------------------------------------------------------
     def _mapping(self, z, c):
@@ -300,13 +332,12 @@ class Generator(nn.Module):
             out = out + up.view(B, C, 2 * H, 2 * W)
         return out
 
-    def _styled_conv(self, layer, x, w_lat, noise, c, s=None):
+    def _styled_conv(self, layer, x, w_lat, noise, c, s=None, demod=None):
         mc = layer.conv
         B, H, W, _ = x.shape
         if s is None:
             s = self._style(mc, w_lat, c)
-        demod = None
-        if mc.demodulate:
+        if mc.demodulate and demod is None:
             wsq = c['wsq'][mc]
             d = ops.conv2d_fwd((s * s).view(B, 1, 1, -1), wsq, None, mc.out_channel, 1, 1, 1, 0).view(B, -1)
             demod = torch.rsqrt(d + 1e-8)
@@ -384,14 +415,14 @@ class Generator(nn.Module):
             if return_latents:
                 return image, latents
             return image
-        st = self._all_styles(latents, c)
-        x = self._styled_conv(self.conv1, x, None, noise[0], c, s=st[self.conv1.conv])
+        st, dm = self._all_styles(latents, c)
+        x = self._styled_conv(self.conv1, x, None, noise[0], c, s=st[self.conv1.conv], demod=dm.get(self.conv1.conv))
         last = len(self.to_rgbs) == 0
         skip = self._to_rgb(self.to_rgb1, x, None, None, c, final=last, s=st[self.to_rgb1.conv])
         for j in range(len(self.to_rgbs)):
             la, lb, tr = self.layers[2 * j], self.layers[2 * j + 1], self.to_rgbs[j]
-            x = self._styled_conv(la, x, None, noise[1 + 2 * j], c, s=st[la.conv])
-            x = self._styled_conv(lb, x, None, noise[2 + 2 * j], c, s=st[lb.conv])
+            x = self._styled_conv(la, x, None, noise[1 + 2 * j], c, s=st[la.conv], demod=dm.get(la.conv))
+            x = self._styled_conv(lb, x, None, noise[2 + 2 * j], c, s=st[lb.conv], demod=dm.get(lb.conv))
             skip = self._to_rgb(tr, x, None, skip, c, final=(j == len(self.to_rgbs) - 1), s=st[tr.conv])
         image = skip                                                                        # 0.5*x+0.5 fused above
         if not self.training:
