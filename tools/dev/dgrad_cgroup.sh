@@ -1,0 +1,13 @@
+#!/bin/bash
+# dev: block order of the strided data gradients: M-tiles per class group (CONTRAD_DGRAD_CGROUP; 8 = default, huge = all
+# heavy classes first = longest-processing-time-first)
+cd $GRAFT_REPO_ROOT
+export CONV_ITERS=20 CONV_WARM=5
+for spec in "64:33,128,256,3,2,0;17,256,512,3,2,0;9,512,512,3,2,0" "192:33,128,256,3,2,0;17,256,512,3,2,0;9,512,512,3,2,0" "16:513,32,64,3,2,0;257,64,128,3,2,0;129,128,256,3,2,0;65,256,512,3,2,0;33,512,512,3,2,0" "48:513,32,64,3,2,0;257,64,128,3,2,0;129,128,256,3,2,0;65,256,512,3,2,0;33,512,512,3,2,0;17,512,512,3,2,0"; do
+  export CONV_BATCH=${spec%%:*} CONV_CUSTOM="${spec#*:}"
+  for g in 8 2 32 1000000; do
+    export CONTRAD_DGRAD_CGROUP=$g
+    echo "== batch $CONV_BATCH cgroup $g"
+    timeout 100 python tools/bench_conv.py 2>&1 | grep "^H" | sed 's/| fwd.*| dgrad/| dgrad/; s/| wgrad.*//'
+  done
+done
