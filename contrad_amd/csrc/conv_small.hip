@@ -132,9 +132,16 @@ __global__ __launch_bounds__(256, RGB_MIN_WAVES) void rgb_conv_wgrad_kernel(RgbW
     stage_halo(lds, h, n, h0);
     __syncthreads();
     const int rows = min(a.TH, a.H - h0);
-    for (int pix = slot; pix < rows * a.W; pix += slots) {
+    const int npix = rows * a.W;
+    // gy is the only stream from HBM here (one float4 per thread and pixel): fetched one iteration ahead, otherwise every
+    // iteration stalls on the full memory latency with only 2 - 4 waves per SIMD to cover it (rocprofv3: 60 % of the
+    // wave cycles waiting, 2.2 TB/s)
+    const float* gbase = a.gy + (size_t)(n * a.H + h0) * a.W * a.ldy + cg * 4;
+    float4 g_next = (slot < npix) ? *reinterpret_cast<const float4*>(gbase + (size_t)slot * a.ldy) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int pix = slot; pix < npix; pix += slots) {
       const int r = pix / a.W, c = pix - r * a.W;
-      const float4 g = *reinterpret_cast<const float4*>(a.gy + ((size_t)(n * a.H + h0 + r) * a.W + c) * a.ldy + cg * 4);
+      const float4 g = g_next;
+      if (pix + slots < npix) g_next = *reinterpret_cast<const float4*>(gbase + (size_t)(pix + slots) * a.ldy);
       accb.x += g.x; accb.y += g.y; accb.z += g.z; accb.w += g.w;
       const f32x2 g01 = {g.x, g.y}, g23 = {g.z, g.w};
 #pragma unroll
@@ -387,13 +394,16 @@ extern "C" int contrad_rgb_conv_fwd(const float* img, const float* wp, const flo
   return 0;
 }
 
-static int rgb_wgrad_grid(int N, int H, int W) {
+static int rgb_wgrad_grid(int N, int H, int W, int k) {
   const int tiles = N * cdiv(H, pick_th(W));
-  return tiles < 512 ? tiles : 512;
+  // resident blocks per CU: 3 for the 3x3 instance (156 VGPRs), 8 for the 1x1 one -- one full round, no ragged second
+  // one (512 blocks = 2 waves per SIMD could not cover the latency of the gy stream: 2.2 TB/s)
+  const int cap = (k == 3) ? 768 : 2048;
+  return tiles < cap ? tiles : cap;
 }
 
 extern "C" long long contrad_rgb_conv_wgrad_workspace_bytes(int N, int Cin, int H, int W, int K, int k) {
-  return (long long)rgb_wgrad_grid(N, H, W) * (k * k * Cin + 1) * K * (long long)sizeof(float);
+  return (long long)rgb_wgrad_grid(N, H, W, k) * (k * k * Cin + 1) * K * (long long)sizeof(float);
 }
 
 extern "C" int contrad_rgb_conv_wgrad(const float* img, const float* gy, float* dwp, float* dbias, int N,
@@ -408,7 +418,7 @@ extern "C" int contrad_rgb_conv_wgrad(const float* img, const float* gy, float* 
   a.img = img; a.gy = gy; a.partial = workspace;
   a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.K = K; a.ldy = ldy; a.k = k; a.pad = k / 2; a.TH = pick_th(W);
   a.in_scale = in_scale; a.in_shift = in_shift;
-  const int grid = rgb_wgrad_grid(N, H, W);
+  const int grid = rgb_wgrad_grid(N, H, W, k);
   size_t smem = (size_t)Cin * (a.TH + 2 * a.pad) * (W + 2 * a.pad) * sizeof(float);
   const size_t red = 256 * sizeof(float4);
   if (smem < red) smem = red;
