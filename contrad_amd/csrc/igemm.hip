@@ -701,11 +701,23 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     for (long long q0 = g0 - (g0 % (64 / R)); q0 < n4; q0 += gstride) {   // (whole waves iterate together: shuffles below)
       const long long q = q0 + (g0 % (64 / R));
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (q < n4)
-        for (int k = r; k < splits; k += R) {
+      if (q < n4) {
+        // four slabs per trip, all four loads issued before the first add: the serial "load, add, load, add" chain was
+        // latency-bound (2.8 TB/s on 54 MB).  Fixed order: ((k, k+R) + (k+2R, k+3R)) per trip, trips in sequence.
+        int k = r;
+        for (; k + 3 * R < splits; k += 4 * R) {
+          const float4 v0 = *reinterpret_cast<const float4*>(ws + (long long)k * total + q * 4);
+          const float4 v1 = *reinterpret_cast<const float4*>(ws + (long long)(k + R) * total + q * 4);
+          const float4 v2 = *reinterpret_cast<const float4*>(ws + (long long)(k + 2 * R) * total + q * 4);
+          const float4 v3 = *reinterpret_cast<const float4*>(ws + (long long)(k + 3 * R) * total + q * 4);
+          s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+          s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; k < splits; k += R) {
           const float4 v = *reinterpret_cast<const float4*>(ws + (long long)k * total + q * 4);
           s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
+      }
       for (int o = R >> 1; o > 0; o >>= 1) {
         s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64);
         s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
