@@ -773,6 +773,7 @@ int launch(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
 }
 
 #include "igemm_lean.h"
+#include "wgrad_c32.h"
 
 template <int MODE, int BM, int BN>
 int launch_lean(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
@@ -1156,6 +1157,7 @@ extern "C" int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm
 extern "C" int contrad_conv2d_path(const contrad_conv_desc* d, int mode) {
   if (check_desc(d) || mode < 0 || mode > 2) return -22;
   if (!vec_ok(d, mode)) return 0;
+  if (mode == MODE_WGRAD && wgrad_c32_ok(d)) return 4;
   long long pps = 0;
   if (mode == MODE_WGRAD) {
     int bm, bn, tm, tn, sp, p;
@@ -1183,6 +1185,7 @@ extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int 
     const int tm_pad = cgroup > 0 ? cdiv(tiles_m, cgroup) * cgroup : tiles_m;
     return (long long)tm_pad * tiles_n * s * s;
   }
+  if (wgrad_c32_ok(d)) return wgrad_c32_blocks(d);
   int bm, bn, tm, tn, splits, pps;
   wgrad_plan(d, &bm, &bn, &tm, &tn, &splits, &pps);
   return (long long)tm * tn * splits;
@@ -1190,6 +1193,8 @@ extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int 
 
 extern "C" long long contrad_conv2d_wgrad_workspace_bytes(const contrad_conv_desc* d) {
   if (check_desc(d)) return -22;
+  if (wgrad_c32_ok(d))
+    return (long long)wgrad_c32_blocks(d) * ((long long)d->KH * d->KW * d->C + 1) * d->K * (long long)sizeof(float);
   int bm, bn, tm, tn, splits, pps;
   wgrad_plan(d, &bm, &bn, &tm, &tn, &splits, &pps);
   return (long long)splits * ((long long)d->KH * d->KW * d->C + 1) * d->K * (long long)sizeof(float);
@@ -1203,6 +1208,23 @@ extern "C" int contrad_conv2d_wgrad(const contrad_conv_desc* d, const float* x, 
   CONTRAD_ARG(x && gy && dwp && workspace);
   if (vec_ok(d, MODE_WGRAD)) CONTRAD_ARG(aligned16(x, gy, workspace));
   CONTRAD_ARG(workspace_bytes >= contrad_conv2d_wgrad_workspace_bytes(d));
+  if (wgrad_c32_ok(d) && aligned16(x, gy, workspace)) {
+    // accumulator-stationary kernel for the 32 -> 32 channel 3x3 layers (wgrad_c32.h): one partial per block, summed
+    // by the same fixed-order reduce as the split-K slabs
+    const int blocks = wgrad_c32_blocks(d);
+    const long long total = (long long)d->KH * d->KW * d->C * d->K;
+    float* bias_ws = dbias ? workspace + (size_t)blocks * total : nullptr;
+    rc = launch_wgrad_c32(d, x, gy, workspace, bias_ws, (hipStream_t)stream);
+    if (rc) return rc;
+    int R = 1;
+    while (R < 64 && R * 2 <= blocks && (total / 4) * R < 65536) R <<= 1;
+    long long rb = ((total / 4) * R + 255) / 256;
+    if (rb > 2048) rb = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)rb), dim3(256), 0, (hipStream_t)stream, workspace, dwp,
+                       d->KH * d->KW * d->C, d->K, d->ldw, blocks, bias_ws, dbias, R);
+    CONTRAD_CHECK_LAUNCH();
+    return 0;
+  }
   int bm, bn, splits, pps;
   IgemmArgs a{};
   wgrad_plan(d, &bm, &bn, &a.tiles_m, &a.tiles_n, &splits, &pps);

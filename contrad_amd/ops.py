@@ -75,6 +75,8 @@ def conv_kernel_name(mode, d):
     bm, bn = ctypes.c_int(0), ctypes.c_int(0)
     lib().call('contrad_conv2d_tile', ctypes.byref(d), mode, ctypes.byref(bm), ctypes.byref(bn))
     path = lib().raw('contrad_conv2d_path')(ctypes.byref(d), mode)
+    if path == 4:
+        return 'wgrad_c32_kernel'
     if path == 2:
         return 'igemm_lean_kernel<%d, %d, %d>' % (mode, bm.value, bn.value)
     return 'igemm_kernel<%d, %d, %d, %s>' % (mode, bm.value, bn.value, 'true' if path == 1 else 'false')

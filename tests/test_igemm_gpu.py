@@ -40,6 +40,8 @@ CASES = [
     (2, 16, 16, 16, 32, 3, 2, 1),      # Cin = 16 -> DGRAD writes a 16-column tile
     (192, 1, 1, 8192, 1536, 1, 1, 0),  # the merged head GEMM at a per-rank batch of 64: split-K forward
     (12, 4, 4, 512, 512, 3, 1, 1),     # deep 3x3 layer at a small batch: split-K forward starting mid-chunk
+    (4, 128, 128, 32, 32, 3, 1, 1),    # 32 -> 32 at >= 64 k positions: the accumulator-stationary WGRAD (wgrad_c32.h)
+    (3, 64, 512, 32, 32, 3, 1, 1),     # ... a non-square map: 3 images x 16 x 16 tiles of 4 x 32, more tiles than one per block
 ]
 
 
