@@ -67,7 +67,10 @@ def test_launch_plans_are_host_logic(built):
         assert built.raw('contrad_conv2d_fwd_workspace_bytes')(ctypes.byref(d)) == 0
     # Cin = 3 / Cout = 1 / 513 channels: general kernel, scalar or float4 gathers
     assert path(ctypes.byref(_desc(8, 32, 3, 64, 3, 1, 1)), 0) == 0
-    assert path(ctypes.byref(_desc(8, 1, 512, 1, 1, 1, 0)), 0) == 0
+    d1 = _desc(8, 1, 512, 1, 1, 1, 0)                      # the 512 -> 1 logit: its own one-wave-per-row kernel forward,
+    assert path(ctypes.byref(d1), 0) == 5                  # the general kernel for its two gradients
+    assert path(ctypes.byref(d1), 1) == 0 and path(ctypes.byref(d1), 2) == 0
+    assert built.raw('contrad_conv2d_grid_blocks')(ctypes.byref(d1), 0, 1) == 2
     assert path(ctypes.byref(_desc(8, 4, 516, 512, 3, 1, 1)), 0) == 1
     # 32-column GEMM (StyleGAN2 at 512x512): the 128x32 tile
     d = _desc(48, 64, 32, 32, 3, 1, 1)

@@ -33,7 +33,11 @@ def test_rows_are_attributed_by_launch_order(tmp_path):
     adam = 'void (anonymous namespace)::adam_kernel((anonymous namespace)::AdamArgs)'
     other = 'upfirdn4_u1d1_kernel(float const*)'
     # two shapes share instance AND workgroup count: only the order tells them apart
-    plain = [(fwd, 768, 100.0), (other, 10, 5.0), (lean, 1008, 200.0), (lean, 1008, 400.0), (adam, 64, 50.0)]
+    # the engine's dedicated kernels (contrad_conv2d_path 4 / 5) are rows of the shape table as well
+    c32 = 'void (anonymous namespace)::wgrad_c32_kernel((anonymous namespace)::WgradC32Args)'
+    k1 = 'void (anonymous namespace)::fwd_k1_kernel(float const*, float const*, long long, int)'
+    plain = [(fwd, 768, 100.0), (other, 10, 5.0), (lean, 1008, 200.0), (lean, 1008, 400.0), (k1, 1, 2.0), (c32, 512, 100.0),
+             (adam, 64, 50.0)]
     r1 = [(fwd, 768, 100.0), (fwd, 256, 30.0), (lean, 1008, 200.0), (lean, 1008, 400.0), (lean, 512, 60.0), (adam, 64, 50.0)]
     cold = [(fwd, 999, 100.0), (adam, 64, 50.0)]
     dbp = str(tmp_path / 'kt.db')
@@ -49,7 +53,9 @@ def test_rows_are_attributed_by_launch_order(tmp_path):
                  'plain_step': {'steps_sampled': 2, 'rows': [], 'sequence': [
                      ['igemm_lean_kernel<0, 128, 128>', [4, 8, 8, 16, 16, 3, 3, 1, 1], 768, 10.0],
                      ['igemm_lean_kernel<2, 128, 128>', [4, 8, 8, 16, 16, 3, 3, 1, 1], 1008, 20.0],
-                     ['igemm_lean_kernel<2, 128, 128>', [4, 4, 4, 32, 32, 3, 3, 1, 1], 1008, 40.0]]}}}
+                     ['igemm_lean_kernel<2, 128, 128>', [4, 4, 4, 32, 32, 3, 3, 1, 1], 1008, 40.0],
+                     ['fwd_k1_kernel', [4, 1, 1, 16, 1, 1, 1, 1, 0], 1, 0.0],
+                     ['wgrad_c32_kernel', [4, 8, 32, 32, 32, 3, 3, 1, 1], 512, 10.0]]}}}
     tp = str(tmp_path / 'shapes.json')
     json.dump(table, open(tp, 'w'))
     buf = io.StringIO()
@@ -58,7 +64,7 @@ def test_rows_are_attributed_by_launch_order(tmp_path):
     out = buf.getvalue()
     assert '5 steps in the trace' in out
     assert 'section r1_step: 5 conv-engine launches per step, 1 trace step(s) matched' in out
-    assert 'section plain_step: 3 conv-engine launches per step, 3 trace step(s) matched' in out
+    assert 'section plain_step: 5 conv-engine launches per step, 3 trace step(s) matched' in out
     assert '1 trace step(s) matched no section' in out and 'step 0: 1 igemm launches' in out
     plain_part = out.split('section plain_step')[1]
     rows = [l.split() for l in plain_part.splitlines() if l.startswith('igemm_lean_kernel<2,128,128>')]
@@ -66,4 +72,5 @@ def test_rows_are_attributed_by_launch_order(tmp_path):
     # 20 GFLOP in 200 us = 100 TF/s; 40 GFLOP in 400 us = 100 TF/s: each shape got ITS dispatches (same instance + grid)
     assert abs(float(by_shape['4,8,8,16,16,3,3,1,1'][5]) - 200.0) < 1e-6 and abs(float(by_shape['4,4,4,32,32,3,3,1,1'][5]) - 400.0) < 1e-6
     assert abs(float(by_shape['4,8,8,16,16,3,3,1,1'][7]) - 100.0) < 0.1 and abs(float(by_shape['4,4,4,32,32,3,3,1,1'][7]) - 100.0) < 0.1
-    assert '70.0 GFLOP per step in 700.0 us of igemm dispatches -> 100.0 TF/s' in plain_part
+    assert '80.0 GFLOP per step in 802.0 us of igemm dispatches' in plain_part
+    assert any(l.startswith('wgrad_c32_kernel') and abs(float(l.split()[5]) - 100.0) < 1e-6 for l in plain_part.splitlines())

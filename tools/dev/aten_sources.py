@@ -71,6 +71,12 @@ def main(name):
             o = out[0] if isinstance(out, (tuple, list)) and out else out
             if torch.is_tensor(o):
                 numel = o.numel()
+            if frame.startswith('<no'):
+                # C++-side op: name the autograd node being evaluated (its own ATen backward, or the engine summing the
+                # gradient contributions of a tensor with several consumers while that node's outputs are routed)
+                node = torch._C._current_autograd_node() if hasattr(torch._C, '_current_autograd_node') else None
+                frame = '<C++ autograd, node %s> shape %s' % (node.name() if node is not None else 'none',
+                                                               tuple(o.shape) if torch.is_tensor(o) else '-')
             k = (nm, frame)
             by[k][0] += 1
             by[k][1] += numel

@@ -27,6 +27,11 @@ def norm(k):
     return re.sub(r'\s+', '', k)
 
 
+# kernels the conv engine's C-ABI entry points launch as their MAIN dispatch (contrad_conv2d_path), i.e. the rows of
+# bench.py's shape table; their reduce kernels are separate trace rows
+CONV_KERNELS = ('igemm', 'wgrad_c32_kernel', 'fwd_k1_kernel')
+
+
 def main(db_path, table_path):
     db = sqlite3.connect(db_path)
     cur = db.cursor()
@@ -39,7 +44,7 @@ def main(db_path, table_path):
     steps, cur_step = [], []
     for name, t0, t1, gx, gy, gz, wx, wy, wz in rows:
         k = norm(short(name))
-        if 'igemm' in k:
+        if any(n in k for n in CONV_KERNELS):
             threads = gx * max(gy, 1) * max(gz, 1)
             wg = max(wx, 1) * max(wy, 1) * max(wz, 1)
             blocks = threads // wg if threads % wg == 0 and threads >= wg else threads     # (grid in work-items)
