@@ -774,6 +774,7 @@ int launch(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
 
 #include "igemm_lean.h"
 #include "wgrad_c32.h"
+#include "conv_c32.h"
 
 template <int MODE, int BM, int BN>
 int launch_lean(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
@@ -1075,6 +1076,8 @@ extern "C" int contrad_conv2d_fwd_add(const contrad_conv_desc* d, const float* x
   const long long M = (long long)d->N * d->Ho * d->Wo;
   CONTRAD_ARG(M < (1ll << 31));
   a.M = (int)M; a.Ncol = d->K; a.Kg = d->KH * d->KW * d->C;
+  if (conv_c32_ok(d) && aligned16(x, wp, y) && aligned16(addend, nullptr, nullptr))   // weight-stationary kernel (conv_c32.h)
+    return launch_conv_c32<MODE_FWD>(d, x, wp, y, bias, addend, nullptr, slope, gain, (hipStream_t)stream);
   if (fwd_k1_ok(d)) {
     hipLaunchKernelGGL(fwd_k1_kernel, dim3((unsigned)cdivll(M, 4)), dim3(256), 0, (hipStream_t)stream, x, wp, M, d->C,
                        d->ldx, d->ldw, bias, slope, gain, y, d->ldy, addend);
@@ -1120,6 +1123,8 @@ extern "C" int contrad_conv2d_dgrad_ws(const contrad_conv_desc* d, const float* 
   if (rc) return rc;
   CONTRAD_ARG(gy && wp && dx);
   if (vec_ok(d, MODE_DGRAD)) CONTRAD_ARG(aligned16(gy, wp, dx) && aligned16(act_ref, nullptr, nullptr));
+  if (conv_c32_ok(d))   // stride-1 pad-1 3x3: the same weight-stationary kernel with the filter mirrored (conv_c32.h)
+    return launch_conv_c32<MODE_DGRAD>(d, gy, wp, dx, nullptr, nullptr, act_ref, slope, gain, (hipStream_t)stream);
   // every input pixel must be covered by at least one tap of its parity class, otherwise the class
   // (whose gradient is exactly zero) still writes zeros: handled by Kg == 0 -> T == 0 -> acc = 0.
   IgemmArgs a{};
@@ -1192,6 +1197,7 @@ extern "C" int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm
 extern "C" int contrad_conv2d_path(const contrad_conv_desc* d, int mode) {
   if (check_desc(d) || mode < 0 || mode > 2) return -22;
   if (mode == MODE_FWD && fwd_k1_ok(d)) return 5;
+  if (mode != MODE_WGRAD && conv_c32_ok(d)) return 6;
   if (!vec_ok(d, mode)) return 0;
   if (mode == MODE_WGRAD && wgrad_c32_ok(d)) return 4;
   long long pps = 0;
@@ -1209,9 +1215,11 @@ extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int 
     const FwdPlan p = fwd_plan(d);
     const long long M = (long long)d->N * d->Ho * d->Wo;
     if (fwd_k1_ok(d)) return cdivll(M, 4);
+    if (conv_c32_ok(d)) return conv_c32_blocks(d);
     return cdivll(M, p.bm) * cdiv(d->K, p.bn) * (with_workspace ? p.splits : 1);
   }
   if (mode == MODE_DGRAD) {
+    if (conv_c32_ok(d)) return conv_c32_blocks(d);
     const int s = d->stride;
     const long long Mc = (long long)d->N * cdiv(d->H, s) * cdiv(d->W, s);
     const FwdPlan p = dgrad_plan(d, with_workspace != 0);

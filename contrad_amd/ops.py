@@ -79,6 +79,8 @@ def conv_kernel_name(mode, d):
         return 'wgrad_c32_kernel'
     if path == 5:
         return 'fwd_k1_kernel'
+    if path == 6:
+        return 'conv_c32_kernel<%d>' % mode
     if path == 2:
         return 'igemm_lean_kernel<%d, %d, %d>' % (mode, bm.value, bn.value)
     return 'igemm_kernel<%d, %d, %d, %s>' % (mode, bm.value, bn.value, 'true' if path == 1 else 'false')

@@ -40,7 +40,7 @@ CASES = [
     (2, 16, 16, 16, 32, 3, 2, 1),      # Cin = 16 -> DGRAD writes a 16-column tile
     (192, 1, 1, 8192, 1536, 1, 1, 0),  # the merged head GEMM at a per-rank batch of 64: split-K forward
     (12, 4, 4, 512, 512, 3, 1, 1),     # deep 3x3 layer at a small batch: split-K forward starting mid-chunk
-    (4, 128, 128, 32, 32, 3, 1, 1),    # 32 -> 32 at >= 64 k positions: the accumulator-stationary WGRAD (wgrad_c32.h)
+    (4, 128, 128, 32, 32, 3, 1, 1),    # 32 -> 32 at >= 64 k positions: weight-stationary FWD / DGRAD (conv_c32.h), accumulator-stationary WGRAD (wgrad_c32.h)
     (3, 64, 512, 32, 32, 3, 1, 1),     # ... a non-square map: 3 images x 16 x 16 tiles of 4 x 32, more tiles than one per block
 ]
 
@@ -97,9 +97,12 @@ def test_conv_fwd_dgrad_wgrad(case):
         assert rel(db.cpu(), gy.sum((0, 2, 3))) < TOL
 
 
-def test_dgrad_fused_activation_derivative():
-    """dgrad epilogue multiplies by lrelu'(act_ref) * gain -- the backward of the producer's activation."""
-    N, H, W, C, K, k, s, p = 4, 8, 8, 64, 64, 3, 1, 1
+@pytest.mark.parametrize('shape', [(4, 8, 8, 64, 64), (4, 128, 128, 32, 32)], ids=['lean', 'conv_c32'])
+def test_dgrad_fused_activation_derivative(shape):
+    """dgrad epilogue multiplies by lrelu'(act_ref) * gain -- the backward of the producer's activation (on the engine's
+    lean loop and on the weight-stationary kernel of the 32 -> 32 channel layers, conv_c32.h)."""
+    N, H, W, C, K = shape
+    k, s, p = 3, 1, 1
     g = torch.Generator().manual_seed(3)
     a = torch.randn(N, C, H, W, generator=g)             # pre-activation of the producer layer
     w = torch.randn(K, C, k, k, generator=g) * 0.1

@@ -29,7 +29,7 @@ def norm(k):
 
 # kernels the conv engine's C-ABI entry points launch as their MAIN dispatch (contrad_conv2d_path), i.e. the rows of
 # bench.py's shape table; their reduce kernels are separate trace rows
-CONV_KERNELS = ('igemm', 'wgrad_c32_kernel', 'fwd_k1_kernel')
+CONV_KERNELS = ('igemm', 'wgrad_c32_kernel', 'fwd_k1_kernel', 'conv_c32_kernel')
 
 
 def main(db_path, table_path):
