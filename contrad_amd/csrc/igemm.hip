@@ -56,6 +56,8 @@ struct IgemmArgs {
   int cgroup;            // lean DGRAD, stride 2: M-tiles per class group of the block order (0: class-interleaved)
   int dsplits;           // lean DGRAD, stride 1: split-K count (grid.y = splits instead of parity classes), else 0 / 1
   long long slab_elems;  // lean DGRAD split-K: floats per partial slab (N * H * W * ldx)
+  int px_pixels;         // lean DGRAD, pixel-major: dx pixels of the largest parity class (tiles_m = image blocks x this)
+  int pixmajor;          // lean FWD / DGRAD: M-tiles are BM images at one output pixel (tiles_m = image blocks x Ho*Wo), padding taps skipped
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -963,7 +965,7 @@ __global__ void fwd_reduce_kernel(const float* __restrict__ ws, int splits, long
 // FWD plan: tile + split-K count from a small cost model (measured rates of the lean tiles, 768 blocks = a full
 // chip, partial slabs priced at 4 TB/s).  Split-K only pays for small-M, deep-K GEMMs: the merged head layer
 // (M = 3N rows, K = 8192) and the last conv layers at small per-rank batches.
-struct FwdPlan { int bm, bn, splits, tps; };
+struct FwdPlan { int bm, bn, splits, tps, pixmajor; };
 
 // tile + split count for a lean GEMM of M x Ncol outputs over t_total K-tiles (shared by FWD and stride-1 DGRAD)
 void split_plan(long long M, int Ncol, int t_total, double flops, FwdPlan* p) {
@@ -997,16 +999,73 @@ bool splitk_enabled() {
   return on;
 }
 
+// Pixel-major M-tiles (igemm_lean.h): worth it on small maps, where a large share of the tap-positions is padding, and
+// possible when a tile's worth of images exists.  frac = share of tap-positions that are NOT padding.
+// Measured at 1536 images (tools/bench_conv.py, forward): 3x3 on 4x4 maps (0.69 of the tap-positions valid) -11 %, 4x4
+// stride-2 onto 4x4 (0.77) -8.5 %; 3x3 on 8x8 (0.84) +-0, 4x4 stride-2 onto 8x8 (0.88) +8 % -- a pixel-major tile reads every
+// input element exactly once (nothing is shared between the rows of a tile any more, the reuse between neighbouring
+// pixels moves from the L1 to the L2), which costs about as much as 15 % of the MFMAs.
+constexpr double PIXMAJOR_MAX_VALID = 0.80;
+
+bool pixmajor_enabled() {
+  static const bool on = []() { const char* e = getenv("CONTRAD_PIXMAJOR"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+double fwd_valid_tap_fraction(const contrad_conv_desc* d) {
+  long long vh = 0, vw = 0;
+  for (int ho = 0; ho < d->Ho; ++ho)
+    for (int kh = 0; kh < d->KH; ++kh) vh += (unsigned)(ho * d->stride - d->pad + kh) < (unsigned)d->H;
+  for (int wo = 0; wo < d->Wo; ++wo)
+    for (int kw = 0; kw < d->KW; ++kw) vw += (unsigned)(wo * d->stride - d->pad + kw) < (unsigned)d->W;
+  return (double)(vh * vw) / ((double)d->Ho * d->Wo * d->KH * d->KW);
+}
+
+bool fwd_pixmajor_ok(const contrad_conv_desc* d, int bm) {
+  if (!pixmajor_enabled() || d->Ho * d->Wo > 256 || d->N < bm) return false;
+  if ((long long)bm * d->H * d->W * d->ldx * 4 >= (1ll << 30)) return false;      // row offsets inside a tile (bytes)
+  if ((long long)bm * d->Ho * d->Wo * d->ldy * 4 >= (1ll << 31)) return false;    // the epilogue's descriptor range
+  return fwd_valid_tap_fraction(d) <= PIXMAJOR_MAX_VALID;
+}
+
+double dgrad_valid_tap_fraction(const contrad_conv_desc* d) {
+  const int s = d->stride;
+  long long valid = 0, all = 0;
+  for (int h = 0; h < d->H; ++h) {
+    long long vh = 0, ah = 0;
+    for (int kh = (h + d->pad) % s; kh < d->KH; kh += s) { ++ah; vh += (unsigned)((h + d->pad - kh) / s) < (unsigned)d->Ho && h + d->pad - kh >= 0; }
+    for (int w = 0; w < d->W; ++w) {
+      long long vw = 0, aw = 0;
+      for (int kw = (w + d->pad) % s; kw < d->KW; kw += s) { ++aw; vw += (unsigned)((w + d->pad - kw) / s) < (unsigned)d->Wo && w + d->pad - kw >= 0; }
+      valid += vh * vw;
+      all += ah * aw;
+    }
+  }
+  return all ? (double)valid / (double)all : 1.0;
+}
+
+bool dgrad_pixmajor_ok(const contrad_conv_desc* d, int bm) {
+  // stride 1 only: the kernel walks pixel-major tiles inside the parity classes of a strided layer just as well (parity
+  // holds, CONTRAD_PIXMAJOR_STRIDED=1), but a class tile then contracts over 1 .. 4 taps only and the 4x4 stride-2
+  // layer onto 4x4 maps ran 0.714 -> 0.757 ms at 1536 images
+  static const bool strided = []() { const char* e = getenv("CONTRAD_PIXMAJOR_STRIDED"); return e && e[0] == '1'; }();
+  if (!pixmajor_enabled() || d->H * d->W > 256 || d->N < bm || (d->stride != 1 && !strided)) return false;
+  if ((long long)bm * d->Ho * d->Wo * d->ldy * 4 >= (1ll << 30)) return false;    // row offsets inside a tile (bytes)
+  if ((long long)bm * d->H * d->W * d->ldx * 4 >= (1ll << 30)) return false;      // the epilogue's row offsets
+  return dgrad_valid_tap_fraction(d) <= PIXMAJOR_MAX_VALID;
+}
+
 FwdPlan fwd_plan(const contrad_conv_desc* d) {
   const long long M = (long long)d->N * d->Ho * d->Wo;
   const bool vec = vec_ok(d, MODE_FWD);
   const bool lean = vec && lean_ok(d, MODE_FWD, 0);
-  FwdPlan p{64, 64, 1, 0};
+  FwdPlan p{64, 64, 1, 0, 0};
   pick_tile(M, d->K, vec, lean, 1, &p.bm, &p.bn);
   const int t_total = d->KH * d->KW * d->C / BK;
   p.tps = t_total;
-  if (!lean || !splitk_enabled() || p.bn == 32 || t_total < 32) return p;
-  split_plan(M, d->K, t_total, 2.0 * (double)M * d->K * d->C * d->KH * d->KW, &p);
+  if (lean && splitk_enabled() && p.bn != 32 && t_total >= 32)
+    split_plan(M, d->K, t_total, 2.0 * (double)M * d->K * d->C * d->KH * d->KW, &p);
+  if (lean && p.splits <= 1 && fwd_pixmajor_ok(d, p.bm)) p.pixmajor = 1;
   return p;
 }
 
@@ -1018,13 +1077,13 @@ FwdPlan dgrad_plan(const contrad_conv_desc* d, bool may_split) {
   const long long Mc = (long long)d->N * cdiv(d->H, s) * cdiv(d->W, s);   // largest class
   const bool vec = vec_ok(d, MODE_DGRAD);
   const bool lean = vec && lean_ok(d, MODE_DGRAD, 0);
-  FwdPlan p{64, 64, 1, 0};
+  FwdPlan p{64, 64, 1, 0, 0};
   pick_tile(Mc, d->C, vec, lean, s * s, &p.bm, &p.bn);
   const int t_total = d->KH * d->KW * d->K / BK;
   p.tps = t_total;
-  if (!may_split || s != 1 || !lean || !splitk_enabled() || p.bn == 32 || t_total < 32 || (d->C & 3) || (d->ldx & 3))
-    return p;
-  split_plan(Mc, d->C, t_total, 2.0 * (double)Mc * d->K * d->C * d->KH * d->KW, &p);
+  if (may_split && s == 1 && lean && splitk_enabled() && p.bn != 32 && t_total >= 32 && !(d->C & 3) && !(d->ldx & 3))
+    split_plan(Mc, d->C, t_total, 2.0 * (double)Mc * d->K * d->C * d->KH * d->KW, &p);
+  if (lean && p.splits <= 1 && dgrad_pixmajor_ok(d, p.bm)) p.pixmajor = 1;
   return p;
 }
 
@@ -1086,7 +1145,9 @@ extern "C" int contrad_conv2d_fwd_add(const contrad_conv_desc* d, const float* x
   }
   const bool vec = vec_ok(d, MODE_FWD);
   const FwdPlan p = fwd_plan(d);
-  a.tiles_m = cdiv(a.M, p.bm); a.tiles_n = cdiv(a.Ncol, p.bn);
+  a.tiles_m = p.pixmajor ? cdiv(d->N, p.bm) * d->Ho * d->Wo : cdiv(a.M, p.bm);
+  a.tiles_n = cdiv(a.Ncol, p.bn);
+  a.pixmajor = p.pixmajor;
   a.ptiles_per_split = p.tps;
   if (p.splits > 1) {
     CONTRAD_ARG(workspace && workspace_bytes >= contrad_conv2d_fwd_workspace_bytes(d));
@@ -1135,7 +1196,10 @@ extern "C" int contrad_conv2d_dgrad_ws(const contrad_conv_desc* d, const float* 
   const bool vec = vec_ok(d, MODE_DGRAD);
   const FwdPlan pl = dgrad_plan(d, workspace != nullptr);
   const int bm = pl.bm, bn = pl.bn;
-  a.tiles_m = cdiv((int)Mc, bm); a.tiles_n = cdiv(d->C, bn);
+  a.pixmajor = pl.pixmajor;
+  a.px_pixels = cdiv(d->H, s) * cdiv(d->W, s);
+  a.tiles_m = pl.pixmajor ? cdiv(d->N, bm) * a.px_pixels : cdiv((int)Mc, bm);
+  a.tiles_n = cdiv(d->C, bn);
   if (pl.splits > 1) {
     // stride-1 split-K: every split writes raw partial sums into its own slab (dx's layout), dgrad_reduce_kernel sums
     // them in a fixed order and applies the fused act' epilogue
@@ -1206,7 +1270,10 @@ extern "C" int contrad_conv2d_path(const contrad_conv_desc* d, int mode) {
     wgrad_plan(d, &bm, &bn, &tm, &tn, &sp, &p);
     pps = p;
   }
-  return lean_ok(d, mode, pps) ? 2 : 1;
+  if (!lean_ok(d, mode, pps)) return 1;
+  if (mode == MODE_FWD && fwd_plan(d).pixmajor) return 3;
+  if (mode == MODE_DGRAD && dgrad_plan(d, true).pixmajor) return 3;
+  return 2;
 }
 
 extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int mode, int with_workspace) {
@@ -1216,6 +1283,7 @@ extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int 
     const long long M = (long long)d->N * d->Ho * d->Wo;
     if (fwd_k1_ok(d)) return cdivll(M, 4);
     if (conv_c32_ok(d)) return conv_c32_blocks(d);
+    if (p.pixmajor) return (long long)cdiv(d->N, p.bm) * d->Ho * d->Wo * cdiv(d->K, p.bn);
     return cdivll(M, p.bm) * cdiv(d->K, p.bn) * (with_workspace ? p.splits : 1);
   }
   if (mode == MODE_DGRAD) {
@@ -1223,7 +1291,8 @@ extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int 
     const int s = d->stride;
     const long long Mc = (long long)d->N * cdiv(d->H, s) * cdiv(d->W, s);
     const FwdPlan p = dgrad_plan(d, with_workspace != 0);
-    const int tiles_m = cdiv((int)Mc, p.bm), tiles_n = cdiv(d->C, p.bn);
+    const int tiles_m = p.pixmajor ? cdiv(d->N, p.bm) * cdiv(d->H, s) * cdiv(d->W, s) : cdiv((int)Mc, p.bm);
+    const int tiles_n = cdiv(d->C, p.bn);
     if (p.splits > 1) return (long long)tiles_m * tiles_n * p.splits;
     static const int g = []() { const char* e = getenv("CONTRAD_DGRAD_CGROUP"); return e ? atoi(e) : 8; }();
     const int cgroup = (s > 1) ? (g < tiles_m ? g : tiles_m) : 0;

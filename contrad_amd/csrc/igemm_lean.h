@@ -110,6 +110,12 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
 
   int M = p.M, Ncol = p.Ncol;
   int T = 0;                       // K-tiles this block contracts over
+  // pixel-major tiles (p.pixmajor, small maps): the rows of an M-tile are BM IMAGES at ONE output pixel, so "this tap is
+  // padding" is the same for every row and the K walk simply skips such taps (a 3x3 pad-1 layer on a 4x4 map multiplies
+  // zeros in 31 % of its tap-positions, a 4x4 stride-2 layer onto 4x4 in 23 %)
+  unsigned tapmask = 0xFFFFFFFFu;  // taps the walk visits (wave-uniform)
+  long long px_off = 0;            // pixel-major: element offset of row 0 of the tile in the output, its row pitch, rows
+  int px_pitch = 0, px_rows = 0;
   const float* baseA = p.A;        // descriptor bases (block-relative, so byte offsets stay far below 2^31)
   const float* baseB = p.B;
   unsigned va[PA], vb[PB];         // per-thread byte offsets (fixed)
@@ -135,11 +141,39 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     u_a = u_tap / d.KW;
     u_b = u_tap - u_a * d.KW;
     const int HoWo = d.Ho * d.Wo;
+    if (p.pixmajor) {
+      // tile_m = image block * Ho*Wo + pixel: neighbouring blocks read the same BM images
+      const int ib = tile_m / HoWo, pix = tile_m - ib * HoWo;
+      const int ho = pix / d.Wo, wo = pix - ho * d.Wo;
+      const int n_first = ib * BM;
+      unsigned wmask = 0, valid = 0;
+      for (int kw = 0; kw < d.KW; ++kw) wmask |= ((unsigned)(wo * d.stride - d.pad + kw) < (unsigned)d.W ? 1u : 0u) << kw;
+      for (int kh = 0; kh < d.KH; ++kh)
+        if ((unsigned)(ho * d.stride - d.pad + kh) < (unsigned)d.H) valid |= wmask << (kh * d.KW);
+      tapmask = valid ? valid : 0xFFFFFFFFu;   // (no tap at all: T = 0, the walk must still terminate)
+      T = __builtin_popcount(valid) * (d.C / BK);
+      u_tap = valid ? __builtin_ctz(valid) : 0;
+      u_a = u_tap / d.KW;
+      u_b = u_tap - u_a * d.KW;
+      u_c0 = 0;
+      baseA = p.A + ((long long)n_first * d.H * d.W + (long long)(ho * d.stride - d.pad) * d.W + (wo * d.stride - d.pad)) * d.ldx;
+      const int img = d.H * d.W * d.ldx;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int r = qrow + 64 * i;
+        va[i] = (unsigned)((r * img + kq * 4) * 4);
+        inv[i] = (n_first + r < d.N) ? 0u : 0xFFFFFFFFu;
+      }
+      px_off = ((long long)n_first * HoWo + pix) * d.ldy;
+      px_pitch = HoWo * d.ldy;
+      px_rows = min(BM, d.N - n_first);
+    }
     const int sh_w = pow2_shift(d.Wo), sh_h = pow2_shift(d.Ho);
     const int n_first = (sh_w >= 0 && sh_h >= 0) ? (m0 >> (sh_w + sh_h)) : m0 / HoWo;
-    baseA = p.A + ((long long)n_first * d.H * d.W - (d.pad * d.W + d.pad)) * d.ldx;
+    if (!p.pixmajor) baseA = p.A + ((long long)n_first * d.H * d.W - (d.pad * d.W + d.pad)) * d.ldx;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
+      if (p.pixmajor) break;
       const int m = m0 + qrow + 64 * i;
       const bool ok = m < M;
       const int mm = ok ? m : m0;
@@ -186,13 +220,44 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
       u_b = u_tap - u_a * ntw;
     }
     if (ntw == 0) ntw = 1;
-    if (m0 >= M) return;  // uniform per block, before any barrier
     const int HcWc = Hc * Wc;
+    if (p.pixmajor) {
+      // tile_m = image block * (pixels of the largest class) + pixel of this class: BM images at ONE dx pixel
+      const int ib = tile_m / p.px_pixels, cpix = tile_m - ib * p.px_pixels;
+      if (cpix >= HcWc) return;   // uniform per block, before any barrier
+      const int hq = cpix / Wc, wq = cpix - hq * Wc;
+      const int ah = hq + bh, aw = wq + bw;
+      const int n_first = ib * BM;
+      unsigned wmask = 0, valid = 0;
+      for (int tw = 0; tw < ntw; ++tw) wmask |= ((unsigned)(aw - tw) < (unsigned)d.Wo ? 1u : 0u) << tw;
+      for (int th = 0; th < nth; ++th)
+        if ((unsigned)(ah - th) < (unsigned)d.Ho) valid |= wmask << (th * ntw);
+      tapmask = valid ? valid : 0xFFFFFFFFu;
+      T = __builtin_popcount(valid) * (d.K / BK);
+      u_tap = valid ? __builtin_ctz(valid) : 0;
+      u_a = u_tap / ntw;
+      u_b = u_tap - u_a * ntw;
+      u_c0 = 0;
+      M = d.N;
+      baseA = p.A + ((long long)n_first * d.Ho * d.Wo + (long long)(ah - (nth - 1)) * d.Wo + (aw - (ntw - 1))) * d.ldy;
+      const int img = d.Ho * d.Wo * d.ldy;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int r = qrow + 64 * i;
+        va[i] = (unsigned)((r * img + kq * 4) * 4);
+        inv[i] = (n_first + r < d.N) ? 0u : 0xFFFFFFFFu;
+      }
+      px_off = ((long long)n_first * d.H * d.W + (long long)(hq * s + ph) * d.W + (wq * s + pw)) * d.ldx;
+      px_pitch = d.H * d.W * d.ldx;
+      px_rows = min(BM, d.N - n_first);
+    }
+    if (!p.pixmajor && m0 >= M) return;  // uniform per block, before any barrier
     const int sh_w = pow2_shift(Wc), sh_h = pow2_shift(Hc);
     const int n_first = (sh_w >= 0 && sh_h >= 0) ? (m0 >> (sh_w + sh_h)) : m0 / HcWc;
-    baseA = p.A + ((long long)n_first * d.Ho * d.Wo - ((nth - 1) * d.Wo + (ntw - 1))) * d.ldy;
+    if (!p.pixmajor) baseA = p.A + ((long long)n_first * d.Ho * d.Wo - ((nth - 1) * d.Wo + (ntw - 1))) * d.ldy;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
+      if (p.pixmajor) break;
       const int m = m0 + qrow + 64 * i;
       const bool ok = m < M;
       const int mm = ok ? m : m0;
@@ -282,11 +347,15 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
       // same few input pixels (64 B each) in consecutive tiles -> L1/L2 hits; tap-major order swept the block's whole
       // input window (all channels) once per tap, 128 blocks per XCD x ~100 KB did not fit the 4 MB L2, and the
       // kernel fetched 5x its algorithmic bytes from HBM.
-      ++u_tap; ++u_b;
-      if (u_b == d.KW) { u_b = 0; ++u_a; if (u_a == d.KH) { u_a = 0; u_tap = 0; u_c0 += BK; } }
+      do {   // (pixel-major tiles: on to the next tap that is not padding; otherwise every tap is visited)
+        ++u_tap; ++u_b;
+        if (u_b == d.KW) { u_b = 0; ++u_a; if (u_a == d.KH) { u_a = 0; u_tap = 0; u_c0 += BK; } }
+      } while (!((tapmask >> u_tap) & 1u));
     } else if constexpr (MODE == MODE_DGRAD) {
-      ++u_tap; ++u_b;
-      if (u_b == ntw) { u_b = 0; ++u_a; if (u_a == nth) { u_a = 0; u_tap = 0; u_c0 += BK; } }
+      do {
+        ++u_tap; ++u_b;
+        if (u_b == ntw) { u_b = 0; ++u_a; if (u_a == nth) { u_a = 0; u_tap = 0; u_c0 += BK; } }
+      } while (!((tapmask >> u_tap) & 1u));
     } else {
       u_w += gw;
       if (u_w == d.Wo) { u_w = 0; u_h += gh; if (u_h == d.Ho) { u_h = 0; u_n += gn; } }
@@ -471,7 +540,9 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     if (tid < BM) {
       const int m = m0 + tid;
       unsigned off = 2u * COL_OOB;
-      if (m < M) {
+      if (p.pixmajor) {
+        if (tid < px_rows) off = (unsigned)(tid * px_pitch) * 4u;
+      } else if (m < M) {
         int wq, t2, hq, n;
         divmod_u(m, Wc, sh_w, t2, wq);
         divmod_u(t2, Hc, sh_h, n, hq);
@@ -480,7 +551,8 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
       rowoff[tid] = off;
     }
     __syncthreads();
-    const size_t img0 = (size_t)n_first * d.H * d.W * d.ldx + (p.dsplits > 1 ? (size_t)by * (size_t)p.slab_elems : 0);
+    const size_t img0 = p.pixmajor ? (size_t)px_off
+                                   : (size_t)n_first * d.H * d.W * d.ldx + (p.dsplits > 1 ? (size_t)by * (size_t)p.slab_elems : 0);
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C + img0, 0, (int)COL_OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsR =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.act_ref ? p.act_ref + img0 : p.C + img0), 0,
@@ -504,16 +576,18 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
       }
   } else {
     const bool slab = (MODE == MODE_WGRAD) || p.ny > 1;              // split-K partial slab [split][M][Ncol]
-    const int pitch = slab ? Ncol : d.ldy;
-    float* outp = p.C + (slab ? (size_t)by * M * Ncol : (size_t)0) + (size_t)m0 * pitch;
-    const int rows_here = min(BM, M - m0);
+    const bool pxm = (MODE == MODE_FWD) && p.pixmajor;               // rows = images at one pixel: pitch = one image of y
+    const int pitch = pxm ? px_pitch : (slab ? Ncol : d.ldy);
+    const size_t out_off = pxm ? (size_t)px_off : (slab ? (size_t)by * M * Ncol : (size_t)0) + (size_t)m0 * pitch;
+    float* outp = p.C + out_off;
+    const int rows_here = pxm ? px_rows : min(BM, M - m0);
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(outp, 0, rows_here * pitch * 4, 0x00020000);
     const int wave_row = __builtin_amdgcn_readfirstlane(wm * WM);
     const float g1 = p.gain, g0 = p.gain * p.slope;
     // FWD residual merge: y = act(conv + bias) + addend, addend in y's own layout (same descriptor geometry)
     const bool has_add = (MODE == MODE_FWD) && !slab && p.addend != nullptr;                 // uniform
     const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(has_add ? p.addend + (size_t)m0 * pitch : outp), 0, has_add ? rows_here * pitch * 4 : 0, 0x00020000);
+        const_cast<float*>(has_add ? p.addend + out_off : outp), 0, has_add ? rows_here * pitch * 4 : 0, 0x00020000);
     unsigned lanepart[TN];
     float bj[TN];
 #pragma unroll

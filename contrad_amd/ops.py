@@ -81,7 +81,7 @@ def conv_kernel_name(mode, d):
         return 'fwd_k1_kernel'
     if path == 6:
         return 'conv_c32_kernel<%d>' % mode
-    if path == 2:
+    if path in (2, 3):
         return 'igemm_lean_kernel<%d, %d, %d>' % (mode, bm.value, bn.value)
     return 'igemm_kernel<%d, %d, %d, %s>' % (mode, bm.value, bn.value, 'true' if path == 1 else 'false')
 

@@ -60,7 +60,11 @@ def test_launch_plans_are_host_logic(built):
     for (H, C, K, k, s, p) in _SNDCGAN:
         d = _desc(1536, H, C, K, k, s, p)
         for mode in (0, 1, 2):
-            assert path(ctypes.byref(d), mode) == 2, (H, C, K, mode)
+            # lean loop; forward (and stride-1 data gradient) of the two layers onto 4 x 4 maps on pixel-major tiles (31 % /
+            # 23 % of their tap-positions are padding, which those tiles skip)
+            Ho = (H + 2 * p - k) // s + 1
+            want = 3 if (Ho == 4 and (mode == 0 or (mode == 1 and s == 1))) else 2      # (data gradient: stride 1 only)
+            assert path(ctypes.byref(d), mode) == want, (H, C, K, mode)
             assert tile(ctypes.byref(d), mode, ctypes.byref(bm), ctypes.byref(bn)) == 0
             want_bn = 64 if (mode == 1 and C == 64) else 128        # dgrad's columns are the input channels
             assert (bm.value, bn.value) == (128, want_bn), (H, C, K, mode, bm.value, bn.value)

@@ -1,6 +1,8 @@
 """GPU parity: implicit-GEMM conv engine (fwd / dgrad / wgrad) through the C ABI vs PyTorch-CPU fp32
 (the reference's arithmetic for F.conv2d / F.linear / ConvTranspose2d lives in PyTorch).
 Tolerance: 1e-3 relative to the tensor's max magnitude (north_star), typically ~1e-6 observed."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -41,6 +43,10 @@ CASES = [
     (192, 1, 1, 8192, 1536, 1, 1, 0),  # the merged head GEMM at a per-rank batch of 64: split-K forward
     (12, 4, 4, 512, 512, 3, 1, 1),     # deep 3x3 layer at a small batch: split-K forward starting mid-chunk
     (4, 128, 128, 32, 32, 3, 1, 1),    # 32 -> 32 at >= 64 k positions: weight-stationary FWD / DGRAD (conv_c32.h), accumulator-stationary WGRAD (wgrad_c32.h)
+    (130, 4, 4, 32, 64, 3, 1, 1),      # pixel-major tiles (>= one tile of images on a small map): ragged last image block
+    (130, 8, 8, 16, 64, 4, 2, 1),      # ... with the 4x4 stride-2 kernel (4x4 output map); its data gradient: pixel-major inside the parity classes
+    (130, 5, 7, 16, 64, 3, 2, 1),      # ... odd map, 3x3 stride 2: parity classes of different sizes (3x4, 3x3, 2x4, 2x3 pixels)
+    (200, 2, 6, 32, 48, 3, 1, 1),      # ... a 2 x 6 map: most taps of most pixels are padding
     (3, 64, 512, 32, 32, 3, 1, 1),     # ... a non-square map: 3 images x 16 x 16 tiles of 4 x 32, more tiles than one per block
 ]
 
@@ -87,6 +93,11 @@ def test_conv_fwd_dgrad_wgrad(case):
     gy_nhwc = gy.permute(0, 2, 3, 1).contiguous().to(dev)
     dx = ops.conv2d_dgrad(gy_nhwc, wp, (N, H, W, C), k, k, s, p)
     assert rel(dx.permute(0, 3, 1, 2).cpu(), gx_ref) < TOL
+    if os.environ.get('CONTRAD_TEST_EXPECT_DGRAD_PATH'):      # (set by the subprocess test below)
+        import ctypes
+        from contrad_amd import _lib
+        d = ops.make_desc(N, H, W, C, K, k, k, s, p, C, K, wp.stride(0))
+        assert _lib.lib().raw('contrad_conv2d_path')(ctypes.byref(d), 1) == int(os.environ['CONTRAD_TEST_EXPECT_DGRAD_PATH'])
 
     fused_bias = (C % 4 == 0 and K % 4 == 0)
     db = torch.zeros(K, device=dev) if fused_bias else None
@@ -95,6 +106,20 @@ def test_conv_fwd_dgrad_wgrad(case):
     assert rel(dw, gw_ref) < TOL
     if fused_bias:      # bias gradient accumulated from the gy tiles the wgrad kernel streams anyway
         assert rel(db.cpu(), gy.sum((0, 2, 3))) < TOL
+
+
+def test_strided_pixel_major_dgrad_in_a_fresh_process():
+    """The launch plan keeps strided data gradients off the pixel-major tiles (slower on the 4x4 stride-2 layer), but the
+    kernel walks them inside the parity classes all the same: forced on (the switch is read once per process), the
+    4x4 stride-2 and the odd-map 3x3 stride-2 cases must still match the fp32 reference."""
+    import subprocess
+    import sys
+    env = dict(os.environ, CONTRAD_PIXMAJOR_STRIDED='1', CONTRAD_TEST_EXPECT_DGRAD_PATH='3')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-m', 'gpu', '-x', '-k',
+                        '130x8x8x16x64x4x2x1'], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert '1 passed' in r.stdout
 
 
 @pytest.mark.parametrize('shape', [(4, 8, 8, 64, 64), (4, 128, 128, 32, 32)], ids=['lean', 'conv_c32'])

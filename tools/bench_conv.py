@@ -49,12 +49,13 @@ def main(B=int(os.environ.get('CONV_BATCH', '1536'))):
     only = os.environ.get('CONV_LAYERS')
     layers = LAYERS if not only else [LAYERS[int(i)] for i in only.split(',')]
     for (H, C, K, k, s, p) in layers:
-        x = torch.randn(B, H, H, C, device=dev)
+        pad = int(os.environ.get('CONV_LDPAD', '0'))     # dev: channel pitch = channels + pad (an image is then not 2^k bytes)
+        x = torch.randn(B, H, H, C + pad, device=dev)[..., :C]
         wp = torch.randn(k * k * C, K, device=dev) * 0.05
         Ho = ops.out_size(H, k, s, p)
-        gy = torch.randn(B, Ho, Ho, K, device=dev)
-        y = torch.empty(B, Ho, Ho, K, device=dev)
-        dx = torch.empty_like(x)
+        gy = torch.randn(B, Ho, Ho, K + pad, device=dev)[..., :K]
+        y = torch.empty(B, Ho, Ho, K + pad, device=dev)[..., :K]
+        dx = torch.empty(B, H, H, C + pad, device=dev)[..., :C]
         dw = torch.empty_like(wp)
         flops = 2.0 * B * Ho * Ho * K * C * k * k
         t_f = timeit(lambda: ops.conv2d_fwd(x, wp, None, K, k, k, s, p, 0.1, 1.0, out=y))
