@@ -1006,6 +1006,9 @@ bool splitk_enabled() {
 // input element exactly once (nothing is shared between the rows of a tile any more, the reuse between neighbouring
 // pixels moves from the L1 to the L2), which costs about as much as 15 % of the MFMAs.
 constexpr double PIXMAJOR_MAX_VALID = 0.80;
+// WGRAD streams its operands either way (no reuse inside a K-tile to lose), so it pays earlier: 3x3 on 4x4 maps -21 %, 4x4
+// stride-2 onto 4x4 -10 %, 3x3 on 8x8 (0.84 valid) -8 %; 4x4 stride-2 onto 8x8 (0.88) +3 %, 3x3 on 16x16 (0.92) +-0.
+constexpr double PIXMAJOR_WGRAD_MAX_VALID = 0.85;
 
 bool pixmajor_enabled() {
   static const bool on = []() { const char* e = getenv("CONTRAD_PIXMAJOR"); return !(e && e[0] == '0'); }();
@@ -1053,6 +1056,16 @@ bool dgrad_pixmajor_ok(const contrad_conv_desc* d, int bm) {
   if ((long long)bm * d->Ho * d->Wo * d->ldy * 4 >= (1ll << 30)) return false;    // row offsets inside a tile (bytes)
   if ((long long)bm * d->H * d->W * d->ldx * 4 >= (1ll << 30)) return false;      // the epilogue's row offsets
   return dgrad_valid_tap_fraction(d) <= PIXMAJOR_MAX_VALID;
+}
+
+// WGRAD on pixel-major positions (igemm_lean.h): a K-tile is 16 images at one output pixel, and a row tile that lies
+// inside one filter tap skips the K-tiles whose pixel is padding for that tap.  Same threshold as FWD / DGRAD.
+bool wgrad_pixmajor_ok(const contrad_conv_desc* d, int bm, long long pps) {
+  if (!pixmajor_enabled() || !vec_ok(d, MODE_WGRAD) || !lean_ok(d, MODE_WGRAD, pps)) return false;
+  if (bm != 128 || (d->C % 128) != 0 || (d->N % 16) != 0 || d->Ho < 2 || d->Wo < 2 || d->Ho * d->Wo > 256) return false;
+  if (d->pad > d->stride) return false;                                  // interior pixels must never touch padding
+  static const double lim = []() { const char* e = getenv("CONTRAD_PIXMAJOR_WGRAD_MAX"); return e ? atof(e) : PIXMAJOR_WGRAD_MAX_VALID; }();  // dev
+  return fwd_valid_tap_fraction(d) <= lim;
 }
 
 FwdPlan fwd_plan(const contrad_conv_desc* d) {
@@ -1273,6 +1286,11 @@ extern "C" int contrad_conv2d_path(const contrad_conv_desc* d, int mode) {
   if (!lean_ok(d, mode, pps)) return 1;
   if (mode == MODE_FWD && fwd_plan(d).pixmajor) return 3;
   if (mode == MODE_DGRAD && dgrad_plan(d, true).pixmajor) return 3;
+  if (mode == MODE_WGRAD) {
+    int bm, bn, tm, tn, sp, p;
+    wgrad_plan(d, &bm, &bn, &tm, &tn, &sp, &p);
+    if (wgrad_pixmajor_ok(d, bm, p)) return 3;
+  }
   return 2;
 }
 
@@ -1350,6 +1368,7 @@ extern "C" int contrad_conv2d_wgrad(const contrad_conv_desc* d, const float* x, 
   const long long P = (long long)d->N * d->Ho * d->Wo;
   CONTRAD_ARG(P < (1ll << 31) - 4096);
   a.P = (int)P; a.ptiles_per_split = pps;
+  a.pixmajor = wgrad_pixmajor_ok(d, bm, pps) ? 1 : 0;
   rc = dispatch<MODE_WGRAD>(a, bm, bn, vec_ok(d, MODE_WGRAD), dim3(a.tiles_m * a.tiles_n, splits),
                             (hipStream_t)stream);
   if (rc) return rc;

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
   // padding" is the same for every row and the K walk simply skips such taps (a 3x3 pad-1 layer on a 4x4 map multiplies
   // zeros in 31 % of its tap-positions, a 4x4 stride-2 layer onto 4x4 in 23 %)
   unsigned tapmask = 0xFFFFFFFFu;  // taps the walk visits (wave-uniform)
+  unsigned wskip = 0;              // WGRAD pixel-major: border bits at which this tile's K-tiles are skipped
   long long px_off = 0;            // pixel-major: element offset of row 0 of the tile in the output, its row pitch, rows
   int px_pitch = 0, px_rows = 0;
   const float* baseA = p.A;        // descriptor bases (block-relative, so byte offsets stay far below 2^31)
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     if (T < 0) T = 0;
     gw = min(d.Wo, 16);
     gh = min(d.Ho, 16 / gw);
+    if (p.pixmajor) { gw = 1; gh = 1; }   // pixel-major positions: a K-tile is 16 IMAGES at one output pixel
     gn = 16 / (gw * gh);
     const int tpr = d.Wo / gw, tpi = tpr * (d.Ho / gh);   // patches per output row / per image
     u_w = (t_begin % tpr) * gw;
@@ -291,7 +293,31 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     u_n = (t_begin / tpi) * gn;
     n_begin = u_n;
     baseA = p.A + ((long long)n_begin * d.H * d.W - (d.pad * d.W + d.pad)) * d.ldx;
-    baseB = p.B + (long long)t_begin * BK * d.ldy;
+    baseB = p.pixmajor ? p.B + (long long)n_begin * d.Ho * d.Wo * d.ldy : p.B + (long long)t_begin * BK * d.ldy;
+    if (p.pixmajor) {
+      // Every row of this tile belongs to ONE filter tap (the plan guarantees C % BM == 0), so "the tap reads padding at
+      // this pixel" holds for the whole K-tile: such K-tiles are not visited at all.  wskip = the borders (bits as in
+      // inv / edge) at which this tile's tap is padding.  The blocks that also sum the bias gradient visit everything.
+      const int tap0 = m0 / d.C;
+      const int kh = tap0 / d.KW, kw = tap0 - kh * d.KW;
+      const int chh = kh - d.pad, cww = kw - d.pad;
+      const int hb = (d.Ho - 1) * d.stride, wb = (d.Wo - 1) * d.stride;
+      wskip = ((unsigned)chh < (unsigned)d.H ? 0u : 1u) | ((unsigned)(hb + chh) < (unsigned)d.H ? 0u : 2u) |
+              ((unsigned)cww < (unsigned)d.W ? 0u : 4u) | ((unsigned)(wb + cww) < (unsigned)d.W ? 0u : 8u);
+      if (p.bias_ws != nullptr && tile_m == 0) wskip = 0;
+      int hh = u_h, ww = u_w, cnt = 0, first = -1;
+      for (int q = 0; q < T; ++q) {            // scalar: <= a few hundred patches per split
+        const unsigned e = (hh == 0 ? 1u : 0u) | (hh == d.Ho - 1 ? 2u : 0u) | (ww == 0 ? 4u : 0u) | (ww == d.Wo - 1 ? 8u : 0u);
+        if (!(wskip & e)) { ++cnt; if (first < 0) first = q; }
+        if (++ww == d.Wo) { ww = 0; if (++hh == d.Ho) hh = 0; }
+      }
+      T = cnt;
+      if (cnt == 0) wskip = 0;                 // (nothing to visit: the walk must still terminate)
+      for (int q = 0; q < first; ++q) {        // on to the first K-tile this block visits
+        u_w += 1;
+        if (u_w == d.Wo) { u_w = 0; u_h += 1; if (u_h == d.Ho) { u_h = 0; u_n += gn; } }
+      }
+    }
     const int ic = m0 + a_c4 * 4;
     const bool colok = ic < p.Kg;
     const int icc = colok ? ic : 0;
@@ -311,7 +337,8 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       const int col = n0 + b_c4 * 4;
-      vb[i] = (col < Ncol && b_r + B_RPP * i < BK) ? (unsigned)((((b_r + B_RPP * i) * d.ldy) + col) * 4) : LEAN_OOB;
+      const int rowpitch = p.pixmajor ? d.Ho * d.Wo * d.ldy : d.ldy;      // pixel-major: the 16 rows are 16 images
+      vb[i] = (col < Ncol && b_r + B_RPP * i < BK) ? (unsigned)((((b_r + B_RPP * i) * rowpitch) + col) * 4) : LEAN_OOB;
     }
   }
 
@@ -336,7 +363,8 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
       soffB = (unsigned)((tapflat * d.C * d.ldw + u_c0) * 4);
     } else {
       soffA = (unsigned)(((((u_n - n_begin) * d.H + u_h * d.stride) * d.W + u_w * d.stride) * d.ldx) * 4);
-      soffB = (unsigned)(t_next * BK * d.ldy * 4);
+      soffB = p.pixmajor ? (unsigned)((((u_n - n_begin) * d.Ho + u_h) * d.Wo + u_w) * d.ldy * 4)
+                         : (unsigned)(t_next * BK * d.ldy * 4);
       edge = (u_h == 0 ? 1u : 0u) | (u_h == d.Ho - gh ? 2u : 0u) | (u_w == 0 ? 4u : 0u) | (u_w == d.Wo - gw ? 8u : 0u);
     }
   };
@@ -357,8 +385,12 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
         if (u_b == ntw) { u_b = 0; ++u_a; if (u_a == nth) { u_a = 0; u_tap = 0; u_c0 += BK; } }
       } while (!((tapmask >> u_tap) & 1u));
     } else {
-      u_w += gw;
-      if (u_w == d.Wo) { u_w = 0; u_h += gh; if (u_h == d.Ho) { u_h = 0; u_n += gn; } }
+      unsigned e;
+      do {   // (pixel-major: on to the next K-tile whose pixel is not padding for this tile's tap)
+        u_w += gw;
+        if (u_w == d.Wo) { u_w = 0; u_h += gh; if (u_h == d.Ho) { u_h = 0; u_n += gn; } }
+        e = (u_h == 0 ? 1u : 0u) | (u_h == d.Ho - gh ? 2u : 0u) | (u_w == 0 ? 4u : 0u) | (u_w == d.Wo - gw ? 8u : 0u);
+      } while (wskip & e);
     }
   };
   auto load_a_piece = [&](int i) {

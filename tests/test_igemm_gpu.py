@@ -46,6 +46,8 @@ CASES = [
     (130, 4, 4, 32, 64, 3, 1, 1),      # pixel-major tiles (>= one tile of images on a small map): ragged last image block
     (130, 8, 8, 16, 64, 4, 2, 1),      # ... with the 4x4 stride-2 kernel (4x4 output map); its data gradient: pixel-major inside the parity classes
     (130, 5, 7, 16, 64, 3, 2, 1),      # ... odd map, 3x3 stride 2: parity classes of different sizes (3x4, 3x3, 2x4, 2x3 pixels)
+    (144, 4, 4, 128, 64, 3, 1, 1),     # ... weight gradient on pixel-major positions (K-tiles = 16 images at one pixel, padding ones skipped)
+    (144, 8, 8, 128, 96, 4, 2, 1),     # ... the same with the 4x4 stride-2 kernel, ragged column tile
     (200, 2, 6, 32, 48, 3, 1, 1),      # ... a 2 x 6 map: most taps of most pixels are padding
     (3, 64, 512, 32, 32, 3, 1, 1),     # ... a non-square map: 3 images x 16 x 16 tiles of 4 x 32, more tiles than one per block
 ]
