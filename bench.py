@@ -225,8 +225,8 @@ def _write_shape_table(path, name, cfg, warm_prof, marks, n_local):
         d = sections.setdefault(sec, {'steps': 0, 'rows': {}})
         d['steps'] += 1
         # the launch ORDER of one step: rocpd_rows.py aligns the trace's igemm dispatches of a step with it
-        d['sequence'] = [[q[0], list(q[4]), q[5], round(q[1] / 1e9, 4)] for q in warm_prof[marks[i]:marks[i + 1]]]
-        for kname, flops, e0, e1, shape, blocks in warm_prof[marks[i]:marks[i + 1]]:
+        d['sequence'] = [[q[0], list(q[4]), q[5], round(q[1] / 1e9, 4), round(q[6], 4)] for q in warm_prof[marks[i]:marks[i + 1]]]
+        for kname, flops, e0, e1, shape, blocks, _executed in warm_prof[marks[i]:marks[i + 1]]:
             r = d['rows'].setdefault((kname, shape, blocks), [0, 0.0, flops])
             r[0] += 1
             r[1] += e0.elapsed_time(e1)
@@ -242,7 +242,7 @@ def _write_shape_table(path, name, cfg, warm_prof, marks, n_local):
                          'bracket_us': round(ms / cnt * 1e3, 2), 'bracket_tflops': round(flops * cnt / (ms * 1e-3) / 1e12, 2)})
         rows.sort(key=lambda r: -r['gflop_per_launch'] * r['launches_per_step'])
         out['sections'][sec] = {'steps_sampled': d['steps'], 'rows': rows, 'sequence': d['sequence'],
-                                'sequence_fields': ['kernel', 'shape', 'grid_blocks', 'gflop']}
+                                'sequence_fields': ['kernel', 'shape', 'grid_blocks', 'gflop', 'executed_share']}
     with open(path, 'w') as f:
         json.dump(out, f, indent=1)
 
@@ -343,11 +343,12 @@ def run_config(name, args, world, rank, dev, multi):
     ops.PROFILE = []
     wsteps = max(1, warmup // 2)                                     # the later half of the warm-up (clocks ramped)
     wagg = {}
-    for kname, flops, e0, e1 in (q[:4] for q in warm_prof[marks[max(0, warmup - wsteps)]:]):
-        a = wagg.setdefault(kname, [0.0, 0.0, 0])
+    for kname, flops, e0, e1, _shape, _blocks, executed in warm_prof[marks[max(0, warmup - wsteps)]:]:
+        a = wagg.setdefault(kname, [0.0, 0.0, 0, 0.0])
         a[0] += e0.elapsed_time(e1) * 1e-3
         a[1] += flops
         a[2] += 1
+        a[3] += flops * executed
     if args.shape_table and rank == 0:
         _write_shape_table(args.shape_table, name, cfg, warm_prof, marks, n_local)
     del warm_prof
@@ -448,16 +449,18 @@ def run_config(name, args, world, rank, dev, multi):
         # steps); its launches in the timed region are the `achieved` figure
         if dom_name is None:                                        # --warmup 0: everything was bracketed
             tagg = {}
-            for n_, f_, e0, e1 in (q[:4] for q in prof):
-                a = tagg.setdefault(n_, [0.0, 0.0, 0])
-                a[0] += e0.elapsed_time(e1) * 1e-3; a[1] += f_; a[2] += 1
+            for n_, f_, e0, e1, _s, _b, ex_ in prof:
+                a = tagg.setdefault(n_, [0.0, 0.0, 0, 0.0])
+                a[0] += e0.elapsed_time(e1) * 1e-3; a[1] += f_; a[2] += 1; a[3] += f_ * ex_
             dom_name = max(tagg.items(), key=lambda kv: kv[1][0])[0]
             wagg, wsteps = tagg, steps
             prof = [q for q in prof if q[0] == dom_name]
         tsum = sum(q[2].elapsed_time(q[3]) for q in prof) * 1e-3
         fsum = sum(q[1] for q in prof)
+        xsum = sum(q[1] * q[6] for q in prof)          # flops the kernel issued (pixel-major tiles skip padding taps)
         cnt = max(len(prof), 1)
         achieved = fsum / max(tsum, 1e-12) / 1e12
+        executed = xsum / max(tsum, 1e-12) / 1e12
         conv_time_per_step = sum(a[0] for a in wagg.values()) / wsteps
         traffic, traffic_src = _pmc_traffic(name, dom_name) if world == 1 else (None, None)
         fpi = cfg['flop_per_image']
@@ -468,12 +471,21 @@ def run_config(name, args, world, rank, dev, multi):
                     "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                     "launches_per_step": cnt / nprof_steps, "avg_launch_ms": round(tsum / cnt * 1e3, 4),
                     "algorithmic_gflop_per_launch": round(fsum / cnt / 1e9, 2),
+                    "flop_convention": "achieved / frac are quoted on the layer's nominal count 2*N*Ho*Wo*K*C*KH*KW (SURVEY.md "
+                                       "8d: the dense layer of the reference, tap-positions that read zero padding "
+                                       "included); `executed` prices only the multiply-adds the kernel issues -- its "
+                                       "pixel-major tiles (contrad_conv2d_path == 3) skip the padding tap-positions of "
+                                       "the layers on 4x4 / 8x8 maps",
+                    "executed": {"gflop_per_launch": round(xsum / cnt / 1e9, 2), "tflops": round(executed, 2),
+                                 "frac_of_peak": round(executed / PEAK_FP32_MFMA, 4),
+                                 "share_of_nominal": round(xsum / max(fsum, 1.0), 4)},
                     "bracket": "HIP events around the C-ABI call on its stream" +
                                (" (igemm WGRAD kernel + its wgrad_reduce_kernel)" if "<2," in dom_name else "") +
                                ("; the timed region replays one captured hipGraph per step, so the bracketed launches are "
                                 "those of %d eager steps run right after it" % nprof_steps if use_graph else ""),
                     "conv_engine_share_of_step": round(conv_time_per_step / (dt / steps), 3),
                     "all_kernels_warmup": {k: {"tflops": round(v[1] / v[0] / 1e12, 1),
+                                               "executed_tflops": round(v[3] / v[0] / 1e12, 1),
                                                "ms_per_step": round(v[0] / wsteps * 1e3, 3)}
                                            for k, v in sorted(wagg.items())},
                     "step_level": {"achieved": round(value / world * fpi / 1e12, 2),

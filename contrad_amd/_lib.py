@@ -49,6 +49,7 @@ class AdamBatch(ctypes.Structure):
 _CTYPES = {
     'int': ctypes.c_int,
     'float': ctypes.c_float,
+    'double': ctypes.c_double,
     'long long': ctypes.c_longlong,
     'contrad_stream_t': ctypes.c_void_p,
     'void': None,
@@ -73,7 +74,7 @@ def parse_header(path=HEADER_PATH):
     src = open(path).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     protos = {}
-    for m in re.finditer(r'\b(int|long long|void)\s+(contrad_\w+)\s*\(([^)]*)\)\s*;', src):
+    for m in re.finditer(r'\b(int|long long|void|double)\s+(contrad_\w+)\s*\(([^)]*)\)\s*;', src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         argtypes = []
         if args and args != 'void':

@@ -1294,6 +1294,12 @@ extern "C" int contrad_conv2d_path(const contrad_conv_desc* d, int mode) {
   return 2;
 }
 
+extern "C" double contrad_conv2d_executed_fraction(const contrad_conv_desc* d, int mode) {
+  if (check_desc(d) || mode < 0 || mode > 2) return -22.0;
+  if (contrad_conv2d_path(d, mode) != 3) return 1.0;
+  return mode == MODE_DGRAD ? dgrad_valid_tap_fraction(d) : fwd_valid_tap_fraction(d);
+}
+
 extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int mode, int with_workspace) {
   if (check_desc(d) || mode < 0 || mode > 2) return -22;
   if (mode == MODE_FWD) {

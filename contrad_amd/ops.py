@@ -103,7 +103,9 @@ def _conv_call(mode, d, name, *args):
     flops = 2.0 * d.N * d.Ho * d.Wo * d.K * d.C * d.KH * d.KW
     shape = (d.N, d.H, d.W, d.C, d.K, d.KH, d.KW, d.stride, d.pad)
     blocks = lib().raw('contrad_conv2d_grid_blocks')(ctypes.byref(d), mode, 1)
-    PROFILE.append((kname, flops, e0, e1, shape, int(blocks)))
+    # share of those flops the kernel issues (pixel-major tiles skip the tap-positions that read padding)
+    executed = float(lib().raw('contrad_conv2d_executed_fraction')(ctypes.byref(d), mode))
+    PROFILE.append((kname, flops, e0, e1, shape, int(blocks), executed))
 
 
 def make_desc(N, H, W, C, K, KH, KW, stride, pad, ldx, ldy, ldw):

@@ -91,6 +91,11 @@ int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm, int* bn);
  * only: the 512 -> 1 logit of the heads), 6 = the weight-stationary kernel of the 32 -> 32 channel 3x3 stride-1 layers
  * (conv_c32_kernel<mode>, modes 0 and 1); negative = bad descriptor.  Profiling aid. */
 int contrad_conv2d_path(const contrad_conv_desc* d, int mode);
+/* Share of the layer's nominal multiply-adds (2*N*Ho*Wo*K*C*KH*KW, the count every roofline here is quoted on, padding
+ * taps included as in the reference's dense layer) that the kernel actually issues: 1 except on pixel-major tiles (path
+ * 3), which skip the tap-positions that read padding (0.69 for a 3x3 pad-1 layer on a 4x4 map).  (A weight-gradient tile
+ * that also sums the bias gradient visits everything: not reflected.)  Profiling aid. */
+double contrad_conv2d_executed_fraction(const contrad_conv_desc* d, int mode);
 /* Workgroups (256 threads each) of the main igemm launch this geometry gets for `mode` (with_workspace != 0: the plan the
  * *_ws entry points use, i.e. split-K allowed).  Profiling aid: lets a rocprofv3 kernel trace, which names only the
  * template instance, be joined to the layer shape a dispatch served (tools/rocpd_rows.py); negative = bad descriptor. */

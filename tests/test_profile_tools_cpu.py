@@ -53,7 +53,7 @@ def test_rows_are_attributed_by_launch_order(tmp_path):
                  'plain_step': {'steps_sampled': 2, 'rows': [], 'sequence': [
                      ['igemm_lean_kernel<0, 128, 128>', [4, 8, 8, 16, 16, 3, 3, 1, 1], 768, 10.0],
                      ['igemm_lean_kernel<2, 128, 128>', [4, 8, 8, 16, 16, 3, 3, 1, 1], 1008, 20.0],
-                     ['igemm_lean_kernel<2, 128, 128>', [4, 4, 4, 32, 32, 3, 3, 1, 1], 1008, 40.0],
+                     ['igemm_lean_kernel<2, 128, 128>', [4, 4, 4, 32, 32, 3, 3, 1, 1], 1008, 40.0, 0.5],   # pixel-major: half issued
                      ['fwd_k1_kernel', [4, 1, 1, 16, 1, 1, 1, 1, 0], 1, 0.0],
                      ['wgrad_c32_kernel', [4, 8, 32, 32, 32, 3, 3, 1, 1], 512, 10.0]]}}}
     tp = str(tmp_path / 'shapes.json')
@@ -72,5 +72,6 @@ def test_rows_are_attributed_by_launch_order(tmp_path):
     # 20 GFLOP in 200 us = 100 TF/s; 40 GFLOP in 400 us = 100 TF/s: each shape got ITS dispatches (same instance + grid)
     assert abs(float(by_shape['4,8,8,16,16,3,3,1,1'][5]) - 200.0) < 1e-6 and abs(float(by_shape['4,4,4,32,32,3,3,1,1'][5]) - 400.0) < 1e-6
     assert abs(float(by_shape['4,8,8,16,16,3,3,1,1'][7]) - 100.0) < 0.1 and abs(float(by_shape['4,4,4,32,32,3,3,1,1'][7]) - 100.0) < 0.1
-    assert '80.0 GFLOP per step in 802.0 us of igemm dispatches' in plain_part
+    assert '80.0 GFLOP per step in 802.0 us of igemm dispatches' in plain_part and 'issued 60.0 GFLOP' in plain_part
+    assert abs(float(by_shape['4,4,4,32,32,3,3,1,1'][9]) - 0.5) < 1e-6 and abs(float(by_shape['4,4,4,32,32,3,3,1,1'][10]) - 50.0) < 0.1
     assert any(l.startswith('wgrad_c32_kernel') and abs(float(l.split()[5]) - 100.0) < 1e-6 for l in plain_part.splitlines())

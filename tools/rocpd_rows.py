@@ -58,6 +58,9 @@ def main(db_path, table_path):
         db_path.split('/')[-1], table['config'], table['per_gpu_batch']))
     print('# TF/s = GFLOP per launch / rocprof average duration of the igemm dispatch alone (a WGRAD call\'s '
           'wgrad_reduce_kernel is a separate trace row); FLOP rule: %s; frac = TF/s / 157.3' % table['flop_rule'])
+    print('# exec = share of those nominal FLOPs the kernel issues: pixel-major tiles (contrad_conv2d_path 3, small maps) skip '
+          'the tap-positions that read zero padding, which the FLOP rule counts -- xTF/s = TF/s * exec is the rate the '
+          'matrix pipe actually ran at')
     print('# %d steps in the trace (cut at the optimizer launch)' % len(steps))
     matched_steps = set()
     for sec, d in table['sections'].items():
@@ -71,31 +74,35 @@ def main(db_path, table_path):
             nmatch += 1
             matched_steps.add(si)
             for (k, blocks, us), q in zip(st, seq):
-                a = agg.setdefault((norm(q[0]), tuple(q[1]), q[2]), [0, 0.0, q[3]])
+                a = agg.setdefault((norm(q[0]), tuple(q[1]), q[2]), [0, 0.0, q[3], q[4] if len(q) > 4 else 1.0])
                 a[0] += 1
                 a[1] += us
         print('\n== section %s: %d conv-engine launches per step, %d trace step(s) matched ==' % (sec, len(seq), nmatch))
         if not nmatch:
             continue
-        print('%-30s %-34s %7s %7s %8s %10s %11s %7s %6s' % ('kernel', 'shape N,H,W,C,K,KH,KW,s,p', 'blocks', 'n/step',
-                                                            'calls', 'avg_us', 'GFLOP/call', 'TF/s', 'frac'))
-        tot_f = tot_t = 0.0
+        print('%-30s %-34s %7s %7s %8s %10s %11s %7s %6s %5s %6s' % ('kernel', 'shape N,H,W,C,K,KH,KW,s,p', 'blocks', 'n/step',
+                                                                   'calls', 'avg_us', 'GFLOP/call', 'TF/s', 'frac', 'exec',
+                                                                   'xTF/s'))
+        tot_f = tot_t = tot_x = 0.0
         per_kernel = {}
-        for (k, shape, blocks), (c, us, gf) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        for (k, shape, blocks), (c, us, gf, ex) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             avg = us / c
             tf = gf / avg * 1e3 if avg > 0 else 0.0
             tot_f += gf * c / nmatch
+            tot_x += gf * ex * c / nmatch
             tot_t += us / nmatch
-            pk = per_kernel.setdefault(k, [0.0, 0.0, 0])
-            pk[0] += gf * c / nmatch; pk[1] += us / nmatch; pk[2] += c / nmatch
-            print('%-30s %-34s %7d %7.1f %8d %10.2f %11.4f %7.1f %6.3f' % (k, ','.join(map(str, shape)), blocks, c / nmatch, c,
-                                                                           avg, gf, tf, tf / 157.3))
+            pk = per_kernel.setdefault(k, [0.0, 0.0, 0, 0.0])
+            pk[0] += gf * c / nmatch; pk[1] += us / nmatch; pk[2] += c / nmatch; pk[3] += gf * ex * c / nmatch
+            print('%-30s %-34s %7d %7.1f %8d %10.2f %11.4f %7.1f %6.3f %5.2f %6.1f' % (
+                k, ','.join(map(str, shape)), blocks, c / nmatch, c, avg, gf, tf, tf / 157.3, ex, tf * ex))
         print('-- per kernel instance (this section, per step):')
-        for k, (gf, us, n) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1]):
-            print('   %-30s %5.1f launches %9.1f us %10.2f GFLOP -> %6.1f TF/s (%.3f)' % (k, n, us, gf, gf / us * 1e3 if us else 0,
-                                                                                           gf / us * 1e3 / 157.3 if us else 0))
-        print('-- conv engine, %s: %.1f GFLOP per step in %.1f us of igemm dispatches -> %.1f TF/s (%.3f of 157.3)'
-              % (sec, tot_f, tot_t, tot_f / tot_t * 1e3, tot_f / tot_t * 1e3 / 157.3))
+        for k, (gf, us, n, xf) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1]):
+            print('   %-30s %5.1f launches %9.1f us %10.2f GFLOP -> %6.1f TF/s (%.3f)   issued %10.2f GFLOP -> %6.1f TF/s (%.3f)' % (
+                k, n, us, gf, gf / us * 1e3 if us else 0, gf / us * 1e3 / 157.3 if us else 0,
+                xf, xf / us * 1e3 if us else 0, xf / us * 1e3 / 157.3 if us else 0))
+        print('-- conv engine, %s: %.1f GFLOP per step in %.1f us of igemm dispatches -> %.1f TF/s (%.3f of 157.3); issued %.1f '
+              'GFLOP -> %.1f TF/s (%.3f)' % (sec, tot_f, tot_t, tot_f / tot_t * 1e3, tot_f / tot_t * 1e3 / 157.3,
+                                              tot_x, tot_x / tot_t * 1e3, tot_x / tot_t * 1e3 / 157.3))
     un = [i for i in range(len(steps)) if i not in matched_steps]
     if un:
         print('\n== %d trace step(s) matched no section (cold first step / generator-only segments): %s ==' % (
