@@ -57,6 +57,7 @@ struct IgemmArgs {
   int dsplits;           // lean DGRAD, stride 1: split-K count (grid.y = splits instead of parity classes), else 0 / 1
   long long slab_elems;  // lean DGRAD split-K: floats per partial slab (N * H * W * ldx)
   int px_pixels;         // lean DGRAD, pixel-major: dx pixels of the largest parity class (tiles_m = image blocks x this)
+  unsigned char px_order[256];   // pixel-major FWD / DGRAD: the pixel the k-th tile of an image block works on (balance, see pixel_order())
   int pixmajor;          // lean FWD / DGRAD: M-tiles are BM images at one output pixel (tiles_m = image blocks x Ho*Wo), padding taps skipped
 };
 
@@ -1068,6 +1069,33 @@ bool wgrad_pixmajor_ok(const contrad_conv_desc* d, int bm, long long pps) {
   return fwd_valid_tap_fraction(d) <= lim;
 }
 
+// Order in which the pixels of a map are handed to consecutive pixel-major tiles.  The tiles are unequal (a corner pixel
+// of a 3x3 pad-1 layer contracts over 4 taps, an edge pixel over 6, an interior one over 9) and all of them are resident
+// at once (768 blocks on 1024 slots), so a CU's time is the SUM of the 3 blocks it happens to get.
+//   0  row-major (as stored)     1  heaviest first (default)     2  heavy / light alternating
+// Measured (3x3 on 4x4 maps, 1536 images): 0.719 / 0.709 / 0.710 ms forward, 0.716 / 0.708 / 0.707 data gradient -- the
+// imbalance is NOT what keeps these tiles at 0.7 of the image-major tiles' issue rate (their operand traffic is, DESIGN.md
+// section 3).  taps[p] = valid taps of pixel p (any positive weights).
+void pixel_order(const int* taps, int npix, unsigned char* out) {
+  static const int mode = []() { const char* e = getenv("CONTRAD_PIXORDER"); return e ? atoi(e) : 1; }();
+  int idx[256];
+  for (int i = 0; i < npix; ++i) idx[i] = i;
+  if (mode >= 1) {   // stable sort by taps, descending (insertion sort: npix <= 256, host, once per call)
+    for (int i = 1; i < npix; ++i) {
+      const int v = idx[i];
+      int j = i - 1;
+      while (j >= 0 && taps[idx[j]] < taps[v]) { idx[j + 1] = idx[j]; --j; }
+      idx[j + 1] = v;
+    }
+  }
+  if (mode == 2) {   // heaviest, lightest, 2nd heaviest, 2nd lightest, ...
+    int tmp[256];
+    for (int i = 0, lo = 0, hi = npix - 1; i < npix; ++i) tmp[i] = (i & 1) ? idx[hi--] : idx[lo++];
+    for (int i = 0; i < npix; ++i) idx[i] = tmp[i];
+  }
+  for (int i = 0; i < npix; ++i) out[i] = (unsigned char)idx[i];
+}
+
 FwdPlan fwd_plan(const contrad_conv_desc* d) {
   const long long M = (long long)d->N * d->Ho * d->Wo;
   const bool vec = vec_ok(d, MODE_FWD);
@@ -1161,6 +1189,17 @@ extern "C" int contrad_conv2d_fwd_add(const contrad_conv_desc* d, const float* x
   a.tiles_m = p.pixmajor ? cdiv(d->N, p.bm) * d->Ho * d->Wo : cdiv(a.M, p.bm);
   a.tiles_n = cdiv(a.Ncol, p.bn);
   a.pixmajor = p.pixmajor;
+  if (p.pixmajor) {
+    int taps[256];
+    for (int ho = 0; ho < d->Ho; ++ho)
+      for (int wo = 0; wo < d->Wo; ++wo) {
+        int vh = 0, vw = 0;
+        for (int kh = 0; kh < d->KH; ++kh) vh += (unsigned)(ho * d->stride - d->pad + kh) < (unsigned)d->H;
+        for (int kw = 0; kw < d->KW; ++kw) vw += (unsigned)(wo * d->stride - d->pad + kw) < (unsigned)d->W;
+        taps[ho * d->Wo + wo] = vh * vw;
+      }
+    pixel_order(taps, d->Ho * d->Wo, a.px_order);
+  }
   a.ptiles_per_split = p.tps;
   if (p.splits > 1) {
     CONTRAD_ARG(workspace && workspace_bytes >= contrad_conv2d_fwd_workspace_bytes(d));
@@ -1212,6 +1251,19 @@ extern "C" int contrad_conv2d_dgrad_ws(const contrad_conv_desc* d, const float* 
   a.pixmajor = pl.pixmajor;
   a.px_pixels = cdiv(d->H, s) * cdiv(d->W, s);
   a.tiles_m = pl.pixmajor ? cdiv(d->N, bm) * a.px_pixels : cdiv((int)Mc, bm);
+  if (pl.pixmajor) {
+    int taps[256];
+    for (int i = 0; i < a.px_pixels; ++i) taps[i] = 1;
+    if (s == 1)     // (strided: per-class pixel sets, left in row-major order)
+      for (int h = 0; h < d->H; ++h)
+        for (int w = 0; w < d->W; ++w) {
+          int vh = 0, vw = 0;
+          for (int kh = 0; kh < d->KH; ++kh) vh += (unsigned)(h + d->pad - kh) < (unsigned)d->Ho;
+          for (int kw = 0; kw < d->KW; ++kw) vw += (unsigned)(w + d->pad - kw) < (unsigned)d->Wo;
+          taps[h * d->W + w] = vh * vw;
+        }
+    pixel_order(taps, a.px_pixels, a.px_order);
+  }
   a.tiles_n = cdiv(d->C, bn);
   if (pl.splits > 1) {
     // stride-1 split-K: every split writes raw partial sums into its own slab (dx's layout), dgrad_reduce_kernel sums

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     const int HoWo = d.Ho * d.Wo;
     if (p.pixmajor) {
       // tile_m = image block * Ho*Wo + pixel: neighbouring blocks read the same BM images
-      const int ib = tile_m / HoWo, pix = tile_m - ib * HoWo;
+      const int ib = tile_m / HoWo, pix = p.px_order[tile_m - ib * HoWo];
       const int ho = pix / d.Wo, wo = pix - ho * d.Wo;
       const int n_first = ib * BM;
       unsigned wmask = 0, valid = 0;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     const int HcWc = Hc * Wc;
     if (p.pixmajor) {
       // tile_m = image block * (pixels of the largest class) + pixel of this class: BM images at ONE dx pixel
-      const int ib = tile_m / p.px_pixels, cpix = tile_m - ib * p.px_pixels;
+      const int ib = tile_m / p.px_pixels, cpix = p.px_order[tile_m - ib * p.px_pixels];
       if (cpix >= HcWc) return;   // uniform per block, before any barrier
       const int hq = cpix / Wc, wq = cpix - hq * Wc;
       const int ah = hq + bh, aw = wq + bw;
