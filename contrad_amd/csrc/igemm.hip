@@ -23,6 +23,8 @@
 // activation tile run on the same XCD/L2.
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
+#include <utility>
 #include "../../include/contrad_hip.h"
 
 namespace {
@@ -57,6 +59,11 @@ struct IgemmArgs {
   int dsplits;           // lean DGRAD, stride 1: split-K count (grid.y = splits instead of parity classes), else 0 / 1
   long long slab_elems;  // lean DGRAD split-K: floats per partial slab (N * H * W * ldx)
   int px_pixels;         // lean DGRAD, pixel-major: dx pixels of the largest parity class (tiles_m = image blocks x this)
+  // border classes (lean FWD / stride-1 DGRAD, nwin > 0): windows of the output / dx map whose pixels share their set of
+  // non-padding taps; class c owns the M-tiles [win_tile0[c], win_tile0[c + 1]) of the launch
+  short win_h0[16], win_w0[16], win_hc[16], win_wc[16];
+  int win_tile0[17];
+  int nwin;
   unsigned char px_order[256];   // pixel-major FWD / DGRAD: the pixel the k-th tile of an image block works on (balance, see pixel_order())
   int pixmajor;          // lean FWD / DGRAD: M-tiles are BM images at one output pixel (tiles_m = image blocks x Ho*Wo), padding taps skipped
 };
@@ -1025,6 +1032,28 @@ double fwd_valid_tap_fraction(const contrad_conv_desc* d) {
   return (double)(vh * vw) / ((double)d->Ho * d->Wo * d->KH * d->KW);
 }
 
+// When the automatic plan takes border classes (igemm_lean.h, p.nwin) instead of pixel-major or image-major tiles.
+// Measured at 1536 images (CONTRAD_TILEMODE=0/1/2 tools/bench_conv.py; image-major / pixel-major / border classes, ms):
+//   3x3 on 4x4 (0.69 valid)        fwd 0.805 / 0.710 / 0.730   dgrad 0.807 / 0.709 / 0.729
+//   4x4 s2 onto 4x4 (0.77)         fwd 0.718 / 0.649 / 0.720
+//   3x3 on 8x8 (0.84)              fwd 0.805 / 0.805 / 0.726   dgrad 0.808 / 0.803 / 0.724
+//   4x4 s2 onto 8x8 (0.88)         fwd 0.723 / 0.772 / 0.693
+//   3x3 on 16x16 (0.92)            fwd 0.818 / 0.782 / 0.786   dgrad 0.808 / 0.823 / 0.775
+//   4x4 s2 onto 16x16 (0.94)       fwd 0.925 / 0.919 / 0.897
+// -> pixel-major where at most 0.80 of the tap-positions are valid (its tiles are single pixels there anyway), border
+// classes from there up to 0.96 (they keep the reuse of neighbouring pixels inside a tile, which is what pixel-major
+// tiles lose on the larger maps).
+constexpr double BORDER_MAX_VALID = 0.96;
+bool border_classes_ok(const contrad_conv_desc* d, int mode, int bm);
+bool fwd_pixmajor_ok(const contrad_conv_desc* d, int bm);
+bool dgrad_pixmajor_ok(const contrad_conv_desc* d, int bm);
+bool fwd_border_ok(const contrad_conv_desc* d, int bm, double valid) {
+  return valid <= BORDER_MAX_VALID && !fwd_pixmajor_ok(d, bm) && border_classes_ok(d, MODE_FWD, bm);
+}
+bool dgrad_border_ok(const contrad_conv_desc* d, int bm, double valid) {
+  return valid <= BORDER_MAX_VALID && !dgrad_pixmajor_ok(d, bm) && border_classes_ok(d, MODE_DGRAD, bm);
+}
+
 bool fwd_pixmajor_ok(const contrad_conv_desc* d, int bm) {
   if (!pixmajor_enabled() || d->Ho * d->Wo > 256 || d->N < bm) return false;
   if ((long long)bm * d->H * d->W * d->ldx * 4 >= (1ll << 30)) return false;      // row offsets inside a tile (bytes)
@@ -1096,6 +1125,110 @@ void pixel_order(const int* taps, int npix, unsigned char* out) {
   for (int i = 0; i < npix; ++i) out[i] = (unsigned char)idx[i];
 }
 
+// ---- border classes -------------------------------------------------------------------------------------------------
+// Along each axis the pixels of the map fall into runs with the same set of non-padding filter rows / columns (3x3 pad 1:
+// first row, interior, last row); the products of an h-run and a w-run are rectangles whose pixels all read padding at
+// the SAME taps.  An M-tile that enumerates (image, pixel) inside one rectangle can skip those taps (as a pixel-major
+// tile does) and still shares the input neighbourhoods of adjacent pixels between its rows (which a pixel-major tile
+// cannot).  mode 0: output pixels of the forward conv; mode 1: dx pixels of the stride-1 data gradient.
+struct BorderClasses {
+  int n;
+  int h0[16], w0[16], hc[16], wc[16], taps[16];
+};
+
+int axis_runs(const contrad_conv_desc* d, int mode, bool along_h, int* start, int* len, int* ntaps) {
+  const int extent = mode == MODE_FWD ? (along_h ? d->Ho : d->Wo) : (along_h ? d->H : d->W);
+  const int in_ext = mode == MODE_FWD ? (along_h ? d->H : d->W) : (along_h ? d->Ho : d->Wo);
+  const int k = along_h ? d->KH : d->KW;
+  int runs = 0;
+  unsigned prev = 0;
+  for (int o = 0; o < extent; ++o) {
+    unsigned m = 0;
+    for (int t = 0; t < k; ++t) {
+      const int i = mode == MODE_FWD ? o * d->stride - d->pad + t : o + d->pad - t;   // (DGRAD: stride 1)
+      if ((unsigned)i < (unsigned)in_ext) m |= 1u << t;
+    }
+    if (o == 0 || m != prev) {
+      if (runs == 16) return -1;
+      start[runs] = o; len[runs] = 0; ntaps[runs] = __builtin_popcount(m);
+      ++runs;
+      prev = m;
+    }
+    ++len[runs - 1];
+  }
+  return runs;
+}
+
+bool border_classes(const contrad_conv_desc* d, int mode, BorderClasses* bc) {
+  int hs[16], hl[16], ht[16], ws[16], wl[16], wt[16];
+  const int nh = axis_runs(d, mode, true, hs, hl, ht), nw = axis_runs(d, mode, false, ws, wl, wt);
+  if (nh <= 0 || nw <= 0 || nh * nw > 16 || nh * nw < 2) return false;
+  bc->n = 0;
+  for (int a = 0; a < nh; ++a)
+    for (int b = 0; b < nw; ++b) {
+      const int i = bc->n++;
+      bc->h0[i] = hs[a]; bc->hc[i] = hl[a]; bc->w0[i] = ws[b]; bc->wc[i] = wl[b]; bc->taps[i] = ht[a] * wt[b];
+    }
+  for (int i = 1; i < bc->n; ++i)      // heaviest class first (stable insertion sort)
+    for (int j = i; j > 0 && bc->taps[j - 1] < bc->taps[j]; --j) {
+      std::swap(bc->h0[j], bc->h0[j - 1]); std::swap(bc->hc[j], bc->hc[j - 1]); std::swap(bc->w0[j], bc->w0[j - 1]);
+      std::swap(bc->wc[j], bc->wc[j - 1]); std::swap(bc->taps[j], bc->taps[j - 1]);
+    }
+  return true;
+}
+
+// tile mode of a lean FWD / DGRAD launch: 0 image-major, 1 pixel-major, 2 border classes
+int tile_mode_override() {
+  static const int m = []() { const char* e = getenv("CONTRAD_TILEMODE"); return e ? atoi(e) : -1; }();   // dev
+  return m;
+}
+
+bool border_classes_ok(const contrad_conv_desc* d, int mode, int bm) {
+  if (!pixmajor_enabled() || (mode == MODE_DGRAD && d->stride != 1)) return false;
+  BorderClasses bc;
+  if (!border_classes(d, mode, &bc)) return false;
+  int minpix = 1 << 30;
+  for (int i = 0; i < bc.n; ++i) minpix = std::min(minpix, bc.hc[i] * bc.wc[i]);
+  const long long imgs = bm / minpix + 2;        // images one M-tile of the smallest class can touch
+  if (imgs * d->H * d->W * d->ldx * 4 >= (1ll << 30) || imgs * d->Ho * d->Wo * d->ldy * 4 >= (1ll << 30)) return false;
+  // every XCD takes an eighth of every class: the smallest class must have a tile for each of them.  (192 images on an
+  // 8x8 map: 2 half-empty corner tiles, 9 edge tiles per side -- StyleGAN2-32 went 16.2 -> 16.7 ms with classes that small.)
+  if (tile_mode_override() != 2 && (long long)d->N * minpix < 8ll * bm) return false;
+  if ((long long)d->N * minpix < bm) return false;                     // not even one full tile in the smallest class
+  return true;
+}
+
+void fill_border_classes(const contrad_conv_desc* d, int mode, int bm, IgemmArgs* a) {
+  BorderClasses bc;
+  border_classes(d, mode, &bc);
+  a->nwin = bc.n;
+  int t = 0;
+  for (int i = 0; i < bc.n; ++i) {
+    a->win_h0[i] = (short)bc.h0[i]; a->win_w0[i] = (short)bc.w0[i];
+    a->win_hc[i] = (short)bc.hc[i]; a->win_wc[i] = (short)bc.wc[i];
+    a->win_tile0[i] = t;
+    t += (int)cdivll((long long)d->N * bc.hc[i] * bc.wc[i], bm);
+  }
+  a->win_tile0[bc.n] = t;
+  // grid: every XCD (block b -> XCD b % 8) walks its eighth of every class; padded to the largest per-XCD share
+  int most = 0;
+  for (int x = 0; x < 8; ++x) {
+    int sum = 0;
+    for (int i = 0; i < bc.n; ++i) {
+      const int n_c = a->win_tile0[i + 1] - a->win_tile0[i];
+      sum += (((x + 1) * n_c) >> 3) - ((x * n_c) >> 3);
+    }
+    most = std::max(most, sum);
+  }
+  a->tiles_m = 8 * most;
+}
+
+int border_class_tiles(const contrad_conv_desc* d, int mode, int bm) {
+  IgemmArgs a{};
+  fill_border_classes(d, mode, bm, &a);
+  return a.tiles_m;
+}
+
 FwdPlan fwd_plan(const contrad_conv_desc* d) {
   const long long M = (long long)d->N * d->Ho * d->Wo;
   const bool vec = vec_ok(d, MODE_FWD);
@@ -1106,7 +1239,12 @@ FwdPlan fwd_plan(const contrad_conv_desc* d) {
   p.tps = t_total;
   if (lean && splitk_enabled() && p.bn != 32 && t_total >= 32)
     split_plan(M, d->K, t_total, 2.0 * (double)M * d->K * d->C * d->KH * d->KW, &p);
-  if (lean && p.splits <= 1 && fwd_pixmajor_ok(d, p.bm)) p.pixmajor = 1;
+  if (lean && p.splits <= 1) {
+    const int force = tile_mode_override();
+    const double valid = fwd_valid_tap_fraction(d);
+    if (force == 2 ? border_classes_ok(d, MODE_FWD, p.bm) : (force < 0 && fwd_border_ok(d, p.bm, valid))) p.pixmajor = 2;
+    else if (force == 1 || force < 0) p.pixmajor = fwd_pixmajor_ok(d, p.bm) ? 1 : 0;
+  }
   return p;
 }
 
@@ -1124,7 +1262,12 @@ FwdPlan dgrad_plan(const contrad_conv_desc* d, bool may_split) {
   p.tps = t_total;
   if (may_split && s == 1 && lean && splitk_enabled() && p.bn != 32 && t_total >= 32 && !(d->C & 3) && !(d->ldx & 3))
     split_plan(Mc, d->C, t_total, 2.0 * (double)Mc * d->K * d->C * d->KH * d->KW, &p);
-  if (lean && p.splits <= 1 && dgrad_pixmajor_ok(d, p.bm)) p.pixmajor = 1;
+  if (lean && p.splits <= 1) {
+    const int force = tile_mode_override();
+    const double valid = dgrad_valid_tap_fraction(d);
+    if (force == 2 ? border_classes_ok(d, MODE_DGRAD, p.bm) : (force < 0 && dgrad_border_ok(d, p.bm, valid))) p.pixmajor = 2;
+    else if (force == 1 || force < 0) p.pixmajor = dgrad_pixmajor_ok(d, p.bm) ? 1 : 0;
+  }
   return p;
 }
 
@@ -1186,10 +1329,11 @@ extern "C" int contrad_conv2d_fwd_add(const contrad_conv_desc* d, const float* x
   }
   const bool vec = vec_ok(d, MODE_FWD);
   const FwdPlan p = fwd_plan(d);
-  a.tiles_m = p.pixmajor ? cdiv(d->N, p.bm) * d->Ho * d->Wo : cdiv(a.M, p.bm);
+  a.tiles_m = p.pixmajor == 1 ? cdiv(d->N, p.bm) * d->Ho * d->Wo : cdiv(a.M, p.bm);
   a.tiles_n = cdiv(a.Ncol, p.bn);
-  a.pixmajor = p.pixmajor;
-  if (p.pixmajor) {
+  a.pixmajor = p.pixmajor == 1;
+  if (p.pixmajor == 2) fill_border_classes(d, MODE_FWD, p.bm, &a);      // (sets tiles_m)
+  if (p.pixmajor == 1) {
     int taps[256];
     for (int ho = 0; ho < d->Ho; ++ho)
       for (int wo = 0; wo < d->Wo; ++wo) {
@@ -1248,10 +1392,11 @@ extern "C" int contrad_conv2d_dgrad_ws(const contrad_conv_desc* d, const float* 
   const bool vec = vec_ok(d, MODE_DGRAD);
   const FwdPlan pl = dgrad_plan(d, workspace != nullptr);
   const int bm = pl.bm, bn = pl.bn;
-  a.pixmajor = pl.pixmajor;
+  a.pixmajor = pl.pixmajor == 1;
   a.px_pixels = cdiv(d->H, s) * cdiv(d->W, s);
-  a.tiles_m = pl.pixmajor ? cdiv(d->N, bm) * a.px_pixels : cdiv((int)Mc, bm);
-  if (pl.pixmajor) {
+  a.tiles_m = pl.pixmajor == 1 ? cdiv(d->N, bm) * a.px_pixels : cdiv((int)Mc, bm);
+  if (pl.pixmajor == 2) fill_border_classes(d, MODE_DGRAD, bm, &a);     // (sets tiles_m)
+  if (pl.pixmajor == 1) {
     int taps[256];
     for (int i = 0; i < a.px_pixels; ++i) taps[i] = 1;
     if (s == 1)     // (strided: per-class pixel sets, left in row-major order)
@@ -1359,7 +1504,8 @@ extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int 
     const long long M = (long long)d->N * d->Ho * d->Wo;
     if (fwd_k1_ok(d)) return cdivll(M, 4);
     if (conv_c32_ok(d)) return conv_c32_blocks(d);
-    if (p.pixmajor) return (long long)cdiv(d->N, p.bm) * d->Ho * d->Wo * cdiv(d->K, p.bn);
+    if (p.pixmajor == 1) return (long long)cdiv(d->N, p.bm) * d->Ho * d->Wo * cdiv(d->K, p.bn);
+    if (p.pixmajor == 2) return (long long)border_class_tiles(d, MODE_FWD, p.bm) * cdiv(d->K, p.bn);
     return cdivll(M, p.bm) * cdiv(d->K, p.bn) * (with_workspace ? p.splits : 1);
   }
   if (mode == MODE_DGRAD) {
@@ -1367,7 +1513,8 @@ extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int 
     const int s = d->stride;
     const long long Mc = (long long)d->N * cdiv(d->H, s) * cdiv(d->W, s);
     const FwdPlan p = dgrad_plan(d, with_workspace != 0);
-    const int tiles_m = p.pixmajor ? cdiv(d->N, p.bm) * cdiv(d->H, s) * cdiv(d->W, s) : cdiv((int)Mc, p.bm);
+    const int tiles_m = p.pixmajor == 2 ? border_class_tiles(d, MODE_DGRAD, p.bm)
+                        : p.pixmajor == 1 ? cdiv(d->N, p.bm) * cdiv(d->H, s) * cdiv(d->W, s) : cdiv((int)Mc, p.bm);
     const int tiles_n = cdiv(d->C, p.bn);
     if (p.splits > 1) return (long long)tiles_m * tiles_n * p.splits;
     static const int g = []() { const char* e = getenv("CONTRAD_DGRAD_CGROUP"); return e ? atoi(e) : 8; }();

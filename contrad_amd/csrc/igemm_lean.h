@@ -82,6 +82,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
   // Before this the 9..36 tiles of a WGRAD split sat on 8 different XCDs and HBM traffic was 6.5x the algorithmic bytes.
   const int lin = xcd_remap(blockIdx.x, gridDim.x);
   int by, tile_n, tile_m;
+  int wc_h0 = 0, wc_w0 = 0, wc_hc = 0, wc_wc = 0;   // border class of this tile: window origin and size (p.nwin > 0)
   if constexpr (MODE == MODE_WGRAD) {
     const int tiles = p.tiles_m * p.tiles_n;
     by = lin / tiles;
@@ -96,6 +97,27 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     tile_m = g * p.cgroup + q / p.tiles_n;
     tile_n = q % p.tiles_n;
     if (tile_m >= p.tiles_m) return;
+  } else if (MODE != MODE_WGRAD && p.nwin > 0) {
+    // border classes (igemm.hip, border_classes()): the output map (FWD) / dx map (stride-1 DGRAD) is cut into the <= 16
+    // rectangles of pixels that share their set of non-padding taps; every class has its own run of M-tiles over
+    // (image, pixel of the rectangle), heaviest class first
+    // The classes carry unequal work per tile (9 / 6 / 4 taps), and the dispatcher places block b on XCD b % 8: every XCD
+    // takes an eighth of EVERY class (contiguous in the class, so neighbours still share images in the L2), heaviest
+    // class first.  (With the engine's usual contiguous-run-per-XCD order two XCDs got all the 9-tap tiles and the
+    // kernel lasted exactly as long as without any skipping.)
+    const int xcd = blockIdx.x & 7, kb = blockIdx.x >> 3;
+    tile_n = kb % p.tiles_n;
+    int km = kb / p.tiles_n, c = 0;
+    tile_m = -1;
+    for (; c < p.nwin; ++c) {
+      const int n_c = p.win_tile0[c + 1] - p.win_tile0[c];
+      const int lo = (xcd * n_c) >> 3, hi = ((xcd + 1) * n_c) >> 3;
+      if (km < hi - lo) { tile_m = lo + km; break; }
+      km -= hi - lo;
+    }
+    if (tile_m < 0) return;     // (grid padded to 8 x the largest per-XCD share)
+    by = 0;
+    wc_h0 = p.win_h0[c]; wc_w0 = p.win_w0[c]; wc_hc = p.win_hc[c]; wc_wc = p.win_wc[c];
   } else {
     tile_n = lin % p.tiles_n;
     const int r = lin / p.tiles_n;
@@ -169,8 +191,25 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
       px_pitch = HoWo * d.ldy;
       px_rows = min(BM, d.N - n_first);
     }
-    const int sh_w = pow2_shift(d.Wo), sh_h = pow2_shift(d.Ho);
-    const int n_first = (sh_w >= 0 && sh_h >= 0) ? (m0 >> (sh_w + sh_h)) : m0 / HoWo;
+    // rows of the tile = (image, pixel) over the whole output map, or over this tile's border class (window)
+    const bool win = p.nwin > 0;
+    const int gHo = win ? wc_hc : d.Ho, gWo = win ? wc_wc : d.Wo;
+    if (win) {
+      M = d.N * gHo * gWo;
+      unsigned wmask = 0, valid = 0;      // the class's taps: those of its first pixel
+      for (int kw = 0; kw < d.KW; ++kw) wmask |= ((unsigned)(wc_w0 * d.stride - d.pad + kw) < (unsigned)d.W ? 1u : 0u) << kw;
+      for (int kh = 0; kh < d.KH; ++kh)
+        if ((unsigned)(wc_h0 * d.stride - d.pad + kh) < (unsigned)d.H) valid |= wmask << (kh * d.KW);
+      tapmask = valid ? valid : 0xFFFFFFFFu;
+      T = __builtin_popcount(valid) * (d.C / BK);
+      u_tap = valid ? __builtin_ctz(valid) : 0;
+      u_a = u_tap / d.KW;
+      u_b = u_tap - u_a * d.KW;
+      u_c0 = 0;
+      if (m0 >= M) return;   // (uniform per block, before any barrier)
+    }
+    const int sh_w = pow2_shift(gWo), sh_h = pow2_shift(gHo);
+    const int n_first = (sh_w >= 0 && sh_h >= 0) ? (m0 >> (sh_w + sh_h)) : m0 / (gHo * gWo);
     if (!p.pixmajor) baseA = p.A + ((long long)n_first * d.H * d.W - (d.pad * d.W + d.pad)) * d.ldx;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
@@ -179,8 +218,9 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
       const bool ok = m < M;
       const int mm = ok ? m : m0;
       int wo, t, ho, n;
-      divmod_u(mm, d.Wo, sh_w, t, wo);
-      divmod_u(t, d.Ho, sh_h, n, ho);
+      divmod_u(mm, gWo, sh_w, t, wo);
+      divmod_u(t, gHo, sh_h, n, ho);
+      ho += wc_h0; wo += wc_w0;
       va[i] = (unsigned)(((((n - n_first) * d.H + ho * d.stride) * d.W + wo * d.stride) * d.ldx + kq * 4) * 4);
       // valid taps form a rectangle: a KW-bit column mask replicated into the valid kernel rows (KH + KW steps, not KH*KW)
       unsigned wmask = 0, valid = 0;
@@ -221,6 +261,21 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
       u_b = u_tap - u_a * ntw;
     }
     if (ntw == 0) ntw = 1;
+    if (p.nwin > 0) {   // stride 1: this tile's border class of dx pixels (a window of the map), its taps are those of its first pixel
+      Hc = wc_hc; Wc = wc_wc;
+      M = d.N * Hc * Wc;
+      const int ah0 = wc_h0 + bh, aw0 = wc_w0 + bw;
+      unsigned wmask = 0, valid = 0;
+      for (int tw = 0; tw < ntw; ++tw) wmask |= ((unsigned)(aw0 - tw) < (unsigned)d.Wo ? 1u : 0u) << tw;
+      for (int th = 0; th < nth; ++th)
+        if ((unsigned)(ah0 - th) < (unsigned)d.Ho) valid |= wmask << (th * ntw);
+      tapmask = valid ? valid : 0xFFFFFFFFu;
+      T = __builtin_popcount(valid) * (d.K / BK);
+      u_tap = valid ? __builtin_ctz(valid) : 0;
+      u_a = u_tap / ntw;
+      u_b = u_tap - u_a * ntw;
+      u_c0 = 0;
+    }
     const int HcWc = Hc * Wc;
     if (p.pixmajor) {
       // tile_m = image block * (pixels of the largest class) + pixel of this class: BM images at ONE dx pixel
@@ -265,6 +320,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
       int wq, t, n, hq;
       divmod_u(mm, Wc, sh_w, t, wq);
       divmod_u(t, Hc, sh_h, n, hq);
+      hq += wc_h0; wq += wc_w0;               // (border class: position inside the window -> position in the map)
       const int ah = hq + bh, aw = wq + bw;   // ho = ah - th, wo = aw - tw
       va[i] = (unsigned)(((((n - n_first) * d.Ho + ah) * d.Wo + aw) * d.ldy + kq * 4) * 4);
       unsigned wmask = 0, valid = 0;
@@ -564,44 +620,70 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     const int c = n0 + wn * WN + j * 32 + l31;
     colpart[j] = (c < Ncol) ? (unsigned)c * 4u : COL_OOB;
   }
-  if constexpr (MODE == MODE_DGRAD) {
-    // row -> byte offset of the dx pixel relative to the tile's first image (or out of range), staged in LDS
+  const bool rowtab = (MODE == MODE_DGRAD) || (MODE == MODE_FWD && p.nwin > 0);   // rows scattered over the output map
+  if (rowtab) {
+    // row -> byte offset of the output pixel (dx for DGRAD, y for a FWD border class) relative to the tile's first image
+    // (or out of range), staged in LDS
     unsigned* rowoff = reinterpret_cast<unsigned*>(smem);
-    const int sh_w = pow2_shift(Wc), sh_h = pow2_shift(Hc);
-    const int n_first = (sh_w >= 0 && sh_h >= 0) ? (m0 >> (sh_w + sh_h)) : m0 / (Hc * Wc);
+    const int rH = (MODE == MODE_DGRAD) ? Hc : wc_hc, rW = (MODE == MODE_DGRAD) ? Wc : wc_wc;   // extent the rows enumerate
+    const int oH = (MODE == MODE_DGRAD) ? d.H : d.Ho, oW = (MODE == MODE_DGRAD) ? d.W : d.Wo;   // the output map
+    const int old_ = (MODE == MODE_DGRAD) ? d.ldx : d.ldy;
+    const int sh_w = pow2_shift(rW), sh_h = pow2_shift(rH);
+    const int n_first = (sh_w >= 0 && sh_h >= 0) ? (m0 >> (sh_w + sh_h)) : m0 / (rH * rW);
     if (tid < BM) {
       const int m = m0 + tid;
       unsigned off = 2u * COL_OOB;
-      if (p.pixmajor) {
+      if (MODE == MODE_DGRAD && p.pixmajor) {
         if (tid < px_rows) off = (unsigned)(tid * px_pitch) * 4u;
       } else if (m < M) {
         int wq, t2, hq, n;
-        divmod_u(m, Wc, sh_w, t2, wq);
-        divmod_u(t2, Hc, sh_h, n, hq);
-        off = (unsigned)((((n - n_first) * d.H + hq * d.stride + ph) * d.W + (wq * d.stride + pw)) * d.ldx) * 4u;
+        divmod_u(m, rW, sh_w, t2, wq);
+        divmod_u(t2, rH, sh_h, n, hq);
+        hq += wc_h0; wq += wc_w0;
+        if constexpr (MODE == MODE_DGRAD)
+          off = (unsigned)((((n - n_first) * oH + hq * d.stride + ph) * oW + (wq * d.stride + pw)) * old_) * 4u;
+        else
+          off = (unsigned)((((n - n_first) * oH + hq) * oW + wq) * old_) * 4u;
       }
       rowoff[tid] = off;
     }
     __syncthreads();
-    const size_t img0 = p.pixmajor ? (size_t)px_off
-                                   : (size_t)n_first * d.H * d.W * d.ldx + (p.dsplits > 1 ? (size_t)by * (size_t)p.slab_elems : 0);
+    const size_t img0 = (MODE == MODE_DGRAD && p.pixmajor)
+                            ? (size_t)px_off
+                            : (size_t)n_first * oH * oW * old_ +
+                                  ((MODE == MODE_DGRAD && p.dsplits > 1) ? (size_t)by * (size_t)p.slab_elems : 0);
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C + img0, 0, (int)COL_OOB, 0x00020000);
+    // second operand of the epilogue, in the output's own layout: DGRAD the producer's activation (act'), FWD the addend
+    const float* ref = (MODE == MODE_DGRAD) ? p.act_ref : p.addend;
     const __amdgpu_buffer_rsrc_t rsR =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.act_ref ? p.act_ref + img0 : p.C + img0), 0,
-                                          p.act_ref ? (int)COL_OOB : 0, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ref ? ref + img0 : p.C + img0), 0,
+                                          ref ? (int)COL_OOB : 0, 0x00020000);
     const float g1 = p.gain, g0 = p.gain * p.slope;
+    float bj[TN];
+#pragma unroll
+    for (int jj = 0; jj < TN; ++jj) {
+      const int c = n0 + wn * WN + jj * 32 + l31;
+      bj[jj] = (MODE == MODE_FWD && p.bias && c < Ncol) ? p.bias[c] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const unsigned off = rowoff[wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const unsigned vo = off + colpart[j];
-          float v = acc[i][j][r];
-          if (p.act_ref) {   // uniform
-            const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)vo, 0, 0));
-            v *= (a > 0.f) ? g1 : g0;
+        for (int jj = 0; jj < TN; ++jj) {
+          const unsigned vo = off + colpart[jj];
+          float v = acc[i][jj][r];
+          if constexpr (MODE == MODE_DGRAD) {
+            if (ref) {   // uniform
+              const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)vo, 0, 0));
+              v *= (a > 0.f) ? g1 : g0;
+            }
+          } else {
+            v += bj[jj];
+            v = (v > 0.f) ? v : v * p.slope;
+            v *= p.gain;
+            if (ref) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)vo, 0, 0));
           }
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)vo, 0, 0);
         }

@@ -48,6 +48,10 @@ CASES = [
     (130, 5, 7, 16, 64, 3, 2, 1),      # ... odd map, 3x3 stride 2: parity classes of different sizes (3x4, 3x3, 2x4, 2x3 pixels)
     (144, 4, 4, 128, 64, 3, 1, 1),     # ... weight gradient on pixel-major positions (K-tiles = 16 images at one pixel, padding ones skipped)
     (144, 8, 8, 128, 96, 4, 2, 1),     # ... the same with the 4x4 stride-2 kernel, ragged column tile
+    (1040, 8, 8, 64, 64, 3, 1, 1),     # border classes (FWD + DGRAD): 0.84 of the tap-positions valid -> (image, pixel) tiles inside the 9 border rectangles, an eighth of each class per XCD
+    (1040, 12, 20, 16, 64, 4, 2, 1),   # ... 4x4 stride-2 onto a 6 x 10 map (FWD), ragged class tiles
+    (130, 8, 8, 32, 64, 3, 1, 1),      # (too few images for the automatic plan: border classes only when forced, see the subprocess test)
+    (70, 12, 20, 16, 64, 4, 2, 1),
     (200, 2, 6, 32, 48, 3, 1, 1),      # ... a 2 x 6 map: most taps of most pixels are padding
     (3, 64, 512, 32, 32, 3, 1, 1),     # ... a non-square map: 3 images x 16 x 16 tiles of 4 x 32, more tiles than one per block
 ]
@@ -117,11 +121,26 @@ def test_strided_pixel_major_dgrad_in_a_fresh_process():
     import subprocess
     import sys
     env = dict(os.environ, CONTRAD_PIXMAJOR_STRIDED='1', CONTRAD_TEST_EXPECT_DGRAD_PATH='3')
+    env.pop('CONTRAD_TILEMODE', None)          # (a forced tile mode would override the plan under test)
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-m', 'gpu', '-x', '-k',
                         '130x8x8x16x64x4x2x1'], env=env, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert '1 passed' in r.stdout
+
+
+def test_forced_border_classes_in_a_fresh_process():
+    """Border classes with class tiles that are ragged or fewer than the 8 XCDs (small batches: the plan keeps them off
+    there): forced on for FWD and stride-1 DGRAD, the small cases must still match the fp32 reference."""
+    import subprocess
+    import sys
+    env = dict(os.environ, CONTRAD_TILEMODE='2')
+    env.pop('CONTRAD_TEST_EXPECT_DGRAD_PATH', None)
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-m', 'gpu', '-x', '-k',
+                        '130x8x8x32 or 70x12x20 or 200x2x6 or 130x4x4 or 130x5x7 or 16x2x2'], env=env, capture_output=True,
+                       text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert '6 passed' in r.stdout
 
 
 @pytest.mark.parametrize('shape', [(4, 8, 8, 64, 64), (4, 128, 128, 32, 32)], ids=['lean', 'conv_c32'])
