@@ -85,8 +85,9 @@ long long contrad_conv2d_wgrad_workspace_bytes(const contrad_conv_desc* d);
  * 2 wgrad) on this geometry, i.e. which igemm_kernel<mode, bm, bn> instance runs. */
 int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm, int* bn);
 /* Which kernel family serves this shape: 0 = general scalar-gather (igemm_kernel<..., false>), 1 = general float4
- * (igemm_kernel<..., true>), 2 = lean loop (igemm_lean_kernel), 3 = lean loop on pixel-major tiles (small maps: the rows
- * of a tile are images at one output pixel and padding taps are skipped), 4 = the accumulator-stationary weight-gradient kernel of
+ * (igemm_kernel<..., true>), 2 = lean loop (igemm_lean_kernel), 3 = lean loop on tiles that skip padding taps (small maps:
+ * pixel-major tiles -- the rows of a tile are images at one output pixel -- or border classes -- (image, pixel) rows inside
+ * a rectangle of pixels that share their non-padding taps), 4 = the accumulator-stationary weight-gradient kernel of
  * the 32 -> 32 channel 3x3 layers (wgrad_c32_kernel, mode 2 only), 5 = the single-output 1x1 layer (fwd_k1_kernel, mode 0
  * only: the 512 -> 1 logit of the heads), 6 = the weight-stationary kernel of the 32 -> 32 channel 3x3 stride-1 layers
  * (conv_c32_kernel<mode>, modes 0 and 1); negative = bad descriptor.  Profiling aid. */
