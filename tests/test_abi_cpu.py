@@ -95,3 +95,56 @@ def test_launch_plans_are_host_logic(built):
     assert built.raw('contrad_conv2d_dgrad_workspace_bytes')(ctypes.byref(_desc(192, 8, 256, 512, 4, 2, 1))) == 0   # strided
     # contrastive column splits: ~256 blocks
     assert built.raw('contrad_contrast_workspace_bytes')(1024, 128) == 16 * 1024 * 128 * 4
+
+
+def _axis_runs(out_ext, in_ext, k, s, p, mode):
+    """Runs of consecutive output (mode 0) / dx (mode 1, stride 1) coordinates with the same set of non-padding taps."""
+    runs, prev = [], None
+    for o in range(out_ext):
+        m = tuple(t for t in range(k) if 0 <= (o * s - p + t if mode == 0 else o + p - t) < in_ext)
+        if m != prev:
+            runs.append([o, 0, len(m)])
+            prev = m
+        runs[-1][1] += 1
+    return runs
+
+
+def test_padding_skipping_tile_plans_without_gpu(built):
+    """The tiles that skip padding taps are planned on the host: restate the plan in Python and
+    compare what the C ABI reports -- kernel family 3, the share of the nominal multiply-adds that is issued, and the
+    workgroup count, which for border classes is 8 x (the largest per-XCD share of the class tiles) x column tiles."""
+    path, tile = built.raw('contrad_conv2d_path'), built.raw('contrad_conv2d_tile')
+    frac, blocks = built.raw('contrad_conv2d_executed_fraction'), built.raw('contrad_conv2d_grid_blocks')
+    bm, bn = ctypes.c_int(0), ctypes.c_int(0)
+    N = 1536
+    seen = set()
+    for (H, C, K, k, s, p) in _SNDCGAN:
+        d = _desc(N, H, C, K, k, s, p)
+        Ho = (H + 2 * p - k) // s + 1
+        for mode in (0, 1):
+            if mode == 1 and s != 1:
+                assert frac(ctypes.byref(d), mode) == 1.0           # strided data gradient: image-major, nothing skipped
+                continue
+            ext, inn = (Ho, H) if mode == 0 else (H, Ho)
+            runs = _axis_runs(ext, inn, k, s, p, mode)
+            classes = sorted(((a[2] * b[2], a[1] * b[1]) for a in runs for b in runs), key=lambda c: -c[0])
+            valid = sum(t * n for t, n in classes) / float(ext * ext * (k * k if mode == 0 or s == 1 else 1))
+            assert path(ctypes.byref(d), mode) == 3
+            assert abs(frac(ctypes.byref(d), mode) - valid) < 1e-12, (H, k, mode)
+            assert tile(ctypes.byref(d), mode, ctypes.byref(bm), ctypes.byref(bn)) == 0
+            tiles_n = -(-(K if mode == 0 else C) // bn.value)
+            if valid <= 0.80:                                        # pixel-major: image blocks x pixels
+                want = -(-N // bm.value) * ext * ext * tiles_n
+                seen.add('pixel-major')
+            else:                                                    # border classes, an eighth of each class per XCD
+                per_class = [-(-N * npix // bm.value) for _, npix in classes]
+                most = max(sum(((x + 1) * n >> 3) - (x * n >> 3) for n in per_class) for x in range(8))
+                want = 8 * most * tiles_n
+                assert sum(npix for _, npix in classes) == ext * ext and len(classes) == 9
+                seen.add('border classes')
+            assert blocks(ctypes.byref(d), mode, 1) == want, (H, k, mode, want)
+    assert seen == {'pixel-major', 'border classes'}
+    # too few images for a tile of the smallest class on every XCD: image-major tiles, everything issued
+    d = _desc(192, 8, 256, 256, 3, 1, 1)
+    assert path(ctypes.byref(d), 0) == 2 and frac(ctypes.byref(d), 0) == 1.0
+    assert path(ctypes.byref(d), 2) == 3 and abs(frac(ctypes.byref(d), 2) - 484.0 / 576.0) < 1e-12   # (WGRAD: pixel-major positions)
