@@ -1,5 +1,6 @@
 #!/bin/bash
 # dev: K-splits per parity class for the stride-2 3x3 data gradients (CONTRAD_DGRAD_SSPLIT forces S; 0 = unsplit), dgrad column
+# NEEDS tools/experiments/dgrad_strided_splitk.diff applied and the library rebuilt (the experiment was not adopted)
 # of bench_conv (includes the slab reduce)
 cd $GRAFT_REPO_ROOT
 export CONV_ITERS=20 CONV_WARM=5
