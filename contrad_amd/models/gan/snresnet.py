@@ -70,17 +70,24 @@ class D_SNResNet18(BaseDiscriminator):
                        self.projection2[2]]
 
     def _trunk(self, images, wp):
+        rec = self._recorded = [] if getattr(self, '_record_activations', False) else None   # test hook: linear regions used
         x = A.RgbConvBiasActFn.apply(images, wp[self.conv1], self.conv1.bias, 64, (3, 2.0, -1.0), _SLOPE, 1.0)
+        if rec is not None:
+            rec.append(x.detach())
         for li in range(1, 5):
             for blk in getattr(self, 'layer%d' % li):
                 p, s = blk.planes, blk.stride
                 o = A.ConvBiasActFn.apply(x, wp[blk.conv1], blk.conv1.bias, (p, 3, 3, s, 1), _SLOPE, 1.0)
+                if rec is not None:
+                    rec.append(o.detach())
                 o = A.ConvBiasActFn.apply(o, wp[blk.conv2], blk.conv2.bias, (p, 3, 3, 1, 1), 1.0, 1.0)
                 sc = x
                 if len(blk.shortcut):
                     m = blk.shortcut[0]
                     sc = A.ConvBiasActFn.apply(x, wp[m], m.bias, (p, 1, 1, s, 0), 1.0, 1.0)
                 x = A.ActFn.apply(A.LinCombFn.apply(o, sc, 1.0, 1.0), _SLOPE, 1.0)
+                if rec is not None:
+                    rec.append(x.detach())
         if x.shape[1] != 4 or x.shape[2] != 4:
             raise NotImplementedError('D_SNResNet18: 32x32 inputs (avg_pool2d(4) over the final 4x4 map, snresnet.py:86)')
         return x.mean((1, 2))                                     # (B, 512); tiny
@@ -115,9 +122,13 @@ class D_SNResNet18(BaseDiscriminator):
         def lin(m, t, K, slope):
             return A.ConvBiasActFn.apply(t, wp[m], m.bias, (K, 1, 1, 1, 0), slope, 1.0)
 
-        out = lin(self.linear.l2, lin(self.linear.l1, fd, dh, _SLOPE), 1, 1.0).view(B, 1)
-        proj = lin(self.projection[2], lin(self.projection[0], f4, dh, _SLOPE), dp, 1.0).view(B, dp)
-        proj2 = lin(self.projection2[2], lin(self.projection2[0], f4, dh, _SLOPE), dp, 1.0).view(B, dp)
+        h_l, h_p, h_p2 = lin(self.linear.l1, fd, dh, _SLOPE), lin(self.projection[0], f4, dh, _SLOPE), \
+            lin(self.projection2[0], f4, dh, _SLOPE)
+        if getattr(self, '_record_activations', False):
+            self._recorded_heads = tuple(t.detach().reshape(B, dh) for t in (h_l, h_p, h_p2))
+        out = lin(self.linear.l2, h_l, 1, 1.0).view(B, 1)
+        proj = lin(self.projection[2], h_p, dp, 1.0).view(B, dp)
+        proj2 = lin(self.projection2[2], h_p2, dp, 1.0).view(B, dp)
         return out, proj, proj2, (feat if want_features else None)
 
     def penultimate(self, inputs):

@@ -444,23 +444,30 @@ def snresnet18_param_shapes(d_hidden=1024, d_project=128):
     return shapes
 
 
-def snresnet18_features(sd, x, training=True):
-    """SNResNet.penultimate (snresnet.py:77-89) with BasicBlock.forward (:36-41)."""
+def snresnet18_features(sd, x, training=True, act_masks=None):
+    """SNResNet.penultimate (snresnet.py:77-89) with BasicBlock.forward (:36-41).  act_masks: optional list of boolean
+    masks (one per LeakyReLU, in execution order) that fix the linear region instead of the sign of the pre-activation
+    (same-region parity tests)."""
+    masks = iter(act_masks) if act_masks is not None else None
+
+    def act(y):
+        return _lrelu(y, 0.1, next(masks) if masks is not None else None)
+
     def conv(pre, h, stride, pad):
         return F.conv2d(h, spectral_norm_weight(sd, pre, training), sd[pre + '.bias'], stride=stride, padding=pad)
-    h = F.leaky_relu(conv('conv1', x * 2. - 1., 1, 1), 0.1)
+    h = act(conv('conv1', x * 2. - 1., 1, 1))
     for pre, inp, planes, s, sc in snresnet18_blocks():
-        o = F.leaky_relu(conv(pre + '.conv1', h, s, 1), 0.1)
+        o = act(conv(pre + '.conv1', h, s, 1))
         o = conv(pre + '.conv2', o, 1, 1)
         o = o + (conv(pre + '.shortcut.0', h, s, 0) if sc else h)
-        h = F.leaky_relu(o, 0.1)
+        h = act(o)
     h = F.avg_pool2d(h, 4)
     return h.reshape(h.size(0), -1)
 
 
-def snresnet18_forward(sd, x, sg_linear=False, training=True):
-    feats = snresnet18_features(sd, x, training)
-    out, proj, proj2 = d_heads(sd, feats, sg_linear, training)
+def snresnet18_forward(sd, x, sg_linear=False, training=True, act_masks=None, hidden_masks=None):
+    feats = snresnet18_features(sd, x, training, act_masks)
+    out, proj, proj2 = d_heads(sd, feats, sg_linear, training, hidden_masks)
     return out, proj, proj2, feats
 
 

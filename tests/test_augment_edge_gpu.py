@@ -162,7 +162,7 @@ def test_simclr_hq_at_512_matches_oracle():
     assert torch.equal(P2[:, 11], q['blur_mask']) and torch.equal(P2[:, 0], q['theta'][:, 0, 0])
 
 
-def test_simclr_hq_cutout_against_reference_golden(golden):
+def test_simclr_hq_cutout_against_reference_golden(golden, margin):
     """Scope row N4: `simclr_hq_cutout` (augment/__init__.py:124-133) = simclr_hq + RandomApply(CutOut(15), 0.5); golden
     from the reference pipeline, host sampler reproduces the draw order incl. CutOut's two randint draws."""
     from contrad_amd import config
@@ -200,4 +200,4 @@ def test_simclr_hq_cutout_against_reference_golden(golden):
     xd = x.to(DEV).requires_grad_()
     (aug.apply(xd, P, p['contrast_first'], p['sigma']) * w.to(DEV)).sum().backward()
     e = ((xd.grad.cpu() - xr.grad).norm() / xr.grad.norm()).item()
-    assert e < 2e-3, e
+    margin('augment backward simclr_hq_cutout 64^2 (l2)', e, 2e-3)     # clamp boundaries of single pixels

@@ -16,6 +16,8 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 FLIP_TOL = float(__import__('os').environ.get('CONTRAD_FLIP_TOL', '1e-2'))     # ReLU slope flips in G: observed < 7e-3; see tests/test_sndcgan_gpu.py
 DEV = 'cuda'
+RAW_NORM_TOL = 2e-2       # gradient norms vs the RAW golden: ReLU slope flips 1 <-> 0 in G
+AUG_BWD_TOL = 2e-3        # clamp boundaries of single pixels (pre-clamp value at 0 / 1 within fp32 rounding)
 
 
 def rel(a, b):
@@ -29,7 +31,7 @@ def l2(a, b):
 
 
 @pytest.mark.parametrize('seed', [0, 1, 2, 3])
-def test_augment_backward_matches_oracle(seed):
+def test_augment_backward_matches_oracle(seed, margin):
     """d(sum(out * w)) / d(images) through crop+flip gather, contrast, straight-through HSV and gray."""
     B = 16
     torch.manual_seed(seed); np.random.seed(seed)
@@ -48,7 +50,7 @@ def test_augment_backward_matches_oracle(seed):
     out = aug.apply(xd, P, p['contrast_first'])
     (out * w.to(DEV)).sum().backward()
     # clamp boundaries (pre-activation exactly at 0/1 after fp32 rounding) can flip single pixels: L2 criterion
-    assert l2(xd.grad, xr.grad) < 2e-3, l2(xd.grad, xr.grad)
+    margin('augment backward 32^2 seed %d (l2)' % seed, l2(xd.grad, xr.grad), AUG_BWD_TOL)
 
 
 def test_bn_relu_backward():
@@ -77,7 +79,7 @@ class _P(object):
     temp, lbd_a, distributed = 0.1, 1.0, False
 
 
-def test_generator_step_matches_reference(golden):
+def test_generator_step_matches_reference(golden, margin):
     g = golden('sndcgan_gstep')
     G, D = build()
     set_grad(G, True); set_grad(D, False)
@@ -100,14 +102,14 @@ def test_generator_step_matches_reference(golden):
             if ref < 1e-7:          # ConvT / linear biases in front of a BatchNorm: exactly-zero gradient up to noise
                 assert grads[name].norm().item() < 1e-5, name
             else:
-                assert abs(grads[name].norm().item() - ref) < 2e-2 * ref, (name, grads[name].norm().item(), ref)
+                margin('sndcgan gstep raw golden/gradnorm/' + name, abs(grads[name].norm().item() - ref) / ref, RAW_NORM_TOL)
         elif k.startswith('grad/'):
             name = k[5:]
             if float(g['gradnorm/' + name]) >= 1e-7:
-                assert l2(grads[name], g[k]) < FLIP_TOL, name
+                margin('sndcgan gstep raw golden/grad-l2/' + name, l2(grads[name], g[k]), FLIP_TOL)
 
 
-def test_generator_step_on_the_same_linear_region():
+def test_generator_step_on_the_same_linear_region(margin):
     """Strict check vs the oracle with the leaky-relu regions of D recorded from the HIP run (ReLU / clamp flips in
     G and the augmentation are absent for this seed)."""
     N = 8
@@ -142,7 +144,7 @@ def test_generator_step_on_the_same_linear_region():
         ref = ogsd[k].grad
         if ref.norm().item() < 1e-7:
             continue
-        assert l2(prm.grad, ref) < 5e-3, (k, l2(prm.grad, ref))
+        margin('sndcgan gstep same-region/grad-l2/' + k, l2(prm.grad, ref), TOL)
 
 
 def test_no_grad_forward_sees_the_optimizer_update():

@@ -22,6 +22,8 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 FLIP_TOL = float(__import__('os').environ.get('CONTRAD_FLIP_TOL', '1e-3'))
 DEV = 'cuda'
+RAW_NORM_TOL = 2e-2       # gradient norms vs the RAW golden: slope flips of single units
+AUG_BWD_TOL = 2e-3        # clamp boundaries of single pixels (pre-clamp value at 0 / 1 within fp32 rounding)
 
 
 def rel(a, b):
@@ -84,7 +86,7 @@ class _P(object):
     temp, lbd_a, distributed = 0.1, 1.0, False
 
 
-def test_stylegan2_generator_step_matches_reference(golden):
+def test_stylegan2_generator_step_matches_reference(golden, margin):
     g = golden('stylegan2_gstep')
     G, D, _ = _build(int(g['gseed']), int(g['dseed']))
     set_grad(G, True); set_grad(D, False)
@@ -115,14 +117,14 @@ def test_stylegan2_generator_step_matches_reference(golden):
                 assert grads[name].norm().item() < 1e-6, name
             else:
                 e = abs(grads[name].norm().item() - ref) / ref
-                assert e < 2e-2, (name, e)
+                margin('stylegan2 gstep raw golden/gradnorm/' + name, e, RAW_NORM_TOL)
         elif k.startswith('grad/'):
             name = k[5:]
             if float(g['gradnorm/' + name]) >= 1e-9:
-                assert l2(grads[name], g[k]) < FLIP_TOL, (name, l2(grads[name], g[k]))
+                margin('stylegan2 gstep raw golden/grad-l2/' + name, l2(grads[name], g[k]), FLIP_TOL)
 
 
-def test_stylegan2_generator_step_on_the_same_linear_region():
+def test_stylegan2_generator_step_on_the_same_linear_region(margin):
     """Strict element-wise check against the oracle with D's leaky-relu regions recorded from the HIP run."""
     B = 4
     G, D, gsd = _build(780, 2026)
@@ -161,11 +163,11 @@ def test_stylegan2_generator_step_on_the_same_linear_region():
         if ref.norm().item() < 1e-9:
             continue
         # G's own leaky-relus / the augmentation's clamps can still flip single units: L2 criterion
-        assert l2(prm.grad, ref) < 5e-3, (k, l2(prm.grad, ref))
+        margin('stylegan2 gstep same-region/grad-l2/' + k, l2(prm.grad, ref), TOL)
 
 
 @pytest.mark.parametrize('size,B', [(96, 5), (512, 3)])
-def test_large_image_augment_backward_matches_oracle(size, B):
+def test_large_image_augment_backward_matches_oracle(size, B, margin):
     """d(sum(out * w)) / d(images) through simclr_hq at sizes beyond the LDS-resident path: gather transpose, contrast,
     straight-through HSV, gray, and the masked Gaussian blur's reflect-padding transpose (ksize 9 / 51)."""
     from sg2_inputs import seeded_images
@@ -190,7 +192,7 @@ def test_large_image_augment_backward_matches_oracle(size, B):
         xd = x.to(DEV).requires_grad_()
         out = aug.apply(xd, P, cf, p['sigma'])
         (out * w.to(DEV)).sum().backward()
-        assert l2(xd.grad, xr.grad) < 2e-3, (cf, l2(xd.grad, xr.grad))
+        margin('augment backward %d^2 contrast_first=%s (l2)' % (size, cf), l2(xd.grad, xr.grad), AUG_BWD_TOL)
 
 
 def test_blur_adjoint_identity():
