@@ -117,8 +117,9 @@ def cpu_baseline_c10(n=64):
 
 
 def cpu_baseline_sg2(name, n):
-    """The oracle's StyleGAN2 discriminator step on the host cores (D forward/backward + losses + R1 + Adam on a fixed
-    synthetic fake batch: the generator forward, ~9 % of the FLOPs, is left out of the CPU sample and said so)."""
+    """The oracle's StyleGAN2 D-step on the host cores -- the same step the GPU side times: generator forward under
+    no_grad (fresh latents, per-layer noise and style mixing each step), augmentation, D forward / backward, losses
+    [+ R1], Adam."""
     from oracle import contrad_oracle as O
     from oracle import stylegan2_oracle as S
     cfg = CONFIGS[name]
@@ -134,7 +135,10 @@ def cpu_baseline_sg2(name, n):
     m = {k: torch.zeros_like(sd[k]) for k in params}
     v = {k: torch.zeros_like(sd[k]) for k in params}
     x = torch.rand(n, 3, size, size)
-    fake = torch.rand(n, 3, size, size)
+    gshapes = S.g_param_shapes(size, small32, cm)
+    gsd = S.fill_kernels(S.det_fill_g(gshapes), gshapes)
+    log_size = int(np.log2(size))
+    n_latent, n_noise = 2 * log_size - 2, 2 * log_size - 3
     aug_cfg = O.SIMCLR_CIFAR if name == 'sg2_32' else O.SIMCLR_HQ_AFHQ
     lr = 2e-3 if small32 else 2.5e-3
     every = cfg['d_reg_every']
@@ -149,6 +153,10 @@ def cpu_baseline_sg2(name, n):
         return tuple(torch.cat([a, b]) for a, b in zip(r, f))
 
     def step(t):
+        with torch.no_grad():             # Generator.forward in train mode, style_mix 0.9 (generator.py:236-291)
+            noise = [torch.randn(n, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2)) for i in range(n_noise)]
+            mix_layer = torch.where(torch.rand(n) < 0.9, torch.randint(1, n_latent, (n,)), torch.full((n,), n_latent))
+            fake = S.g_forward(gsd, torch.randn(n, 512), size, noise, mix=(torch.randn(n, 512), mix_layer))
         if name == 'sg2_32':
             aug = O.simclr_apply(torch.cat([x, x, fake]), O.sample_simclr_params(3 * n, size, size, aug_cfg))
         else:
@@ -170,10 +178,56 @@ def cpu_baseline_sg2(name, n):
 
     dt, steps = _time_cpu(step, max_steps=3)
     return {"value": n / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%s ContraD D-step (augment + D fwd/bwd + losses%s + Adam; fakes synthetic, G forward not "
-                      "included), %dx%d, batch %d, %d timed steps after 1 warm-up (oracle = PyTorch-CPU restatement, "
+            "sample": "%s ContraD D-step (G forward no-grad + augment + D fwd/bwd + losses%s + Adam), %dx%d, batch %d, "
+                      "%d timed steps after 1 warm-up (oracle = PyTorch-CPU restatement, "
                       "%.3f s/step)" % (cfg['arch'], ' + R1 every step' if name == 'sg2_32' else ', no R1 step in the sample',
                                         size, size, n, steps, dt)}
+
+
+class _GraphWatchdog(object):
+    """Per-rank deadline around the graph capture + replay of one workload (world size > 1 only; main() has the order)."""
+
+    def __init__(self, rank, timeout, results, emit):
+        self.rank, self.timeout, self.results, self.emit = rank, timeout, results, emit
+        self.kept, self.timer = {}, None
+
+    def keep(self, name, out):               # rank 0: the eager result of the workload that is about to capture
+        self.kept[name] = out
+
+    def arm(self, name):
+        import threading
+        self.timer = threading.Timer(self.timeout, self._fire, args=(name,))
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self, name):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+        self.kept.pop(name, None)
+
+    def _fire(self, name):
+        sys.stderr.write('bench.py: rank %d: %s did not get through graph capture + replay within %.0f s; reporting the '
+                         'eager result\n' % (self.rank, name, self.timeout))
+        sys.stderr.flush()
+        if self.rank == 0 and name in self.kept:
+            self.results[name] = self.kept[name]
+            self.emit()
+        sys.stdout.flush()
+        os._exit(0)
+
+
+def _gloo_row_gather():
+    """--dev-backend gloo: gloo has no all_gather_into_tensor for device tensors; the list form gives the same rows."""
+    import contrad_amd.third_party.gather_layer as gl
+    import contrad_amd.training.gan.contrad as cd
+
+    def gather_rows(x):
+        outs = [torch.empty_like(x) for _ in range(dist.get_world_size())]
+        dist.all_gather(outs, x.contiguous())
+        return torch.stack(outs, 0)
+    gl.all_gather_rows = gather_rows
+    cd.all_gather_rows = gather_rows
 
 
 def _free_port():
@@ -260,7 +314,7 @@ def _csrc_fingerprint():
     return h.hexdigest()[:16]
 
 
-def run_config(name, args, world, rank, dev, multi):
+def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=None):
     from contrad_amd import config, ops
     from contrad_amd.augment import get_augment
     from contrad_amd.engine import (GradAllReducer, OverlappedGradReducer, d_step, d_step_stylegan2,
@@ -352,13 +406,125 @@ def run_config(name, args, world, rank, dev, multi):
     if args.shape_table and rank == 0:
         _write_shape_table(args.shape_table, name, cfg, warm_prof, marks, n_local)
     del warm_prof
-    ops.PROFILE_ONLY = max(wagg.items(), key=lambda kv: kv[1][0])[0] if wagg else None
+    dom_name = max(wagg.items(), key=lambda kv: kv[1][0])[0] if wagg else None
+    ops.PROFILE_ONLY = dom_name
+    peak_box = [None]                     # peak HBM of the D-step (read before the generator-step side measurement)
+
+    def timed_region():
+        """EXACTLY `steps` steps between two barrier + synchronize brackets; MAX over ranks."""
+        if cfg['d_reg_every'] > 1:      # lazy R1: start right after an R1 step, so K steps hold exactly K // period of them
+            counter[0] = 0
+        barrier()
+        t0 = time.perf_counter()
+        if os.environ.get('CONTRAD_BENCH_STEP_TIMES'):          # dev: per-step wall times (synchronises every step)
+            for i in range(steps):
+                ts = time.perf_counter()
+                d_loss, aux = one_step()
+                torch.cuda.synchronize()
+                sys.stderr.write('%s step %d: %.2f ms\n' % (name, i + 1, (time.perf_counter() - ts) * 1e3))
+        else:
+            for _ in range(steps):
+                d_loss, aux = one_step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if multi:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        finite = bool(torch.isfinite(d_loss).item() and torch.isfinite(aux['penalty']).item())
+        return dt, finite
+
+    def make_out(dt, finite, prof, nprof_steps, launch, dom, wagg_, wsteps_):
+        """This workload's JSON object from one timed region (rank 0 only)."""
+        ms = dt / steps * 1e3
+        value = global_batch * steps / dt
+        graph_run = launch == 'hipGraph replay'
+        # dominant kernel = the conv-engine instance with the largest summed device time (chosen on the warm-up
+        # steps); its launches in the timed region are the `achieved` figure
+        if dom is None:                                             # --warmup 0: everything was bracketed
+            tagg = {}
+            for n_, f_, e0, e1, _s, _b, ex_ in prof:
+                a = tagg.setdefault(n_, [0.0, 0.0, 0, 0.0])
+                a[0] += e0.elapsed_time(e1) * 1e-3; a[1] += f_; a[2] += 1; a[3] += f_ * ex_
+            dom = max(tagg.items(), key=lambda kv: kv[1][0])[0]
+            wagg_, wsteps_ = tagg, steps
+            prof = [q for q in prof if q[0] == dom]
+        tsum = sum(q[2].elapsed_time(q[3]) for q in prof) * 1e-3
+        fsum = sum(q[1] for q in prof)
+        xsum = sum(q[1] * q[6] for q in prof)          # flops the kernel issued (pixel-major tiles skip padding taps)
+        cnt = max(len(prof), 1)
+        achieved = fsum / max(tsum, 1e-12) / 1e12
+        executed = xsum / max(tsum, 1e-12) / 1e12
+        conv_time_per_step = sum(a[0] for a in wagg_.values()) / wsteps_
+        traffic, traffic_src = _pmc_traffic(name, dom) if world == 1 else (None, None)
+        fpi = cfg['flop_per_image']
+        if cfg['d_reg_every'] > 1:      # lazy R1: price the R1 steps actually inside the timed window, not 1 / period
+            fpi = cfg['flop_plain'] + cfg['flop_r1'] * (steps // cfg['d_reg_every']) / steps
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic,
+                    "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                    "launches_per_step": cnt / nprof_steps, "avg_launch_ms": round(tsum / cnt * 1e3, 4),
+                    "algorithmic_gflop_per_launch": round(fsum / cnt / 1e9, 2),
+                    "flop_convention": "achieved / frac are quoted on the layer's nominal count 2*N*Ho*Wo*K*C*KH*KW (SURVEY.md "
+                                       "8d: the dense layer of the reference, tap-positions that read zero padding "
+                                       "included); `executed` prices only the multiply-adds the kernel issues -- its "
+                                       "pixel-major tiles (contrad_conv2d_path == 3) skip the padding tap-positions of "
+                                       "the layers on 4x4 / 8x8 maps",
+                    "executed": {"gflop_per_launch": round(xsum / cnt / 1e9, 2), "tflops": round(executed, 2),
+                                 "frac_of_peak": round(executed / PEAK_FP32_MFMA, 4),
+                                 "share_of_nominal": round(xsum / max(fsum, 1.0), 4)},
+                    "bracket": "HIP events around the C-ABI call on its stream" +
+                               (" (igemm WGRAD kernel + its wgrad_reduce_kernel)" if "<2," in dom else "") +
+                               ("; the timed region replays one captured hipGraph per step, so the bracketed launches are "
+                                "those of %d eager steps run right after it" % nprof_steps if graph_run else ""),
+                    "conv_engine_share_of_step": round(conv_time_per_step / (dt / steps), 3),
+                    "all_kernels_warmup": {k: {"tflops": round(v[1] / v[0] / 1e12, 1),
+                                               "executed_tflops": round(v[3] / v[0] / 1e12, 1),
+                                               "ms_per_step": round(v[0] / wsteps_ * 1e3, 3)}
+                                           for k, v in sorted(wagg_.items())},
+                    "step_level": {"achieved": round(value / world * fpi / 1e12, 2),
+                                   "frac": round(value / world * fpi / 1e12 / PEAK_FP32_MFMA, 4),
+                                   "flop_per_image": fpi}}
+        out = {"metric": "discriminator-step images/sec (ContraD, SimCLR aug)", "value": round(value, 1),
+               "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
+               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": cfg['workload'] % batch, "name": name,
+                          "global_batch": global_batch, "per_gpu_batch": n_local,
+                          "parallelism": "dp%d" % world, "losses_finite": finite,
+                          "launch": launch,
+                          "rccl_ranks": dist.get_world_size() if multi else 1,
+                          "backend": dist.get_backend() if multi else None,
+                          "peak_hbm_gib": round((peak_box[0] or torch.cuda.max_memory_allocated(dev)) / 2 ** 30, 2)},
+               "roofline": roofline}
+        if cfg['d_reg_every'] > 1:
+            out["config"]["r1_steps_in_window"] = steps // cfg['d_reg_every']
+        return out
+
+    # With more than one rank the EAGER launch sequence is timed FIRST and its result kept where main()'s watchdog can
+    # print it: a hipGraph with captured RCCL collectives has never been built on several ranks at once on this stack,
+    # and a capture that HANGS -- unlike one that raises -- cannot be caught.  The capture then runs under that per-rank
+    # watchdog (--graph-timeout); if it completes, the replayed steps are timed the same way and are the reported figure,
+    # with the eager one beside it (config.eager_ms_per_step).
+    eager = None
+    if use_graph and world > 1:
+        dt_e, finite_e = timed_region()
+        eager = (dt_e, finite_e, ops.PROFILE)
+        ops.PROFILE = []
+        if rank == 0:
+            keep(name, make_out(dt_e, finite_e, eager[2], steps, 'eager (graph capture timed out)', dom_name, wagg, wsteps))
+        arm(name)                            # from here until disarm(): a rank that stops making progress is reported, not waited for
+
+    launch = 'hipGraph replay' if use_graph else 'eager'
     if use_graph:
         # the timed region replays ONE captured hipGraph per step (engine.GraphedDStep); events cannot sit inside a
         # graph, so the dominant kernel is bracketed on eager steps run right after the timed region instead
         from contrad_amd.engine import GraphedDStep, GraphedSG2DStep
         ops.PROFILE = None
         try:
+            if os.environ.get('CONTRAD_BENCH_FAKE_CAPTURE_HANG') and world > 1:      # test hook: a capture that never returns
+                while True:
+                    time.sleep(0.5)
             if name == 'c10_b512':
                 graphed[0] = GraphedDStep(P, G, D, opt_D, options, images, warmup=1)
             else:
@@ -373,40 +539,26 @@ def run_config(name, args, world, rank, dev, multi):
         except Exception as e:              # capture not available on this stack: the eager launch sequence is the same work
             sys.stderr.write('bench.py: hipGraph capture failed (%r); timing the eager launch sequence\n' % (e,))
             graphed[0], use_graph = None, False
+            launch = 'eager (graph capture failed: %s)' % type(e).__name__
             ops.PROFILE = []
-    # the lazy-R1 schedule: start the timed window right after an R1 step so that K steps contain exactly K // period
-    if cfg['d_reg_every'] > 1:
-        counter[0] = 0
-    barrier()
-    t0 = time.perf_counter()
-    if os.environ.get('CONTRAD_BENCH_STEP_TIMES'):          # dev: per-step wall times (synchronises every step)
-        for i in range(steps):
-            ts = time.perf_counter()
-            d_loss, aux = one_step()
-            torch.cuda.synchronize()
-            sys.stderr.write('%s step %d: %.2f ms\n' % (name, i + 1, (time.perf_counter() - ts) * 1e3))
+    if eager is not None and not use_graph:
+        dt, finite, prof = eager            # the eager steps were timed above; nothing to repeat
+        nprof_steps = steps
+        ops.PROFILE = None
     else:
-        for _ in range(steps):
-            d_loss, aux = one_step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if use_graph:                       # same kernels, same shapes, eager launches with the dominant kernel bracketed
-        graphed[0] = None
-        ops.PROFILE = []
-        for _ in range(max(3, steps // 4)):
-            one_step()
-        torch.cuda.synchronize()
-    prof, ops.PROFILE = ops.PROFILE, None
-    dom_name, ops.PROFILE_ONLY = ops.PROFILE_ONLY, None
-    nprof_steps = max(3, steps // 4) if use_graph else steps
-    if multi:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    ms = dt / steps * 1e3
-    value = global_batch * steps / dt
-    finite = bool(torch.isfinite(d_loss).item() and torch.isfinite(aux['penalty']).item())
-    peak_mem = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+        dt, finite = timed_region()
+        if use_graph:                       # same kernels, same shapes, eager launches with the dominant kernel bracketed
+            graphed[0] = None
+            ops.PROFILE = []
+            for _ in range(max(3, steps // 4)):
+                one_step()
+            torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        nprof_steps = max(3, steps // 4) if use_graph else steps
+    if eager is not None:
+        disarm(name)
+    ops.PROFILE_ONLY = None
+    peak_box[0] = torch.cuda.max_memory_allocated(dev)
 
     # ---- generator step, reported separately -- never part of `value` ----
     g_step = None
@@ -445,65 +597,9 @@ def run_config(name, args, world, rank, dev, multi):
             sys.stderr.write('bench.py: generator-step measurement skipped (%r)\n' % (e,))
     out = None
     if rank == 0:
-        # dominant kernel = the conv-engine instance with the largest summed device time (chosen on the warm-up
-        # steps); its launches in the timed region are the `achieved` figure
-        if dom_name is None:                                        # --warmup 0: everything was bracketed
-            tagg = {}
-            for n_, f_, e0, e1, _s, _b, ex_ in prof:
-                a = tagg.setdefault(n_, [0.0, 0.0, 0, 0.0])
-                a[0] += e0.elapsed_time(e1) * 1e-3; a[1] += f_; a[2] += 1; a[3] += f_ * ex_
-            dom_name = max(tagg.items(), key=lambda kv: kv[1][0])[0]
-            wagg, wsteps = tagg, steps
-            prof = [q for q in prof if q[0] == dom_name]
-        tsum = sum(q[2].elapsed_time(q[3]) for q in prof) * 1e-3
-        fsum = sum(q[1] for q in prof)
-        xsum = sum(q[1] * q[6] for q in prof)          # flops the kernel issued (pixel-major tiles skip padding taps)
-        cnt = max(len(prof), 1)
-        achieved = fsum / max(tsum, 1e-12) / 1e12
-        executed = xsum / max(tsum, 1e-12) / 1e12
-        conv_time_per_step = sum(a[0] for a in wagg.values()) / wsteps
-        traffic, traffic_src = _pmc_traffic(name, dom_name) if world == 1 else (None, None)
-        fpi = cfg['flop_per_image']
-        if cfg['d_reg_every'] > 1:      # lazy R1: price the R1 steps actually inside the timed window, not 1 / period
-            fpi = cfg['flop_plain'] + cfg['flop_r1'] * (steps // cfg['d_reg_every']) / steps
-        roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic,
-                    "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                    "launches_per_step": cnt / nprof_steps, "avg_launch_ms": round(tsum / cnt * 1e3, 4),
-                    "algorithmic_gflop_per_launch": round(fsum / cnt / 1e9, 2),
-                    "flop_convention": "achieved / frac are quoted on the layer's nominal count 2*N*Ho*Wo*K*C*KH*KW (SURVEY.md "
-                                       "8d: the dense layer of the reference, tap-positions that read zero padding "
-                                       "included); `executed` prices only the multiply-adds the kernel issues -- its "
-                                       "pixel-major tiles (contrad_conv2d_path == 3) skip the padding tap-positions of "
-                                       "the layers on 4x4 / 8x8 maps",
-                    "executed": {"gflop_per_launch": round(xsum / cnt / 1e9, 2), "tflops": round(executed, 2),
-                                 "frac_of_peak": round(executed / PEAK_FP32_MFMA, 4),
-                                 "share_of_nominal": round(xsum / max(fsum, 1.0), 4)},
-                    "bracket": "HIP events around the C-ABI call on its stream" +
-                               (" (igemm WGRAD kernel + its wgrad_reduce_kernel)" if "<2," in dom_name else "") +
-                               ("; the timed region replays one captured hipGraph per step, so the bracketed launches are "
-                                "those of %d eager steps run right after it" % nprof_steps if use_graph else ""),
-                    "conv_engine_share_of_step": round(conv_time_per_step / (dt / steps), 3),
-                    "all_kernels_warmup": {k: {"tflops": round(v[1] / v[0] / 1e12, 1),
-                                               "executed_tflops": round(v[3] / v[0] / 1e12, 1),
-                                               "ms_per_step": round(v[0] / wsteps * 1e3, 3)}
-                                           for k, v in sorted(wagg.items())},
-                    "step_level": {"achieved": round(value / world * fpi / 1e12, 2),
-                                   "frac": round(value / world * fpi / 1e12 / PEAK_FP32_MFMA, 4),
-                                   "flop_per_image": fpi}}
-        out = {"metric": "discriminator-step images/sec (ContraD, SimCLR aug)", "value": round(value, 1),
-               "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
-               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
-               "config": {"workload": cfg['workload'] % batch, "name": name,
-                          "global_batch": global_batch, "per_gpu_batch": n_local,
-                          "parallelism": "dp%d" % world, "losses_finite": finite,
-                          "launch": "hipGraph replay" if use_graph else "eager",
-                          "rccl_ranks": dist.get_world_size() if multi else 1,
-                          "peak_hbm_gib": round(peak_mem, 2)},
-               "roofline": roofline}
-        if cfg['d_reg_every'] > 1:
-            out["config"]["r1_steps_in_window"] = steps // cfg['d_reg_every']
+        out = make_out(dt, finite, prof, nprof_steps, launch, dom_name, wagg, wsteps)
+        if eager is not None:
+            out["config"]["eager_ms_per_step"] = round(eager[0] / steps * 1e3, 3)
         if g_step is not None:
             out["g_step"] = g_step
     # release this workload's memory before the next one
@@ -531,6 +627,12 @@ def main():
                     help='dev: run all collective code paths on a 1-rank RCCL group (single GPU)')
     ap.add_argument('--dev-local-batch', type=int, default=0,
                     help='dev: single-GPU run at this batch (what one rank of an N-GPU job sees); not the headline config')
+    ap.add_argument('--graph-timeout', type=float, default=240.0,
+                    help='N > 1: seconds a workload may spend between the end of its eager timed region and the end of its '
+                         'graph-replay timed region; past that every rank stops and rank 0 prints the line with the eager result')
+    ap.add_argument('--dev-backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="dev: process-group backend.  'gloo' lets several ranks share ONE GPU (RCCL refuses that), so the "
+                         "self-launch, the barriers, the MAX over ranks and the fallback order can be exercised on a 1-GPU box")
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -547,6 +649,8 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit('bench.py --gpus %d inside a launch of WORLD_SIZE=%d' % (args.gpus, world))
+    if args.dev_backend == 'gloo':
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     multi = world > 1 or args.force_dist
@@ -560,7 +664,11 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29566')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=dev)     # "nccl" is RCCL on ROCm
+        if args.dev_backend == 'gloo':
+            dist.init_process_group('gloo')
+            _gloo_row_gather()
+        else:
+            dist.init_process_group('nccl', device_id=dev)     # "nccl" is RCCL on ROCm
         if args.force_dist:
             import contrad_amd.engine as _eng
             _eng.FORCE_DIST = True
@@ -569,12 +677,25 @@ def main():
     if args.dev_local_batch:
         names = names[:1]
     results = {}
+
+    def emit():
+        out = results[names[0]]
+        rest = {n: results[n] for n in names[1:] if n in results}
+        if rest:
+            out["other_configs"] = rest
+        print(json.dumps(out), flush=True)
+
+    # Fallback order with more than one rank: (1) the eager steps of a workload are timed and kept,
+    # (2) graph capture + replay run under this watchdog, (3) if they do not finish within --graph-timeout every rank
+    # leaves through os._exit(0) -- a rank blocked inside a collective cannot be unwound -- and rank 0 first prints the
+    # line with what it has: finished workloads as they are, the current one with its eager result.
+    wd = _GraphWatchdog(rank, args.graph_timeout, results, emit)
     for i, name in enumerate(names):
         if i == 0:
-            results[name] = run_config(name, args, world, rank, dev, multi)
+            results[name] = run_config(name, args, world, rank, dev, multi, wd.keep, wd.arm, wd.disarm)
             continue
         try:                                     # a side workload must never take the headline line down
-            results[name] = run_config(name, args, world, rank, dev, multi)
+            results[name] = run_config(name, args, world, rank, dev, multi, wd.keep, wd.arm, wd.disarm)
         except Exception as e:
             results[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if multi:
@@ -591,10 +712,7 @@ def main():
                     results[name]["cpu_baseline"] = cpu_baseline_sg2(name, 16)
                 else:
                     results[name]["cpu_baseline"] = cpu_baseline_sg2(name, 2)
-        out = results[names[0]]
-        if len(names) > 1:
-            out["other_configs"] = {n: results[n] for n in names[1:]}
-        print(json.dumps(out), flush=True)
+        emit()
 
 
 if __name__ == '__main__':

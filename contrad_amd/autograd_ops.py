@@ -376,6 +376,10 @@ def flipped_kernel(kernel):
     key = (kernel.data_ptr(), kernel._version, tuple(kernel.shape), str(kernel.device))
     hit = _FLIPPED.get(key)
     if hit is None:
+        if torch.cuda.is_current_stream_capturing():
+            # a tensor created inside a capture lives in the graph's private pool and holds data only after a replay:
+            # never let eager code find it in the cache
+            return torch.flip(kernel.detach(), [0, 1]).contiguous()
         if len(_FLIPPED) > 64:
             _FLIPPED.clear()
         hit = _FLIPPED[key] = (torch.flip(kernel.detach(), [0, 1]).contiguous(), kernel)   # (keeps the storage alive)
@@ -400,6 +404,30 @@ class UpFirDn2dBackwardFn(Function):
         kernel, = ctx.saved_tensors
         up, down, pad = ctx.cfg
         return UpFirDn2dFn.apply(h, kernel, up, down, pad), None, None, None, None, None, None
+
+
+class ZeroGradFn(Function):
+    """Identity on ``out`` that hands exact-zero gradients to ``params`` -- the effect of the reference's
+    ``output + (projection.mean() + projection2.mean()) * 0.`` (models/gan/base.py:139-141) for a call that skips the
+    projection GEMMs: every parameter of the module still receives a gradient, so optimizer state and step counts stay
+    uniform across training modes."""
+
+    @staticmethod
+    def forward(ctx, out, *params):
+        ctx.shapes = [p.shape for p in params]
+        return out.view(out.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        if _INPUT_GRAD_ONLY:
+            return (g,) + (None,) * len(ctx.shapes)
+        flat = torch.zeros(sum(int(torch.Size(s).numel()) for s in ctx.shapes), device=g.device, dtype=g.dtype)
+        outs, o = [], 0
+        for s in ctx.shapes:
+            n = int(torch.Size(s).numel())
+            outs.append(flat[o:o + n].view(s))
+            o += n
+        return (g,) + tuple(outs)
 
 
 class LinCombFn(Function):
@@ -461,6 +489,12 @@ class PackWeightsFn(Function):
 
     @staticmethod
     def backward(ctx, *gouts):
+        if _INPUT_GRAD_ONLY:
+            # input_grad_only() is a process-wide switch around ONE autograd.grad call that asks for d / d images only;
+            # a weight gradient arriving here means another backward is running inside it and is silently losing its
+            # parameter gradients -- refuse instead
+            raise RuntimeError('PackWeightsFn.backward inside autograd_ops.input_grad_only(): a backward that needs '
+                               'parameter gradients is running while they are switched off')
         meta = ctx.meta
         meta.dead = True
         if meta.on_backward is not None:

@@ -16,6 +16,16 @@
     if (!(cond)) return -22; /* -EINVAL */           \
   } while (0)
 
+// Development switches (tile modes, split-K on/off, forced tiles ...; tools/README.md) exist only in the variant built with
+// -DCONTRAD_DEV_SWITCHES (libcontrad_hip_dev.so, contrad_amd/build.py; tools/build_variant.sh): the shipped library never
+// reads its environment, so an integrator's environment cannot change a launch plan (no hidden state).
+#ifdef CONTRAD_DEV_SWITCHES
+#include <stdlib.h>
+static inline const char* contrad_dev_env(const char* name) { return getenv(name); }
+#else
+static inline const char* contrad_dev_env(const char*) { return nullptr; }
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_c32_kernel(const ConvC32Args a) {
 
 // 3x3, stride 1, pad 1, 32 -> 32 channels, dense NHWC in and out, the map divisible into 4 x 32 pixel tiles
 inline bool conv_c32_ok(const contrad_conv_desc* d) {
-  static const bool enabled = []() { const char* e = getenv("CONTRAD_CONV_C32"); return !(e && e[0] == '0'); }();
+  static const bool enabled = []() { const char* e = contrad_dev_env("CONTRAD_CONV_C32"); return !(e && e[0] == '0'); }();
   return enabled && d->C == 32 && d->K == 32 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
          d->ldx == 32 && d->ldy == 32 && d->ldw >= 32 && (d->W % CC_TW) == 0 && (d->H % CC_TH) == 0 &&
          (long long)d->N * d->H * d->W >= 1 << 16;       // (small maps: the engine's tiles fill the chip better)

@@ -769,8 +769,11 @@ constexpr size_t smem_bytes(int mode) {
 
 template <int MODE, int BM, int BN, bool VEC>
 int launch(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
-  static bool attr_set = false;  // benign race: idempotent
+  static bool attr_set_dev[64] = {};  // per device (one process may drive several); benign race: idempotent
   const size_t smem = smem_bytes<BM, BN>(MODE);
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  bool& attr_set = attr_set_dev[dev_id & 63];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<MODE, BM, BN, VEC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -788,8 +791,11 @@ int launch(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
 
 template <int MODE, int BM, int BN>
 int launch_lean(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
-  static bool attr_set = false;  // benign race: idempotent
+  static bool attr_set_dev[64] = {};  // per device (one process may drive several); benign race: idempotent
   constexpr size_t smem = lean_smem_bytes<MODE, BM, BN>();
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  bool& attr_set = attr_set_dev[dev_id & 63];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lean_kernel<MODE, BM, BN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -805,7 +811,7 @@ int launch_lean(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
 
 // Does the shape fit the lean loop (igemm_lean.h)?  pps = WGRAD position tiles per split.
 bool lean_ok(const contrad_conv_desc* d, int mode, long long pps) {
-  static const bool enabled = []() { const char* e = getenv("CONTRAD_IGEMM_LEAN"); return !(e && e[0] == '0'); }();
+  static const bool enabled = []() { const char* e = contrad_dev_env("CONTRAD_IGEMM_LEAN"); return !(e && e[0] == '0'); }();
   if (!enabled || BK != 16) return false;
   const long long lim = 1ll << 31;
   if (d->KH * d->KW > 32) return false;
@@ -853,7 +859,7 @@ void pick_tile(long long M, int Ncol, bool vec, bool lean, int mult, int* bm, in
   // back is the instruction overhead per block -- prologue, epilogue and loop control around only 144 MFMAs per wave --
   // plus the loop's memory instructions: ablation table in DESIGN.md section 7, tools/dev/ablate32.sh.)
   if (lean && Ncol <= 32) { *bm = 128; *bn = 32; return; }
-  static const int forced = []() { const char* e = getenv("CONTRAD_IGEMM_TILE"); return e ? atoi(e) : 0; }();  // dev: "128064"
+  static const int forced = []() { const char* e = contrad_dev_env("CONTRAD_IGEMM_TILE"); return e ? atoi(e) : 0; }();  // dev: "128064"
   if (forced) { *bm = forced / 1000; *bn = forced % 1000; return; }
   static const int cand[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
   for (int i = (Ncol > 64 ? 0 : 2); i < 4; ++i) {
@@ -907,9 +913,9 @@ int wgrad_plan(const contrad_conv_desc* d, int* bm, int* bn, int* tiles_m, int* 
   const long long P = (long long)d->N * d->Ho * d->Wo;
   *bn = (d->K > 64) ? 128 : 64;
   *bm = (Kg > 64) ? 128 : 64;
-  static const int forced = []() { const char* e = getenv("CONTRAD_WGRAD_TILE"); return e ? atoi(e) : 0; }();  // dev
+  static const int forced = []() { const char* e = contrad_dev_env("CONTRAD_WGRAD_TILE"); return e ? atoi(e) : 0; }();  // dev
   if (forced) { *bm = forced / 1000; *bn = forced % 1000; }
-  static const int target = []() { const char* e = getenv("CONTRAD_WGRAD_BLOCKS"); return e ? atoi(e) : 1024; }();  // dev
+  static const int target = []() { const char* e = contrad_dev_env("CONTRAD_WGRAD_BLOCKS"); return e ? atoi(e) : 1024; }();  // dev
   if (!vec_ok(d, MODE_WGRAD)) { *bm = 64; *bn = 64; }
   *tiles_m = cdiv(Kg, *bm);
   *tiles_n = cdiv(d->K, *bn);
@@ -1003,7 +1009,7 @@ bool fwd_k1_ok(const contrad_conv_desc* d) {
 }
 
 bool splitk_enabled() {
-  static const bool on = []() { const char* e = getenv("CONTRAD_IGEMM_SPLITK"); return !(e && e[0] == '0'); }();
+  static const bool on = []() { const char* e = contrad_dev_env("CONTRAD_IGEMM_SPLITK"); return !(e && e[0] == '0'); }();
   return on;
 }
 
@@ -1019,7 +1025,7 @@ constexpr double PIXMAJOR_MAX_VALID = 0.80;
 constexpr double PIXMAJOR_WGRAD_MAX_VALID = 0.85;
 
 bool pixmajor_enabled() {
-  static const bool on = []() { const char* e = getenv("CONTRAD_PIXMAJOR"); return !(e && e[0] == '0'); }();
+  static const bool on = []() { const char* e = contrad_dev_env("CONTRAD_PIXMAJOR"); return !(e && e[0] == '0'); }();
   return on;
 }
 
@@ -1081,7 +1087,7 @@ bool dgrad_pixmajor_ok(const contrad_conv_desc* d, int bm) {
   // stride 1 only: the kernel walks pixel-major tiles inside the parity classes of a strided layer just as well (parity
   // holds, CONTRAD_PIXMAJOR_STRIDED=1), but a class tile then contracts over 1 .. 4 taps only and the 4x4 stride-2
   // layer onto 4x4 maps ran 0.714 -> 0.757 ms at 1536 images
-  static const bool strided = []() { const char* e = getenv("CONTRAD_PIXMAJOR_STRIDED"); return e && e[0] == '1'; }();
+  static const bool strided = []() { const char* e = contrad_dev_env("CONTRAD_PIXMAJOR_STRIDED"); return e && e[0] == '1'; }();
   if (!pixmajor_enabled() || d->H * d->W > 256 || d->N < bm || (d->stride != 1 && !strided)) return false;
   if ((long long)bm * d->Ho * d->Wo * d->ldy * 4 >= (1ll << 30)) return false;    // row offsets inside a tile (bytes)
   if ((long long)bm * d->H * d->W * d->ldx * 4 >= (1ll << 30)) return false;      // the epilogue's row offsets
@@ -1094,7 +1100,7 @@ bool wgrad_pixmajor_ok(const contrad_conv_desc* d, int bm, long long pps) {
   if (!pixmajor_enabled() || !vec_ok(d, MODE_WGRAD) || !lean_ok(d, MODE_WGRAD, pps)) return false;
   if (bm != 128 || (d->C % 128) != 0 || (d->N % 16) != 0 || d->Ho < 2 || d->Wo < 2 || d->Ho * d->Wo > 256) return false;
   if (d->pad > d->stride) return false;                                  // interior pixels must never touch padding
-  static const double lim = []() { const char* e = getenv("CONTRAD_PIXMAJOR_WGRAD_MAX"); return e ? atof(e) : PIXMAJOR_WGRAD_MAX_VALID; }();  // dev
+  static const double lim = []() { const char* e = contrad_dev_env("CONTRAD_PIXMAJOR_WGRAD_MAX"); return e ? atof(e) : PIXMAJOR_WGRAD_MAX_VALID; }();  // dev
   return fwd_valid_tap_fraction(d) <= lim;
 }
 
@@ -1106,7 +1112,7 @@ bool wgrad_pixmajor_ok(const contrad_conv_desc* d, int bm, long long pps) {
 // imbalance is NOT what keeps these tiles at 0.7 of the image-major tiles' issue rate (their operand traffic is, DESIGN.md
 // section 3).  taps[p] = valid taps of pixel p (any positive weights).
 void pixel_order(const int* taps, int npix, unsigned char* out) {
-  static const int mode = []() { const char* e = getenv("CONTRAD_PIXORDER"); return e ? atoi(e) : 1; }();
+  static const int mode = []() { const char* e = contrad_dev_env("CONTRAD_PIXORDER"); return e ? atoi(e) : 1; }();
   int idx[256];
   for (int i = 0; i < npix; ++i) idx[i] = i;
   if (mode >= 1) {   // stable sort by taps, descending (insertion sort: npix <= 256, host, once per call)
@@ -1179,7 +1185,7 @@ bool border_classes(const contrad_conv_desc* d, int mode, BorderClasses* bc) {
 
 // tile mode of a lean FWD / DGRAD launch: 0 image-major, 1 pixel-major, 2 border classes
 int tile_mode_override() {
-  static const int m = []() { const char* e = getenv("CONTRAD_TILEMODE"); return e ? atoi(e) : -1; }();   // dev
+  static const int m = []() { const char* e = contrad_dev_env("CONTRAD_TILEMODE"); return e ? atoi(e) : -1; }();   // dev
   return m;
 }
 
@@ -1313,13 +1319,14 @@ extern "C" int contrad_conv2d_fwd_add(const contrad_conv_desc* d, const float* x
   int rc = check_desc(d);
   if (rc) return rc;
   CONTRAD_ARG(x && wp && y);
-  if (vec_ok(d, MODE_FWD)) CONTRAD_ARG(aligned16(x, wp, y));
+  if (vec_ok(d, MODE_FWD)) CONTRAD_ARG(aligned16(x, wp, y) && aligned16(addend, nullptr, nullptr));
   IgemmArgs a{};
   a.A = x; a.B = wp; a.C = y; a.bias = bias; a.addend = addend; a.d = *d; a.slope = slope; a.gain = gain;
   const long long M = (long long)d->N * d->Ho * d->Wo;
   CONTRAD_ARG(M < (1ll << 31));
   a.M = (int)M; a.Ncol = d->K; a.Kg = d->KH * d->KW * d->C;
-  if (conv_c32_ok(d) && aligned16(x, wp, y) && aligned16(addend, nullptr, nullptr))   // weight-stationary kernel (conv_c32.h)
+  if (conv_c32_ok(d))   // weight-stationary kernel (conv_c32.h); (alignment is an argument error above, so the dispatch is
+                        // exactly what contrad_conv2d_path / _grid_blocks report)
     return launch_conv_c32<MODE_FWD>(d, x, wp, y, bias, addend, nullptr, slope, gain, (hipStream_t)stream);
   if (fwd_k1_ok(d)) {
     hipLaunchKernelGGL(fwd_k1_kernel, dim3((unsigned)cdivll(M, 4)), dim3(256), 0, (hipStream_t)stream, x, wp, M, d->C,
@@ -1438,7 +1445,7 @@ extern "C" int contrad_conv2d_dgrad_ws(const contrad_conv_desc* d, const float* 
   // 72 -> 99, 84 -> 102, 78 -> 117, 82 -> 99 TF/s; groups of 32 / 64 lose again on layers with < ~100 M-tiles (few
   // groups -> a tail of light classes).  tools/bench_conv.py; CONTRAD_DGRAD_CGROUP=0 restores the old order.
   {
-    static const int g = []() { const char* e = getenv("CONTRAD_DGRAD_CGROUP"); return e ? atoi(e) : 8; }();
+    static const int g = []() { const char* e = contrad_dev_env("CONTRAD_DGRAD_CGROUP"); return e ? atoi(e) : 8; }();
     a.cgroup = (s > 1) ? (g < a.tiles_m ? g : a.tiles_m) : 0;
   }
   const int tm_pad = a.cgroup > 0 ? cdiv(a.tiles_m, a.cgroup) * a.cgroup : a.tiles_m;
@@ -1517,7 +1524,7 @@ extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int 
                         : p.pixmajor == 1 ? cdiv(d->N, p.bm) * cdiv(d->H, s) * cdiv(d->W, s) : cdiv((int)Mc, p.bm);
     const int tiles_n = cdiv(d->C, p.bn);
     if (p.splits > 1) return (long long)tiles_m * tiles_n * p.splits;
-    static const int g = []() { const char* e = getenv("CONTRAD_DGRAD_CGROUP"); return e ? atoi(e) : 8; }();
+    static const int g = []() { const char* e = contrad_dev_env("CONTRAD_DGRAD_CGROUP"); return e ? atoi(e) : 8; }();
     const int cgroup = (s > 1) ? (g < tiles_m ? g : tiles_m) : 0;
     const int tm_pad = cgroup > 0 ? cdiv(tiles_m, cgroup) * cgroup : tiles_m;
     return (long long)tm_pad * tiles_n * s * s;
@@ -1545,7 +1552,7 @@ extern "C" int contrad_conv2d_wgrad(const contrad_conv_desc* d, const float* x, 
   CONTRAD_ARG(x && gy && dwp && workspace);
   if (vec_ok(d, MODE_WGRAD)) CONTRAD_ARG(aligned16(x, gy, workspace));
   CONTRAD_ARG(workspace_bytes >= contrad_conv2d_wgrad_workspace_bytes(d));
-  if (wgrad_c32_ok(d) && aligned16(x, gy, workspace)) {
+  if (wgrad_c32_ok(d)) {   // (C = K = 32: vec_ok holds, so the operands were checked for 16-byte alignment above)
     // accumulator-stationary kernel for the 32 -> 32 channel 3x3 layers (wgrad_c32.h): one partial per block, summed
     // by the same fixed-order reduce as the split-K slabs
     const int blocks = wgrad_c32_blocks(d);

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_c32_kernel(const WgradC32Args a)
 
 // 3x3, stride 1, pad 1, 32 -> 32 channels, dense NHWC, grid divisible into 4 x 32 tiles
 inline bool wgrad_c32_ok(const contrad_conv_desc* d) {
-  static const bool enabled = []() { const char* e = getenv("CONTRAD_WGRAD_C32"); return !(e && e[0] == '0'); }();
+  static const bool enabled = []() { const char* e = contrad_dev_env("CONTRAD_WGRAD_C32"); return !(e && e[0] == '0'); }();
   return enabled && d->C == 32 && d->K == 32 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
          d->ldx == 32 && d->ldy == 32 && d->ldw == 32 && (d->W % WC_TW) == 0 && (d->H % WC_TH) == 0 &&
          (long long)d->N * d->H * d->W >= 1 << 16;       // (small maps: the engine's split-K GEMM has enough reuse)
@@ -166,9 +166,12 @@ inline int wgrad_c32_blocks(const contrad_conv_desc* d) {
 
 inline int launch_wgrad_c32(const contrad_conv_desc* d, const float* x, const float* gy, float* ws, float* bias_ws,
                             hipStream_t stream) {
-  static bool attr_set = false;
+  static bool attr_set_dev[64] = {};   // per device; benign race: idempotent
   constexpr size_t smem = (size_t)(WC_XS + WC_GS) * sizeof(float);
   static_assert(smem >= 4 * WC_C * WC_C * sizeof(float), "the epilogue reuses the tile buffers");
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  bool& attr_set = attr_set_dev[dev_id & 63];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_c32_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -229,20 +229,26 @@ def d_step_stylegan2_contrad(P, G, D, opt_D, options, images, step, reducer=None
 
 
 def _quiesce_before_capture(*modules):
-    """Called right before a stream capture.  With a process group, every EAGER collective issued so far is still listed
-    in ProcessGroupNCCL's watchdog thread until that thread has seen it complete (it polls every 100 ms).  The capture
-    pulls RCCL's own stream into capture mode, and on this stack ``hipEventQuery`` then refuses the events of those earlier
-    works as well ("operation not permitted on an event last recorded in a capturing stream") -- the watchdog rethrows and
-    the process aborts.  Seen once in nine runs of tests/dist_graph_worker.py, on a cold box where the watchdog had not
-    drained yet.  So: drain the device, then give the watchdog time to retire what it still holds."""
+    """Called right before a stream capture; returns the ``capture_error_mode`` to capture with.
+
+    With a process group, every EAGER collective issued so far is still listed in ProcessGroupNCCL's watchdog thread until
+    that thread has seen it complete (it polls every 100 ms).  The capture pulls RCCL's own stream into capture mode, and
+    under the default 'global' capture mode ``hipEventQuery`` from ANY thread is then refused ("operation not permitted on
+    an event last recorded in a capturing stream") -- the watchdog rethrows and the whole job aborts.  Seen once in nine
+    runs of tests/dist_graph_worker.py, on a cold box where the watchdog had not drained yet.  Deterministic part: with a
+    process group the capture runs in 'thread_local' mode, in which only THIS thread's calls are policed, so the watchdog
+    thread may keep polling whatever it still holds.  Belt and braces: the device is drained first and the watchdog gets a
+    moment to retire the eager works (there is no API to wait for that)."""
     for m in modules:                       # no autograd graph of an eager step may stay referenced across the capture
         if hasattr(m, 'drop_pack_cache'):
             m.drop_pack_cache()
     torch.cuda.synchronize()
     if dist.is_available() and dist.is_initialized():
         import time
-        time.sleep(1.0)
+        time.sleep(0.5)
         torch.cuda.synchronize()
+        return 'thread_local'
+    return 'global'
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -292,8 +298,8 @@ class GraphedDStep(object):
         G.invalidate_cache()              # the step re-packs G's weights itself: G moves between D-steps in training
         self.graph = torch.cuda.CUDAGraph()
         self._scratch = {}           # this graph's own conv scratch (ops.private_workspace)
-        _quiesce_before_capture(self.D)
-        with _ops.private_workspace(self._scratch), torch.cuda.graph(self.graph):
+        mode = _quiesce_before_capture(self.D)
+        with _ops.private_workspace(self._scratch), torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.d_loss, self.aux = self._body()
         G.invalidate_cache()              # (what the capture allocated is filled by the first replay, not now)
         torch.cuda.synchronize()
@@ -450,8 +456,8 @@ class GraphedSG2DStep(object):
         G.invalidate_cache()              # as GraphedDStep: the packed tables are rebuilt inside the step
         self.graph = torch.cuda.CUDAGraph()
         self._scratch = {}           # this graph's own conv scratch (ops.private_workspace)
-        _quiesce_before_capture(self.D)
-        with _ops.private_workspace(self._scratch), torch.cuda.graph(self.graph):
+        mode = _quiesce_before_capture(self.D)
+        with _ops.private_workspace(self._scratch), torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.d_loss, self.aux = self._body()
         G.invalidate_cache()
         torch.cuda.synchronize()
@@ -535,8 +541,8 @@ class GraphedGStep(object):
         G.invalidate_cache()
         self.graph = torch.cuda.CUDAGraph()
         self._scratch = {}           # this graph's own conv scratch (ops.private_workspace)
-        _quiesce_before_capture(self.D)
-        with _ops.private_workspace(self._scratch), torch.cuda.graph(self.graph):
+        mode = _quiesce_before_capture(self.D)
+        with _ops.private_workspace(self._scratch), torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.g_loss = self._body()
         G.invalidate_cache()
         torch.cuda.synchronize()
@@ -581,8 +587,8 @@ class GraphedSG2GStep(object):
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         self._scratch = {}           # this graph's own conv scratch (ops.private_workspace)
-        _quiesce_before_capture(self.D)
-        with _ops.private_workspace(self._scratch), torch.cuda.graph(self.graph):
+        mode = _quiesce_before_capture(self.D)
+        with _ops.private_workspace(self._scratch), torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.g_loss = self._body()
         G.invalidate_cache()
         torch.cuda.synchronize()

@@ -520,7 +520,7 @@ class ResidualDiscriminatorP(BaseDiscriminator):
     # BaseDiscriminator.forward: call _run(..., want_proj=projection or projection2).  The reference evaluates both
     # projection heads in every call and adds 0 * their means to the logits (base.py:139-141, so that DDP sees every
     # parameter used); here a call that does not ask for them (R1's D(x), the generator step of train_stylegan2.py)
-    # skips their GEMMs -- the parameters then receive no gradient from that call instead of an exact zero.
+    # skips their GEMMs; the parameters still receive their exact-zero gradients (A.ZeroGradFn / the unpack node).
     _lazy_projections = True
 
     def _run(self, inputs, sg_linear, finetuning, want_features, want_proj=True):
@@ -563,6 +563,11 @@ class ResidualDiscriminatorP(BaseDiscriminator):
                                          1.0, *self._xch(idx['p2'], fused)).view(B, dp)
             proj2 = A.ConvBiasActFn.apply(h_pq[..., dh:], wp[idx['q2']], self.projection2[2].bias, (dp,) + g1[1:], 1.0,
                                           1.0, *self._xch(idx['q2'], fused)).view(B, dp)
+        else:
+            # skipped heads: their packed weights get zeros from the unpack node; the four biases get them here, so that
+            # EVERY parameter carries a gradient after any call (base.py:139-141) and the Adam state stays uniform
+            out = A.ZeroGradFn.apply(out, self.projection[0].bias, self.projection[2].bias, self.projection2[0].bias,
+                                     self.projection2[2].bias)
         if rec is not None:
             if not hasattr(self, '_recorded'):
                 self._recorded = []

@@ -250,6 +250,11 @@ class Generator(nn.Module):
         order = list(c['mod_cols'].items())
         key = (B, L, cols, str(out.device))
         if self._gather_key != key:
+            if torch.cuda.is_current_stream_capturing():
+                # the index is a pageable host -> device copy and would live in the graph's private pool: it has to exist
+                # before the capture (one eager forward at this batch size; the Graphed*Step constructors run one)
+                raise RuntimeError('Generator: first forward at batch size %d inside a stream capture; run one eager '
+                                   'forward at this batch size before capturing' % B)
             rows = torch.arange(B, dtype=torch.int64).view(B, 1)
             pieces = [((rows * L + lat_idx[mc]) * cols + o + torch.arange(n, dtype=torch.int64).view(1, n)).reshape(-1)
                       for mc, (o, n) in order]

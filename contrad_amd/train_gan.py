@@ -39,6 +39,11 @@ def parse_args(argv=None):
     parser.add_argument('--use_warmup', action='store_true', help='Use warmup strategy on LR')
     parser.add_argument('--temp', default=0.1, type=float)
     parser.add_argument('--lbd_a', default=1.0, type=float)
+    # train_gan.py:55-60: FID / GIF logging is outside the hot path (out of scope) -- the flags are accepted
+    # so that the reference's command lines run unchanged
+    parser.add_argument('--no_fid', action='store_true', help='accepted for CLI compatibility (FIDs are never tracked here)')
+    parser.add_argument('--no_gif', action='store_true', help='accepted for CLI compatibility (no GIFs are written here)')
+    parser.add_argument('--n_eval_avg', default=3, type=int, help='accepted for CLI compatibility')
     parser.add_argument('--print_every', default=50, type=int)
     parser.add_argument('--evaluate_every', default=2000, type=int, help='checkpoint period (steps)')
     parser.add_argument('--save_every', default=100000, type=int)
@@ -46,6 +51,10 @@ def parse_args(argv=None):
     parser.add_argument('--resume', default=None, type=str)
     parser.add_argument('--finetune', default=None, type=str)
     parser.add_argument('--workers', default=0, type=int)
+    # train_gan.py:79-82 (NODE count / node rank of the reference's mp.spawn launch): accepted; this build is one process
+    # per GPU of ONE node and takes rank / world size from the launcher's environment (RANK / WORLD_SIZE)
+    parser.add_argument('--world-size', default=1, type=int, help='accepted for CLI compatibility (nodes; single-node build)')
+    parser.add_argument('--rank', default=0, type=int, help='accepted for CLI compatibility (node rank)')
     parser.add_argument('--port', default=40404, type=int)
     # additions
     parser.add_argument('--synthetic', action='store_true', help='uniform-random images instead of a dataset')

@@ -148,3 +148,17 @@ def test_padding_skipping_tile_plans_without_gpu(built):
     d = _desc(192, 8, 256, 256, 3, 1, 1)
     assert path(ctypes.byref(d), 0) == 2 and frac(ctypes.byref(d), 0) == 1.0
     assert path(ctypes.byref(d), 2) == 3 and abs(frac(ctypes.byref(d), 2) - 484.0 / 576.0) < 1e-12   # (WGRAD: pixel-major positions)
+
+
+def test_shipped_library_reads_no_environment(built):
+    """SURVEY.md 8b (no hidden state): the development switches of the conv engine (tile modes, forced tiles, split-K
+    on / off ...) are compiled into libcontrad_hip_dev.so only; the shipped library neither imports getenv nor carries
+    any of their names."""
+    import subprocess
+    from contrad_amd import build
+    def names(path):
+        return subprocess.run(['strings', path], capture_output=True, text=True, check=True).stdout
+    def imports(path):
+        return subprocess.run(['nm', '-D', path], capture_output=True, text=True, check=True).stdout
+    assert 'CONTRAD_' not in names(build.LIB) and 'getenv' not in imports(build.LIB)
+    assert 'CONTRAD_TILEMODE' in names(build.DEV_LIB) and 'getenv' in imports(build.DEV_LIB)

@@ -1,0 +1,46 @@
+"""bench.py's own multi-rank code path, before 8-GPU hardware meets it: the self-launch under torch.distributed.run, one
+rank per process, the barrier + synchronize brackets, MAX over ranks of the timed region, the single JSON line from rank
+0 -- and the fallback order for a graph capture that never returns (eager result first, capture under a watchdog).
+Two ranks share cuda:0 over gloo (``--dev-backend gloo``; RCCL refuses two ranks on one device)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None, timeout=600):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dev-backend', 'gloo', '--config', 'c10_b512',
+           '--steps', '2', '--warmup', '1', '--no-cpu-baseline'] + extra
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    return r, lines
+
+
+def test_two_gloo_ranks_eager_line():
+    r, lines = _run(['--graph', 'off'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 2 and out['warmup'] == 1 and out['scaling'] == 'strong'
+    assert out['config']['global_batch'] == 512 and out['config']['per_gpu_batch'] == 256
+    assert out['config']['rccl_ranks'] == 2 and out['config']['backend'] == 'gloo' and out['config']['launch'] == 'eager'
+    assert out['config']['losses_finite'] and out['value'] > 0
+    assert abs(out['value'] - 512 * 2 / (out['ms_per_step'] * 2e-3)) < 1e-2 * out['value']
+    assert out['roofline']['kernel'] and 'cpu_baseline' not in out
+
+
+def test_graph_capture_that_never_returns_reports_the_eager_result():
+    r, lines = _run(['--graph', 'on', '--graph-timeout', '6'], {'CONTRAD_BENCH_FAKE_CAPTURE_HANG': '1'})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['launch'] == 'eager (graph capture timed out)'
+    assert out['config']['losses_finite'] and out['value'] > 0 and out['steps'] == 2
+    assert 'did not get through graph capture' in r.stderr

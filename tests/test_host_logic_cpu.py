@@ -139,3 +139,49 @@ def test_bench_workload_table_matches_baseline_json():
     for name, cfg in c.items():
         assert os.path.exists(os.path.join(ROOT, 'configs', *cfg['gin'])), name
     assert 1024 < bench._free_port() < 65536
+
+
+def test_bench_graph_watchdog_prints_the_kept_eager_result_and_exits_zero():
+    """bench.py's fallback order for N > 1: the eager result is kept, the capture runs under a
+    per-rank deadline, past it rank 0 prints the line with the eager result and every rank leaves with exit code 0."""
+    import json
+    import subprocess
+    import sys
+    code = (
+        "import sys, time, json; sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "results = {'c10_b512': {'value': 1.0, 'config': {'launch': 'hipGraph replay'}}}\n"
+        "names = ['c10_b512', 'sg2_32']\n"
+        "def emit():\n"
+        "    out = results[names[0]]\n"
+        "    rest = {n: results[n] for n in names[1:] if n in results}\n"
+        "    if rest: out['other_configs'] = rest\n"
+        "    print(json.dumps(out), flush=True)\n"
+        "wd = bench._GraphWatchdog(int(sys.argv[1]), 0.3, results, emit)\n"
+        "wd.keep('sg2_32', {'value': 2.0, 'config': {'launch': 'eager (graph capture timed out)'}})\n"
+        "wd.arm('sg2_32')\n"
+        "time.sleep(30)\n"
+        "print('not reached')\n" % ROOT)
+    for rank, want_line in ((0, True), (1, False)):
+        r = subprocess.run([sys.executable, '-c', code, str(rank)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=120, text=True)
+        assert r.returncode == 0 and 'not reached' not in r.stdout
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        assert len(lines) == (1 if want_line else 0)
+        if want_line:
+            out = json.loads(lines[0])
+            assert out['value'] == 1.0 and out['other_configs']['sg2_32']['config']['launch'].startswith('eager (graph')
+    # a disarmed watchdog never fires
+    code2 = code.replace("time.sleep(30)", "wd.disarm('sg2_32'); time.sleep(1.0); print('reached')").replace("print('not reached')", "")
+    r = subprocess.run([sys.executable, '-c', code2, '0'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, text=True)
+    assert r.returncode == 0 and 'reached' in r.stdout and '{' not in r.stdout
+
+
+def test_train_gan_accepts_every_flag_of_the_reference_cli():
+    """train_gan.py:41-85: the reference's command lines must parse unchanged (logging flags are accepted and ignored)."""
+    from contrad_amd.train_gan import parse_args
+    a = parse_args(['configs/gan/cifar10/c10_b512.gin', 'sndcgan', '--mode', 'contrad', '--aug', 'simclr', '--use_warmup',
+                    '--temp', '0.1', '--lbd_a', '1.0', '--no_fid', '--no_gif', '--n_eval_avg', '3', '--print_every', '50',
+                    '--evaluate_every', '2000', '--save_every', '100000', '--comment', 'x', '--workers', '0',
+                    '--world-size', '1', '--rank', '0', '--port', '40404'])
+    assert a.mode == 'contrad' and a.no_fid and a.no_gif and a.n_eval_avg == 3 and a.world_size == 1 and a.rank == 0

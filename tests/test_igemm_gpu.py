@@ -114,13 +114,20 @@ def test_conv_fwd_dgrad_wgrad(case):
         assert rel(db.cpu(), gy.sum((0, 2, 3))) < TOL
 
 
+def _dev_lib():
+    """The build with the development switches compiled in (contrad_amd/build.py): the shipped library reads no environment."""
+    from contrad_amd import build
+    assert os.path.exists(build.DEV_LIB), 'run __graft_entry__.build() first'
+    return build.DEV_LIB
+
+
 def test_strided_pixel_major_dgrad_in_a_fresh_process():
     """The launch plan keeps strided data gradients off the pixel-major tiles (slower on the 4x4 stride-2 layer), but the
     kernel walks them inside the parity classes all the same: forced on (the switch is read once per process), the
     4x4 stride-2 and the odd-map 3x3 stride-2 cases must still match the fp32 reference."""
     import subprocess
     import sys
-    env = dict(os.environ, CONTRAD_PIXMAJOR_STRIDED='1', CONTRAD_TEST_EXPECT_DGRAD_PATH='3')
+    env = dict(os.environ, CONTRAD_PIXMAJOR_STRIDED='1', CONTRAD_TEST_EXPECT_DGRAD_PATH='3', CONTRAD_HIP_LIB=_dev_lib())
     env.pop('CONTRAD_TILEMODE', None)          # (a forced tile mode would override the plan under test)
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-m', 'gpu', '-x', '-k',
                         '130x8x8x16x64x4x2x1'], env=env, capture_output=True, text=True, timeout=600,
@@ -134,7 +141,7 @@ def test_forced_border_classes_in_a_fresh_process():
     there): forced on for FWD and stride-1 DGRAD, the small cases must still match the fp32 reference."""
     import subprocess
     import sys
-    env = dict(os.environ, CONTRAD_TILEMODE='2')
+    env = dict(os.environ, CONTRAD_TILEMODE='2', CONTRAD_HIP_LIB=_dev_lib())
     env.pop('CONTRAD_TEST_EXPECT_DGRAD_PATH', None)
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-m', 'gpu', '-x', '-k',
                         '130x8x8x32 or 70x12x20 or 200x2x6 or 130x4x4 or 130x5x7 or 16x2x2'], env=env, capture_output=True,
