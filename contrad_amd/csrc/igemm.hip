@@ -56,6 +56,11 @@ struct IgemmArgs {
   int ptiles_per_split;  // WGRAD
   int ny;                // lean kernels: grid.y folded into the 1-D grid (DGRAD classes / WGRAD splits)
   int cgroup;            // lean DGRAD, stride 2: M-tiles per class group of the block order (0: class-interleaved)
+  // lean DGRAD, stride 2 with unequal parity classes (3x3: 4 / 2 / 2 / 1 taps), balanced order (cbal > 0): a block of class
+  // c walks cb_reps[c] consecutive M-tiles, so that every block contracts the same number of K-tiles; a group covers cbal
+  // M-tile indices of every class and holds cb_start[4] blocks per N-tile, class c at [cb_start[c], cb_start[c + 1])
+  int cbal;
+  int cb_reps[4], cb_start[5];
   int dsplits;           // lean DGRAD, stride 1: split-K count (grid.y = splits instead of parity classes), else 0 / 1
   long long slab_elems;  // lean DGRAD split-K: floats per partial slab (N * H * W * ldx)
   int px_pixels;         // lean DGRAD, pixel-major: dx pixels of the largest parity class (tiles_m = image blocks x this)
@@ -851,8 +856,9 @@ bool vec_ok(const contrad_conv_desc* d, int mode) {
 
 // Tile choice: the biggest tile that still yields >= 3 blocks per CU (4 are resident); measured on the lean
 // kernels at 3N = 192 / 384 / 1536 images (tools/ab_tile.sh): below that fill the 64x64 tile (TM = TN = 1) wins even
-// though it does 4x the LDS traffic per flop.  mult = independent grids of this size (DGRAD parity classes).
-void pick_tile(long long M, int Ncol, bool vec, bool lean, int mult, int* bm, int* bn) {
+// though it does 4x the LDS traffic per flop.  mult4 / 4 = independent grids of this size (DGRAD parity classes: 4; in the
+// balanced order of a 3x3 stride-2 layer 9 / 4 -- its blocks walk 1 / 2 / 2 / 4 M-tiles of the four classes).
+void pick_tile(long long M, int Ncol, bool vec, bool lean, int mult4, int* bm, int* bn) {   // mult4 = 4 x independent grids
   if (!vec) { *bm = 64; *bn = 64; return; }
   // lean only: 4 x 1 waves, no MFMA columns wasted.  (A 256 x 32 tile -- two MFMA tiles per wave sharing one B fragment --
   // was tried in round 2: 89.0 vs 88.3 TF/s, because all per-row work doubles with it.  What holds these K = 288 layers
@@ -864,7 +870,7 @@ void pick_tile(long long M, int Ncol, bool vec, bool lean, int mult, int* bm, in
   static const int cand[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
   for (int i = (Ncol > 64 ? 0 : 2); i < 4; ++i) {
     *bm = cand[i][0]; *bn = cand[i][1];
-    if (cdivll(M, *bm) * cdivll(Ncol, *bn) * mult >= 768) return;
+    if (cdivll(M, *bm) * cdivll(Ncol, *bn) * mult4 >= 768 * 4) return;
   }
 }
 
@@ -1240,7 +1246,7 @@ FwdPlan fwd_plan(const contrad_conv_desc* d) {
   const bool vec = vec_ok(d, MODE_FWD);
   const bool lean = vec && lean_ok(d, MODE_FWD, 0);
   FwdPlan p{64, 64, 1, 0, 0};
-  pick_tile(M, d->K, vec, lean, 1, &p.bm, &p.bn);
+  pick_tile(M, d->K, vec, lean, 4, &p.bm, &p.bn);
   const int t_total = d->KH * d->KW * d->C / BK;
   p.tps = t_total;
   if (lean && splitk_enabled() && p.bn != 32 && t_total >= 32)
@@ -1254,6 +1260,8 @@ FwdPlan fwd_plan(const contrad_conv_desc* d) {
   return p;
 }
 
+long long dgrad_balance(const contrad_conv_desc* d, int tiles_m, IgemmArgs* a);
+
 // DGRAD plan.  Stride 1 on the lean kernel may split K like FWD (small-M, deep-K layers: the 4x4 / 8x8 levels at small
 // per-rank batches ran 64x64 tiles at 2/3 of the 128x128 tile's matrix-pipe utilisation just to have enough blocks);
 // strided DGRAD keeps grid.y for its parity classes.  Without a workspace the plan never splits.
@@ -1263,7 +1271,12 @@ FwdPlan dgrad_plan(const contrad_conv_desc* d, bool may_split) {
   const bool vec = vec_ok(d, MODE_DGRAD);
   const bool lean = vec && lean_ok(d, MODE_DGRAD, 0);
   FwdPlan p{64, 64, 1, 0, 0};
-  pick_tile(Mc, d->C, vec, lean, s * s, &p.bm, &p.bn);
+  int mult4 = 4 * s * s;
+  if (lean && s == 2) {                      // balanced order (dgrad_balance): blocks per (M-tile index, N-tile) = start / R
+    IgemmArgs probe{};
+    if (dgrad_balance(d, 8, &probe) > 0) mult4 = 4 * probe.cb_start[4] / probe.cbal;
+  }
+  pick_tile(Mc, d->C, vec, lean, mult4, &p.bm, &p.bn);
   const int t_total = d->KH * d->KW * d->K / BK;
   p.tps = t_total;
   if (may_split && s == 1 && lean && splitk_enabled() && p.bn != 32 && t_total >= 32 && !(d->C & 3) && !(d->ldx & 3))
@@ -1275,6 +1288,36 @@ FwdPlan dgrad_plan(const contrad_conv_desc* d, bool may_split) {
     else if (force == 1 || force < 0) p.pixmajor = dgrad_pixmajor_ok(d, p.bm) ? 1 : 0;
   }
   return p;
+}
+
+// Balanced block order of a strided lean DGRAD (igemm_lean.h, p.cbal): possible when the parity classes carry different tap
+// counts and every count divides the largest (3x3 stride 2: 4, 2, 2, 1 -> runs of 1, 2, 2, 4 M-tiles per block; the 4x4
+// stride-2 layers of SNDCGAN have four equal classes and keep the plain order).  Fills a->cbal / cb_reps / cb_start and
+// returns the number of blocks per N-tile (M-direction), or 0 when the plain order stays.
+long long dgrad_balance(const contrad_conv_desc* d, int tiles_m, IgemmArgs* a) {
+  static const bool on = []() { const char* e = contrad_dev_env("CONTRAD_DGRAD_BALANCE"); return !(e && e[0] == '0'); }();
+  const int s = d->stride;
+  if (!on || s != 2) return 0;
+  int taps[4], most = 0, least = 1 << 30;
+  for (int c = 0; c < 4; ++c) {
+    const int ph = c / s, pw = c % s;
+    const int kh0 = (ph + d->pad) % s, kw0 = (pw + d->pad) % s;
+    const int nth = kh0 < d->KH ? (d->KH - kh0 + s - 1) / s : 0, ntw = kw0 < d->KW ? (d->KW - kw0 + s - 1) / s : 0;
+    taps[c] = nth * ntw;
+    most = std::max(most, taps[c]); least = std::min(least, taps[c]);
+  }
+  if (least <= 0 || most == least) return 0;           // an empty class (1x1 stride 2) or nothing to balance
+  int start = 0;
+  const int R = 8;                                     // M-tile indices of every class per group (the plain order's cgroup)
+  for (int c = 0; c < 4; ++c) {
+    if (most % taps[c] || R % (most / taps[c])) return 0;
+    a->cb_reps[c] = most / taps[c];
+    a->cb_start[c] = start;
+    start += R / a->cb_reps[c];
+  }
+  a->cb_start[4] = start;
+  a->cbal = R;
+  return (long long)cdiv(tiles_m, R) * start;
 }
 
 // dx[m][c] = gain * act'(act_ref[m][c]) * sum_s ws[s][m][c]   (slabs in dx's own layout, fixed summation order)
@@ -1448,6 +1491,16 @@ extern "C" int contrad_conv2d_dgrad_ws(const contrad_conv_desc* d, const float* 
     static const int g = []() { const char* e = contrad_dev_env("CONTRAD_DGRAD_CGROUP"); return e ? atoi(e) : 8; }();
     a.cgroup = (s > 1) ? (g < a.tiles_m ? g : a.tiles_m) : 0;
   }
+  // ... and equal work per block where the classes are unequal (3x3 stride 2: 4 / 2 / 2 / 1 taps): a block of a light
+  // class walks 2 / 4 consecutive M-tiles (dgrad_balance(); igemm_lean.h).  Neighbours are then equal AND every block of
+  // the launch carries the same number of K-tiles, so the tail of the launch is not a few 4-tap blocks running alone.
+  if (vec && lean_ok(d, MODE_DGRAD, 0) && !a.pixmajor && a.nwin == 0) {
+    const long long blocks = dgrad_balance(d, a.tiles_m, &a);
+    if (blocks > 0) {
+      a.cgroup = 0;
+      return dispatch<MODE_DGRAD>(a, bm, bn, vec, dim3((unsigned)(blocks * a.tiles_n), 1), (hipStream_t)stream);
+    }
+  }
   const int tm_pad = a.cgroup > 0 ? cdiv(a.tiles_m, a.cgroup) * a.cgroup : a.tiles_m;
   return dispatch<MODE_DGRAD>(a, bm, bn, vec, dim3(tm_pad * a.tiles_n, s * s), (hipStream_t)stream);
 }
@@ -1524,6 +1577,11 @@ extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int 
                         : p.pixmajor == 1 ? cdiv(d->N, p.bm) * cdiv(d->H, s) * cdiv(d->W, s) : cdiv((int)Mc, p.bm);
     const int tiles_n = cdiv(d->C, p.bn);
     if (p.splits > 1) return (long long)tiles_m * tiles_n * p.splits;
+    if (vec_ok(d, MODE_DGRAD) && lean_ok(d, MODE_DGRAD, 0) && p.pixmajor == 0) {
+      IgemmArgs a{};
+      const long long blocks = dgrad_balance(d, tiles_m, &a);
+      if (blocks > 0) return blocks * tiles_n;
+    }
     static const int g = []() { const char* e = contrad_dev_env("CONTRAD_DGRAD_CGROUP"); return e ? atoi(e) : 8; }();
     const int cgroup = (s > 1) ? (g < tiles_m ? g : tiles_m) : 0;
     const int tm_pad = cgroup > 0 ? cdiv(tiles_m, cgroup) * cgroup : tiles_m;

@@ -48,10 +48,13 @@ __device__ __forceinline__ void divmod_u(int x, int d, int sh, int& q, int& r) {
   else { q = x / d; r = x - q * d; }
 }
 
+// One tile of the launch: everything after the block -> (tile_m, tile_n, class / split) decode.  Its early returns are
+// block-uniform and sit before the first barrier.  (A separate function so that a block can walk SEVERAL tiles: the strided
+// data gradient hands its light parity classes out in runs of 2 / 4 M-tiles per block, see the decode in the kernel.)
 template <int MODE, int BM, int BN>
-__global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(const IgemmArgs p) {
+__device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const int tile_m, const int tile_n, const int by,
+                                          const int wc_h0, const int wc_w0, const int wc_hc, const int wc_wc) {
   static_assert(BK == 16, "the lean loop is written for a 16-deep K-tile");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool A_Q = (MODE != MODE_WGRAD);   // A K-contiguous in memory -> quad layout
   constexpr bool B_Q = (MODE == MODE_DGRAD);
   constexpr int QSA = BM * 4 + 16, QSB = BN * 4 + 16;   // quad stride (+16: the 4 quads of a row-group hit 4 bank groups)
@@ -74,55 +77,6 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int l31 = lane & 31, lhi = lane >> 5;
 
-  // 1-D grid, remapped so that each XCD (own L2) owns a contiguous run of ids.  Decode order = who shares operands:
-  //   FWD    tile_n fastest                      (the N-tiles of one M-tile read the same im2col rows)
-  //   DGRAD  tile_n, then parity class, tile_m   (the s*s classes of one M-tile read the same gy pixels); stride 2:
-  //          groups of M-tiles, class-major inside a group (equal work on neighbouring block ids)
-  //   WGRAD  all (tile_m, tile_n) of one split   (every tile of a split reads the same positions of x and gy)
-  // Before this the 9..36 tiles of a WGRAD split sat on 8 different XCDs and HBM traffic was 6.5x the algorithmic bytes.
-  const int lin = xcd_remap(blockIdx.x, gridDim.x);
-  int by, tile_n, tile_m;
-  int wc_h0 = 0, wc_w0 = 0, wc_hc = 0, wc_wc = 0;   // border class of this tile: window origin and size (p.nwin > 0)
-  if constexpr (MODE == MODE_WGRAD) {
-    const int tiles = p.tiles_m * p.tiles_n;
-    by = lin / tiles;
-    const int b = lin - by * tiles;
-    tile_n = b % p.tiles_n; tile_m = b / p.tiles_n;
-  } else if (MODE == MODE_DGRAD && p.cgroup > 0) {
-    // strided DGRAD: groups of cgroup M-tiles, class-major inside a group (igemm.hip, contrad_conv2d_dgrad)
-    const int per_group = p.cgroup * p.ny * p.tiles_n;
-    const int g = lin / per_group, r = lin - g * per_group;
-    by = r / (p.cgroup * p.tiles_n);
-    const int q = r - by * (p.cgroup * p.tiles_n);
-    tile_m = g * p.cgroup + q / p.tiles_n;
-    tile_n = q % p.tiles_n;
-    if (tile_m >= p.tiles_m) return;
-  } else if (MODE != MODE_WGRAD && p.nwin > 0) {
-    // border classes (igemm.hip, border_classes()): the output map (FWD) / dx map (stride-1 DGRAD) is cut into the <= 16
-    // rectangles of pixels that share their set of non-padding taps; every class has its own run of M-tiles over
-    // (image, pixel of the rectangle), heaviest class first
-    // The classes carry unequal work per tile (9 / 6 / 4 taps), and the dispatcher places block b on XCD b % 8: every XCD
-    // takes an eighth of EVERY class (contiguous in the class, so neighbours still share images in the L2), heaviest
-    // class first.  (With the engine's usual contiguous-run-per-XCD order two XCDs got all the 9-tap tiles and the
-    // kernel lasted exactly as long as without any skipping.)
-    const int xcd = blockIdx.x & 7, kb = blockIdx.x >> 3;
-    tile_n = kb % p.tiles_n;
-    int km = kb / p.tiles_n, c = 0;
-    tile_m = -1;
-    for (; c < p.nwin; ++c) {
-      const int n_c = p.win_tile0[c + 1] - p.win_tile0[c];
-      const int lo = (xcd * n_c) >> 3, hi = ((xcd + 1) * n_c) >> 3;
-      if (km < hi - lo) { tile_m = lo + km; break; }
-      km -= hi - lo;
-    }
-    if (tile_m < 0) return;     // (grid padded to 8 x the largest per-XCD share)
-    by = 0;
-    wc_h0 = p.win_h0[c]; wc_w0 = p.win_w0[c]; wc_hc = p.win_hc[c]; wc_wc = p.win_wc[c];
-  } else {
-    tile_n = lin % p.tiles_n;
-    const int r = lin / p.tiles_n;
-    by = r % p.ny; tile_m = r / p.ny;
-  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // loader coordinates: quad loader = (row qrow + 64 i, k-quad kq); row loader = (k-row r + RPP i, column quad c4)
@@ -743,6 +697,78 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
         }
       }
     }
+  }
+}
+
+template <int MODE, int BM, int BN>
+__global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(const IgemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // 1-D grid, remapped so that each XCD (own L2) owns a contiguous run of ids.  Decode order = who shares operands:
+  //   FWD    tile_n fastest                      (the N-tiles of one M-tile read the same im2col rows)
+  //   DGRAD  tile_n, then parity class, tile_m   (the s*s classes of one M-tile read the same gy pixels); stride 2:
+  //          groups of M-tiles, class-major inside a group (equal work on neighbouring block ids)
+  //   WGRAD  all (tile_m, tile_n) of one split   (every tile of a split reads the same positions of x and gy)
+  // Before this the 9..36 tiles of a WGRAD split sat on 8 different XCDs and HBM traffic was 6.5x the algorithmic bytes.
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  int by, tile_n, tile_m;
+  int nrep = 1;                                     // M-tiles this block walks (strided DGRAD, balanced order: 1 / 2 / 4)
+  int wc_h0 = 0, wc_w0 = 0, wc_hc = 0, wc_wc = 0;   // border class of this tile: window origin and size (p.nwin > 0)
+  if constexpr (MODE == MODE_WGRAD) {
+    const int tiles = p.tiles_m * p.tiles_n;
+    by = lin / tiles;
+    const int b = lin - by * tiles;
+    tile_n = b % p.tiles_n; tile_m = b / p.tiles_n;
+  } else if (MODE == MODE_DGRAD && p.cbal > 0) {
+    // strided DGRAD, equal work per block (igemm.hip, dgrad_balance()): the parity classes of a 3x3 stride-2 layer contract
+    // over 4 / 2 / 2 / 1 taps, so a block of class c walks cb_reps[c] = 1 / 2 / 2 / 4 consecutive M-tiles of its class -- every
+    // block multiplies the same number of K-tiles.  Order: groups of cbal M-tile indices, class-major inside a group (the
+    // gy rows the classes of a group share are still in the L2 when the next class reads them).
+    const int per_group = p.cb_start[4] * p.tiles_n;
+    const int g = lin / per_group, r = lin - g * per_group;
+    const int blk = r / p.tiles_n;
+    tile_n = r - blk * p.tiles_n;
+    by = (blk >= p.cb_start[1]) + (blk >= p.cb_start[2]) + (blk >= p.cb_start[3]);
+    nrep = p.cb_reps[by];
+    tile_m = g * p.cbal + (blk - p.cb_start[by]) * nrep;
+    if (tile_m >= p.tiles_m) return;
+  } else if (MODE == MODE_DGRAD && p.cgroup > 0) {
+    // strided DGRAD: groups of cgroup M-tiles, class-major inside a group (igemm.hip, contrad_conv2d_dgrad)
+    const int per_group = p.cgroup * p.ny * p.tiles_n;
+    const int g = lin / per_group, r = lin - g * per_group;
+    by = r / (p.cgroup * p.tiles_n);
+    const int q = r - by * (p.cgroup * p.tiles_n);
+    tile_m = g * p.cgroup + q / p.tiles_n;
+    tile_n = q % p.tiles_n;
+    if (tile_m >= p.tiles_m) return;
+  } else if (MODE != MODE_WGRAD && p.nwin > 0) {
+    // border classes (igemm.hip, border_classes()): the output map (FWD) / dx map (stride-1 DGRAD) is cut into the <= 16
+    // rectangles of pixels that share their set of non-padding taps; every class has its own run of M-tiles over
+    // (image, pixel of the rectangle), heaviest class first
+    // The classes carry unequal work per tile (9 / 6 / 4 taps), and the dispatcher places block b on XCD b % 8: every XCD
+    // takes an eighth of EVERY class (contiguous in the class, so neighbours still share images in the L2), heaviest
+    // class first.  (With the engine's usual contiguous-run-per-XCD order two XCDs got all the 9-tap tiles and the
+    // kernel lasted exactly as long as without any skipping.)
+    const int xcd = blockIdx.x & 7, kb = blockIdx.x >> 3;
+    tile_n = kb % p.tiles_n;
+    int km = kb / p.tiles_n, c = 0;
+    tile_m = -1;
+    for (; c < p.nwin; ++c) {
+      const int n_c = p.win_tile0[c + 1] - p.win_tile0[c];
+      const int lo = (xcd * n_c) >> 3, hi = ((xcd + 1) * n_c) >> 3;
+      if (km < hi - lo) { tile_m = lo + km; break; }
+      km -= hi - lo;
+    }
+    if (tile_m < 0) return;     // (grid padded to 8 x the largest per-XCD share)
+    by = 0;
+    wc_h0 = p.win_h0[c]; wc_w0 = p.win_w0[c]; wc_hc = p.win_hc[c]; wc_wc = p.win_wc[c];
+  } else {
+    tile_n = lin % p.tiles_n;
+    const int r = lin / p.tiles_n;
+    by = r % p.ny; tile_m = r / p.ny;
+  }
+  for (int rep = 0; rep < nrep; ++rep) {
+    lean_tile<MODE, BM, BN>(p, smem, tile_m + rep, tile_n, by, wc_h0, wc_w0, wc_hc, wc_wc);
+    if (rep + 1 < nrep) __syncthreads();   // (the epilogue's row table and the next tile's first LDS stores share smem)
   }
 }
 

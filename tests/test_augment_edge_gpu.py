@@ -200,4 +200,4 @@ def test_simclr_hq_cutout_against_reference_golden(golden, margin):
     xd = x.to(DEV).requires_grad_()
     (aug.apply(xd, P, p['contrast_first'], p['sigma']) * w.to(DEV)).sum().backward()
     e = ((xd.grad.cpu() - xr.grad).norm() / xr.grad.norm()).item()
-    margin('augment backward simclr_hq_cutout 64^2 (l2)', e, 2e-3)     # clamp boundaries of single pixels
+    margin('augment backward simclr_hq_cutout 64^2 (l2)', e, 1e-3)     # observed 2.8e-6

@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 FLIP_TOL = float(__import__('os').environ.get('CONTRAD_FLIP_TOL', '1e-2'))     # ReLU slope flips in G: observed < 7e-3; see tests/test_sndcgan_gpu.py
 DEV = 'cuda'
-RAW_NORM_TOL = 2e-2       # gradient norms vs the RAW golden: ReLU slope flips 1 <-> 0 in G
-AUG_BWD_TOL = 2e-3        # clamp boundaries of single pixels (pre-clamp value at 0 / 1 within fp32 rounding)
+RAW_NORM_TOL = 1e-3       # gradient norms vs the RAW golden (observed 2.9e-4; element-wise L2 vs the raw golden: FLIP_TOL)
+AUG_BWD_TOL = 1e-3        # observed 8e-8 (profiles/r04_test_margins.txt)
 
 
 def rel(a, b):

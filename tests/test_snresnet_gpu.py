@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 FLIP_TOL = float(__import__('os').environ.get('CONTRAD_FLIP_TOL', '1.5e-2'))     # ReLU slope flips (1 <-> 0): observed worst 7.2e-3; see tests/test_sndcgan_gpu.py
 DEV = 'cuda'
-RAW_NORM_TOL = 2e-2       # raw golden, gradient norms: slope flips of single units (see the same-region test for the strict check)
+RAW_NORM_TOL = 5e-3       # raw golden, gradient norms: slope flips of single units move them by up to 2.3e-3 (observed); the strict
+                          # 1e-3 check is the same-region test below (observed 6.6e-5)
 
 
 def rel(a, b):

@@ -22,8 +22,8 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 FLIP_TOL = float(__import__('os').environ.get('CONTRAD_FLIP_TOL', '1e-3'))
 DEV = 'cuda'
-RAW_NORM_TOL = 2e-2       # gradient norms vs the RAW golden: slope flips of single units
-AUG_BWD_TOL = 2e-3        # clamp boundaries of single pixels (pre-clamp value at 0 / 1 within fp32 rounding)
+RAW_NORM_TOL = 1e-3       # gradient norms vs the RAW golden (observed 1.8e-4)
+AUG_BWD_TOL = 1e-3        # observed 5.8e-6 (profiles/r04_test_margins.txt)
 
 
 def rel(a, b):
