@@ -794,24 +794,32 @@ int launch(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
 #include "wgrad_c32.h"
 #include "conv_c32.h"
 
-template <int MODE, int BM, int BN>
-int launch_lean(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
+template <int MODE, int BM, int BN, bool BAL>
+int launch_lean_inst(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
   static bool attr_set_dev[64] = {};  // per device (one process may drive several); benign race: idempotent
   constexpr size_t smem = lean_smem_bytes<MODE, BM, BN>();
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);
   bool& attr_set = attr_set_dev[dev_id & 63];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lean_kernel<MODE, BM, BN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lean_kernel<MODE, BM, BN, BAL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   IgemmArgs b = a;
   b.ny = (int)grid.y;
-  hipLaunchKernelGGL((igemm_lean_kernel<MODE, BM, BN>), dim3(grid.x * grid.y), dim3(NTHREADS), smem, stream, b);
+  hipLaunchKernelGGL((igemm_lean_kernel<MODE, BM, BN, BAL>), dim3(grid.x * grid.y), dim3(NTHREADS), smem, stream, b);
   CONTRAD_CHECK_LAUNCH();
   return 0;
+}
+
+template <int MODE, int BM, int BN>
+int launch_lean(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
+  if constexpr (MODE == MODE_DGRAD) {
+    if (a.cbal > 0) return launch_lean_inst<MODE, BM, BN, true>(a, grid, stream);   // balanced strided order (igemm_lean.h)
+  }
+  return launch_lean_inst<MODE, BM, BN, false>(a, grid, stream);
 }
 
 // Does the shape fit the lean loop (igemm_lean.h)?  pps = WGRAD position tiles per split.
@@ -985,7 +993,7 @@ __global__ void fwd_reduce_kernel(const float* __restrict__ ws, int splits, long
 // FWD plan: tile + split-K count from a small cost model (measured rates of the lean tiles, 768 blocks = a full
 // chip, partial slabs priced at 4 TB/s).  Split-K only pays for small-M, deep-K GEMMs: the merged head layer
 // (M = 3N rows, K = 8192) and the last conv layers at small per-rank batches.
-struct FwdPlan { int bm, bn, splits, tps, pixmajor; };
+struct FwdPlan { int bm, bn, splits, tps, pixmajor, balanced; };   // balanced: strided DGRAD, equal-work block order
 
 // tile + split count for a lean GEMM of M x Ncol outputs over t_total K-tiles (shared by FWD and stride-1 DGRAD)
 void split_plan(long long M, int Ncol, int t_total, double flops, FwdPlan* p) {
@@ -1245,7 +1253,7 @@ FwdPlan fwd_plan(const contrad_conv_desc* d) {
   const long long M = (long long)d->N * d->Ho * d->Wo;
   const bool vec = vec_ok(d, MODE_FWD);
   const bool lean = vec && lean_ok(d, MODE_FWD, 0);
-  FwdPlan p{64, 64, 1, 0, 0};
+  FwdPlan p{64, 64, 1, 0, 0, 0};
   pick_tile(M, d->K, vec, lean, 4, &p.bm, &p.bn);
   const int t_total = d->KH * d->KW * d->C / BK;
   p.tps = t_total;
@@ -1262,6 +1270,15 @@ FwdPlan fwd_plan(const contrad_conv_desc* d) {
 
 long long dgrad_balance(const contrad_conv_desc* d, int tiles_m, IgemmArgs* a);
 
+// Class-group size of the plain strided order: the M-tiles x N-tiles of one class inside a group are consecutive block
+// ids, and 32 of them = one block for every CU of an XCD (round 2 had a fixed 8, which is this for the 4 N-tiles of the
+// 512-channel layers only; with 1 / 2 / 8 N-tiles 32 / 16 / 4 measured 20 - 35 % faster on single-round launches).
+int dgrad_cgroup(int tiles_m, int tiles_n) {
+  static const int forced = []() { const char* e = contrad_dev_env("CONTRAD_DGRAD_CGROUP"); return e ? atoi(e) : 0; }();
+  int g = forced > 0 ? forced : std::max(1, 32 / std::max(tiles_n, 1));
+  return g < tiles_m ? g : tiles_m;
+}
+
 // DGRAD plan.  Stride 1 on the lean kernel may split K like FWD (small-M, deep-K layers: the 4x4 / 8x8 levels at small
 // per-rank batches ran 64x64 tiles at 2/3 of the 128x128 tile's matrix-pipe utilisation just to have enough blocks);
 // strided DGRAD keeps grid.y for its parity classes.  Without a workspace the plan never splits.
@@ -1270,13 +1287,21 @@ FwdPlan dgrad_plan(const contrad_conv_desc* d, bool may_split) {
   const long long Mc = (long long)d->N * cdiv(d->H, s) * cdiv(d->W, s);   // largest class
   const bool vec = vec_ok(d, MODE_DGRAD);
   const bool lean = vec && lean_ok(d, MODE_DGRAD, 0);
-  FwdPlan p{64, 64, 1, 0, 0};
-  int mult4 = 4 * s * s;
-  if (lean && s == 2) {                      // balanced order (dgrad_balance): blocks per (M-tile index, N-tile) = start / R
+  FwdPlan p{64, 64, 1, 0, 0, 0};
+  pick_tile(Mc, d->C, vec, lean, 4 * s * s, &p.bm, &p.bn);
+  if (lean && s == 2) {
+    // Unequal parity classes (3x3 stride 2: 4 / 2 / 2 / 1 taps).  Measured on the StyleGAN2 shapes at 16 ... 192 images
+    // (tools/dev/dgrad_cgroup2.sh, dgrad_balance.sh): a launch that fits the chip in about one round
+    // (<= 1024 blocks = 4 per CU) is fastest in the plain class-group order with 32-block class chunks -- the dispatcher
+    // deals an XCD's blocks round-robin over its 32 CUs, so every CU then holds one block of EVERY class; a longer launch
+    // is fastest with equal work per block (dgrad_balance: blocks of the light classes walk 2 / 4 M-tiles).
     IgemmArgs probe{};
-    if (dgrad_balance(d, 8, &probe) > 0) mult4 = 4 * probe.cb_start[4] / probe.cbal;
+    static const bool force = []() { const char* e = contrad_dev_env("CONTRAD_DGRAD_BALANCE"); return e && e[0] == '2'; }();   // dev
+    if (dgrad_balance(d, 8, &probe) > 0 && (force || cdivll(Mc, p.bm) * cdiv(d->C, p.bn) * s * s > 1024)) {
+      p.balanced = 1;
+      pick_tile(Mc, d->C, vec, lean, 4 * probe.cb_start[4] / probe.cbal, &p.bm, &p.bn);   // 9 / 4 blocks per tile index
+    }
   }
-  pick_tile(Mc, d->C, vec, lean, mult4, &p.bm, &p.bn);
   const int t_total = d->KH * d->KW * d->K / BK;
   p.tps = t_total;
   if (may_split && s == 1 && lean && splitk_enabled() && p.bn != 32 && t_total >= 32 && !(d->C & 3) && !(d->ldx & 3))
@@ -1487,14 +1512,11 @@ extern "C" int contrad_conv2d_dgrad_ws(const contrad_conv_desc* d, const float* 
   // gy rows a group's classes share are still cache-resident when the next class reads them.  3x3 s2 at batch 32:
   // 72 -> 99, 84 -> 102, 78 -> 117, 82 -> 99 TF/s; groups of 32 / 64 lose again on layers with < ~100 M-tiles (few
   // groups -> a tail of light classes).  tools/bench_conv.py; CONTRAD_DGRAD_CGROUP=0 restores the old order.
-  {
-    static const int g = []() { const char* e = contrad_dev_env("CONTRAD_DGRAD_CGROUP"); return e ? atoi(e) : 8; }();
-    a.cgroup = (s > 1) ? (g < a.tiles_m ? g : a.tiles_m) : 0;
-  }
+  a.cgroup = (s > 1) ? dgrad_cgroup(a.tiles_m, a.tiles_n) : 0;
   // ... and equal work per block where the classes are unequal (3x3 stride 2: 4 / 2 / 2 / 1 taps): a block of a light
   // class walks 2 / 4 consecutive M-tiles (dgrad_balance(); igemm_lean.h).  Neighbours are then equal AND every block of
   // the launch carries the same number of K-tiles, so the tail of the launch is not a few 4-tap blocks running alone.
-  if (vec && lean_ok(d, MODE_DGRAD, 0) && !a.pixmajor && a.nwin == 0) {
+  if (pl.balanced && vec && lean_ok(d, MODE_DGRAD, 0) && !a.pixmajor && a.nwin == 0) {
     const long long blocks = dgrad_balance(d, a.tiles_m, &a);
     if (blocks > 0) {
       a.cgroup = 0;
@@ -1577,13 +1599,12 @@ extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int 
                         : p.pixmajor == 1 ? cdiv(d->N, p.bm) * cdiv(d->H, s) * cdiv(d->W, s) : cdiv((int)Mc, p.bm);
     const int tiles_n = cdiv(d->C, p.bn);
     if (p.splits > 1) return (long long)tiles_m * tiles_n * p.splits;
-    if (vec_ok(d, MODE_DGRAD) && lean_ok(d, MODE_DGRAD, 0) && p.pixmajor == 0) {
+    if (p.balanced && vec_ok(d, MODE_DGRAD) && lean_ok(d, MODE_DGRAD, 0) && p.pixmajor == 0) {
       IgemmArgs a{};
       const long long blocks = dgrad_balance(d, tiles_m, &a);
       if (blocks > 0) return blocks * tiles_n;
     }
-    static const int g = []() { const char* e = contrad_dev_env("CONTRAD_DGRAD_CGROUP"); return e ? atoi(e) : 8; }();
-    const int cgroup = (s > 1) ? (g < tiles_m ? g : tiles_m) : 0;
+    const int cgroup = (s > 1) ? dgrad_cgroup(tiles_m, tiles_n) : 0;
     const int tm_pad = cgroup > 0 ? cdiv(tiles_m, cgroup) * cgroup : tiles_m;
     return (long long)tm_pad * tiles_n * s * s;
   }

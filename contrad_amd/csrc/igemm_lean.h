@@ -51,10 +51,14 @@ __device__ __forceinline__ void divmod_u(int x, int d, int sh, int& q, int& r) {
 // One tile of the launch: everything after the block -> (tile_m, tile_n, class / split) decode.  Its early returns are
 // block-uniform and sit before the first barrier.  (A separate function so that a block can walk SEVERAL tiles: the strided
 // data gradient hands its light parity classes out in runs of 2 / 4 M-tiles per block, see the decode in the kernel.)
-template <int MODE, int BM, int BN>
+template <int MODE, int BM, int BN, bool BAL>
 __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const int tile_m, const int tile_n, const int by,
                                           const int wc_h0, const int wc_w0, const int wc_hc, const int wc_wc) {
   static_assert(BK == 16, "the lean loop is written for a 16-deep K-tile");
+  static_assert(!BAL || MODE == MODE_DGRAD, "balanced order: strided data gradient only");
+  // BAL (balanced strided DGRAD): image-major tiles of the parity classes only -- no pixel-major tiles, border classes or
+  // split-K; folding the three plan fields to constants keeps that instance's scalar registers for its tile loop
+  const int pl_pixmajor = BAL ? 0 : p.pixmajor, pl_nwin = BAL ? 0 : p.nwin, pl_dsplits = BAL ? 0 : p.dsplits;
   constexpr bool A_Q = (MODE != MODE_WGRAD);   // A K-contiguous in memory -> quad layout
   constexpr bool B_Q = (MODE == MODE_DGRAD);
   constexpr int QSA = BM * 4 + 16, QSB = BN * 4 + 16;   // quad stride (+16: the 4 quads of a row-group hit 4 bank groups)
@@ -86,7 +90,7 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
 
   int M = p.M, Ncol = p.Ncol;
   int T = 0;                       // K-tiles this block contracts over
-  // pixel-major tiles (p.pixmajor, small maps): the rows of an M-tile are BM IMAGES at ONE output pixel, so "this tap is
+  // pixel-major tiles (pl_pixmajor, small maps): the rows of an M-tile are BM IMAGES at ONE output pixel, so "this tap is
   // padding" is the same for every row and the K walk simply skips such taps (a 3x3 pad-1 layer on a 4x4 map multiplies
   // zeros in 31 % of its tap-positions, a 4x4 stride-2 layer onto 4x4 in 23 %)
   unsigned tapmask = 0xFFFFFFFFu;  // taps the walk visits (wave-uniform)
@@ -118,7 +122,7 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
     u_a = u_tap / d.KW;
     u_b = u_tap - u_a * d.KW;
     const int HoWo = d.Ho * d.Wo;
-    if (p.pixmajor) {
+    if (pl_pixmajor) {
       // tile_m = image block * Ho*Wo + pixel: neighbouring blocks read the same BM images
       const int ib = tile_m / HoWo, pix = p.px_order[tile_m - ib * HoWo];
       const int ho = pix / d.Wo, wo = pix - ho * d.Wo;
@@ -146,7 +150,7 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
       px_rows = min(BM, d.N - n_first);
     }
     // rows of the tile = (image, pixel) over the whole output map, or over this tile's border class (window)
-    const bool win = p.nwin > 0;
+    const bool win = pl_nwin > 0;
     const int gHo = win ? wc_hc : d.Ho, gWo = win ? wc_wc : d.Wo;
     if (win) {
       M = d.N * gHo * gWo;
@@ -164,10 +168,10 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
     }
     const int sh_w = pow2_shift(gWo), sh_h = pow2_shift(gHo);
     const int n_first = (sh_w >= 0 && sh_h >= 0) ? (m0 >> (sh_w + sh_h)) : m0 / (gHo * gWo);
-    if (!p.pixmajor) baseA = p.A + ((long long)n_first * d.H * d.W - (d.pad * d.W + d.pad)) * d.ldx;
+    if (!pl_pixmajor) baseA = p.A + ((long long)n_first * d.H * d.W - (d.pad * d.W + d.pad)) * d.ldx;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-      if (p.pixmajor) break;
+      if (pl_pixmajor) break;
       const int m = m0 + qrow + 64 * i;
       const bool ok = m < M;
       const int mm = ok ? m : m0;
@@ -190,8 +194,8 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
     }
   } else if constexpr (MODE == MODE_DGRAD) {
     const int s = d.stride;
-    // stride 1 with split-K (p.dsplits > 1): grid.y counts K-splits, there is a single parity class
-    const int cls = (p.dsplits > 1) ? 0 : by;
+    // stride 1 with split-K (pl_dsplits > 1): grid.y counts K-splits, there is a single parity class
+    const int cls = (pl_dsplits > 1) ? 0 : by;
     ph = cls / s;
     pw = cls % s;
     Hc = (d.H - ph + s - 1) / s;
@@ -205,7 +209,7 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
     M = d.N * Hc * Wc;
     Ncol = d.C;
     T = nth * ntw * d.K / BK;
-    if (p.dsplits > 1) {   // this block contracts K-tiles [t_begin, t_begin + T) into its slab (taps-inner order)
+    if (pl_dsplits > 1) {   // this block contracts K-tiles [t_begin, t_begin + T) into its slab (taps-inner order)
       const int t_begin = by * p.ptiles_per_split, ntaps = nth * ntw;
       T = min(p.ptiles_per_split, T - t_begin);
       if (T < 0) T = 0;
@@ -215,7 +219,7 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
       u_b = u_tap - u_a * ntw;
     }
     if (ntw == 0) ntw = 1;
-    if (p.nwin > 0) {   // stride 1: this tile's border class of dx pixels (a window of the map), its taps are those of its first pixel
+    if (pl_nwin > 0) {   // stride 1: this tile's border class of dx pixels (a window of the map), its taps are those of its first pixel
       Hc = wc_hc; Wc = wc_wc;
       M = d.N * Hc * Wc;
       const int ah0 = wc_h0 + bh, aw0 = wc_w0 + bw;
@@ -231,7 +235,7 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
       u_c0 = 0;
     }
     const int HcWc = Hc * Wc;
-    if (p.pixmajor) {
+    if (pl_pixmajor) {
       // tile_m = image block * (pixels of the largest class) + pixel of this class: BM images at ONE dx pixel
       const int ib = tile_m / p.px_pixels, cpix = p.px_order[tile_m - ib * p.px_pixels];
       if (cpix >= HcWc) return;   // uniform per block, before any barrier
@@ -261,13 +265,13 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
       px_pitch = d.H * d.W * d.ldx;
       px_rows = min(BM, d.N - n_first);
     }
-    if (!p.pixmajor && m0 >= M) return;  // uniform per block, before any barrier
+    if (!pl_pixmajor && m0 >= M) return;  // uniform per block, before any barrier
     const int sh_w = pow2_shift(Wc), sh_h = pow2_shift(Hc);
     const int n_first = (sh_w >= 0 && sh_h >= 0) ? (m0 >> (sh_w + sh_h)) : m0 / HcWc;
-    if (!p.pixmajor) baseA = p.A + ((long long)n_first * d.Ho * d.Wo - ((nth - 1) * d.Wo + (ntw - 1))) * d.ldy;
+    if (!pl_pixmajor) baseA = p.A + ((long long)n_first * d.Ho * d.Wo - ((nth - 1) * d.Wo + (ntw - 1))) * d.ldy;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-      if (p.pixmajor) break;
+      if (pl_pixmajor) break;
       const int m = m0 + qrow + 64 * i;
       const bool ok = m < M;
       const int mm = ok ? m : m0;
@@ -295,7 +299,7 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
     if (T < 0) T = 0;
     gw = min(d.Wo, 16);
     gh = min(d.Ho, 16 / gw);
-    if (p.pixmajor) { gw = 1; gh = 1; }   // pixel-major positions: a K-tile is 16 IMAGES at one output pixel
+    if (pl_pixmajor) { gw = 1; gh = 1; }   // pixel-major positions: a K-tile is 16 IMAGES at one output pixel
     gn = 16 / (gw * gh);
     const int tpr = d.Wo / gw, tpi = tpr * (d.Ho / gh);   // patches per output row / per image
     u_w = (t_begin % tpr) * gw;
@@ -303,8 +307,8 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
     u_n = (t_begin / tpi) * gn;
     n_begin = u_n;
     baseA = p.A + ((long long)n_begin * d.H * d.W - (d.pad * d.W + d.pad)) * d.ldx;
-    baseB = p.pixmajor ? p.B + (long long)n_begin * d.Ho * d.Wo * d.ldy : p.B + (long long)t_begin * BK * d.ldy;
-    if (p.pixmajor) {
+    baseB = pl_pixmajor ? p.B + (long long)n_begin * d.Ho * d.Wo * d.ldy : p.B + (long long)t_begin * BK * d.ldy;
+    if (pl_pixmajor) {
       // Every row of this tile belongs to ONE filter tap (the plan guarantees C % BM == 0), so "the tap reads padding at
       // this pixel" holds for the whole K-tile: such K-tiles are not visited at all.  wskip = the borders (bits as in
       // inv / edge) at which this tile's tap is padding.  The blocks that also sum the bias gradient visit everything.
@@ -347,7 +351,7 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       const int col = n0 + b_c4 * 4;
-      const int rowpitch = p.pixmajor ? d.Ho * d.Wo * d.ldy : d.ldy;      // pixel-major: the 16 rows are 16 images
+      const int rowpitch = pl_pixmajor ? d.Ho * d.Wo * d.ldy : d.ldy;      // pixel-major: the 16 rows are 16 images
       vb[i] = (col < Ncol && b_r + B_RPP * i < BK) ? (unsigned)((((b_r + B_RPP * i) * rowpitch) + col) * 4) : LEAN_OOB;
     }
   }
@@ -373,7 +377,7 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
       soffB = (unsigned)((tapflat * d.C * d.ldw + u_c0) * 4);
     } else {
       soffA = (unsigned)(((((u_n - n_begin) * d.H + u_h * d.stride) * d.W + u_w * d.stride) * d.ldx) * 4);
-      soffB = p.pixmajor ? (unsigned)((((u_n - n_begin) * d.Ho + u_h) * d.Wo + u_w) * d.ldy * 4)
+      soffB = pl_pixmajor ? (unsigned)((((u_n - n_begin) * d.Ho + u_h) * d.Wo + u_w) * d.ldy * 4)
                          : (unsigned)(t_next * BK * d.ldy * 4);
       edge = (u_h == 0 ? 1u : 0u) | (u_h == d.Ho - gh ? 2u : 0u) | (u_w == 0 ? 4u : 0u) | (u_w == d.Wo - gw ? 8u : 0u);
     }
@@ -574,7 +578,7 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
     const int c = n0 + wn * WN + j * 32 + l31;
     colpart[j] = (c < Ncol) ? (unsigned)c * 4u : COL_OOB;
   }
-  const bool rowtab = (MODE == MODE_DGRAD) || (MODE == MODE_FWD && p.nwin > 0);   // rows scattered over the output map
+  const bool rowtab = (MODE == MODE_DGRAD) || (MODE == MODE_FWD && pl_nwin > 0);   // rows scattered over the output map
   if (rowtab) {
     // row -> byte offset of the output pixel (dx for DGRAD, y for a FWD border class) relative to the tile's first image
     // (or out of range), staged in LDS
@@ -587,7 +591,7 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
     if (tid < BM) {
       const int m = m0 + tid;
       unsigned off = 2u * COL_OOB;
-      if (MODE == MODE_DGRAD && p.pixmajor) {
+      if (MODE == MODE_DGRAD && pl_pixmajor) {
         if (tid < px_rows) off = (unsigned)(tid * px_pitch) * 4u;
       } else if (m < M) {
         int wq, t2, hq, n;
@@ -602,10 +606,10 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
       rowoff[tid] = off;
     }
     __syncthreads();
-    const size_t img0 = (MODE == MODE_DGRAD && p.pixmajor)
+    const size_t img0 = (MODE == MODE_DGRAD && pl_pixmajor)
                             ? (size_t)px_off
                             : (size_t)n_first * oH * oW * old_ +
-                                  ((MODE == MODE_DGRAD && p.dsplits > 1) ? (size_t)by * (size_t)p.slab_elems : 0);
+                                  ((MODE == MODE_DGRAD && pl_dsplits > 1) ? (size_t)by * (size_t)p.slab_elems : 0);
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C + img0, 0, (int)COL_OOB, 0x00020000);
     // second operand of the epilogue, in the output's own layout: DGRAD the producer's activation (act'), FWD the addend
     const float* ref = (MODE == MODE_DGRAD) ? p.act_ref : p.addend;
@@ -644,7 +648,7 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
       }
   } else {
     const bool slab = (MODE == MODE_WGRAD) || p.ny > 1;              // split-K partial slab [split][M][Ncol]
-    const bool pxm = (MODE == MODE_FWD) && p.pixmajor;               // rows = images at one pixel: pitch = one image of y
+    const bool pxm = (MODE == MODE_FWD) && pl_pixmajor;               // rows = images at one pixel: pitch = one image of y
     const int pitch = pxm ? px_pitch : (slab ? Ncol : d.ldy);
     const size_t out_off = pxm ? (size_t)px_off : (slab ? (size_t)by * M * Ncol : (size_t)0) + (size_t)m0 * pitch;
     float* outp = p.C + out_off;
@@ -700,7 +704,7 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
   }
 }
 
-template <int MODE, int BM, int BN>
+template <int MODE, int BM, int BN, bool BAL = false>
 __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(const IgemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // 1-D grid, remapped so that each XCD (own L2) owns a contiguous run of ids.  Decode order = who shares operands:
@@ -718,7 +722,7 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     by = lin / tiles;
     const int b = lin - by * tiles;
     tile_n = b % p.tiles_n; tile_m = b / p.tiles_n;
-  } else if (MODE == MODE_DGRAD && p.cbal > 0) {
+  } else if constexpr (BAL) {
     // strided DGRAD, equal work per block (igemm.hip, dgrad_balance()): the parity classes of a 3x3 stride-2 layer contract
     // over 4 / 2 / 2 / 1 taps, so a block of class c walks cb_reps[c] = 1 / 2 / 2 / 4 consecutive M-tiles of its class -- every
     // block multiplies the same number of K-tiles.  Order: groups of cbal M-tile indices, class-major inside a group (the
@@ -766,9 +770,13 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
     const int r = lin / p.tiles_n;
     by = r % p.ny; tile_m = r / p.ny;
   }
-  for (int rep = 0; rep < nrep; ++rep) {
-    lean_tile<MODE, BM, BN>(p, smem, tile_m + rep, tile_n, by, wc_h0, wc_w0, wc_hc, wc_wc);
-    if (rep + 1 < nrep) __syncthreads();   // (the epilogue's row table and the next tile's first LDS stores share smem)
+  if constexpr (BAL) {
+    for (int rep = 0; rep < nrep; ++rep) {
+      lean_tile<MODE, BM, BN, true>(p, smem, tile_m + rep, tile_n, by, 0, 0, 0, 0);
+      if (rep + 1 < nrep) __syncthreads();   // (the epilogue's row table and the next tile's first LDS stores share smem)
+    }
+  } else {
+    lean_tile<MODE, BM, BN, false>(p, smem, tile_m, tile_n, by, wc_h0, wc_w0, wc_hc, wc_wc);
   }
 }
 

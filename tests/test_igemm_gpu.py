@@ -54,6 +54,14 @@ CASES = [
     (70, 12, 20, 16, 64, 4, 2, 1),
     (200, 2, 6, 32, 48, 3, 1, 1),      # ... a 2 x 6 map: most taps of most pixels are padding
     (3, 64, 512, 32, 32, 3, 1, 1),     # ... a non-square map: 3 images x 16 x 16 tiles of 4 x 32, more tiles than one per block
+    # balanced block order of the strided data gradient (3x3 stride 2: blocks of the 4 / 2 / 2 / 1-tap parity classes walk
+    # 1 / 2 / 2 / 4 M-tiles): several groups of 8 M-tile indices, ragged last group, classes of different sizes
+    (7, 17, 17, 64, 128, 3, 2, 0),     # 567 / 504 / 504 / 448 rows per class: 9 (8, 8, 7) tiles of 64 -> two groups, the second almost empty
+    (40, 9, 9, 32, 48, 3, 2, 0),       # 1000 / 800 / 800 / 640 rows, Cout = 48: ragged K walk (3 K-tiles per tap)
+    (3, 33, 33, 128, 144, 3, 2, 0),    # two N-tiles (128 + ragged 16), 128-row tiles
+    (20, 11, 15, 16, 32, 3, 2, 1),     # pad 1: the class order is 1 / 2 / 2 / 4 taps, non-square odd map
+    (2, 129, 129, 16, 16, 3, 2, 0),    # a long launch: 66 M-tiles per class at BM = 128 -> nine groups
+    (16, 65, 65, 64, 64, 3, 2, 0),     # > 1024 blocks in the plain order: the plan itself takes the balanced order here
 ]
 
 
@@ -134,6 +142,22 @@ def test_strided_pixel_major_dgrad_in_a_fresh_process():
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert '1 passed' in r.stdout
+
+
+def test_forced_balanced_strided_dgrad_in_a_fresh_process():
+    """The balanced block order of the 3x3 stride-2 data gradient (blocks of the light parity classes walk 2 / 4 M-tiles) is
+    taken by the plan only for launches of more than 1024 blocks; forced on (dev build), the small ragged cases -- several
+    groups, an almost empty last group, classes of different sizes, pad 0 and pad 1 -- must match the fp32 reference too."""
+    import subprocess
+    import sys
+    env = dict(os.environ, CONTRAD_DGRAD_BALANCE='2', CONTRAD_HIP_LIB=_dev_lib())
+    env.pop('CONTRAD_TILEMODE', None); env.pop('CONTRAD_TEST_EXPECT_DGRAD_PATH', None)
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-m', 'gpu', '-x', '-k',
+                        '5x33x33x32 or 7x17x17x64 or 40x9x9x32 or 3x33x33x128 or 20x11x15x16 or 2x129x129x16 or 2x64x64x16x32x3x2'],
+                       env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert '7 passed' in r.stdout
 
 
 def test_forced_border_classes_in_a_fresh_process():

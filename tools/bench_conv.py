@@ -58,9 +58,10 @@ def main(B=int(os.environ.get('CONV_BATCH', '1536'))):
         dx = torch.empty(B, H, H, C + pad, device=dev)[..., :C]
         dw = torch.empty_like(wp)
         flops = 2.0 * B * Ho * Ho * K * C * k * k
-        t_f = timeit(lambda: ops.conv2d_fwd(x, wp, None, K, k, k, s, p, 0.1, 1.0, out=y))
-        t_d = timeit(lambda: ops.conv2d_dgrad(gy, wp, tuple(x.shape), k, k, s, p, out=dx))
-        t_w = timeit(lambda: ops.conv2d_wgrad(x, gy, k, k, s, p, out=dw))
+        modes = os.environ.get('CONV_MODES', 'fwd,dgrad,wgrad').split(',')      # dev: time a subset (the others print inf)
+        t_f = timeit(lambda: ops.conv2d_fwd(x, wp, None, K, k, k, s, p, 0.1, 1.0, out=y)) if 'fwd' in modes else float('inf')
+        t_d = timeit(lambda: ops.conv2d_dgrad(gy, wp, tuple(x.shape), k, k, s, p, out=dx)) if 'dgrad' in modes else float('inf')
+        t_w = timeit(lambda: ops.conv2d_wgrad(x, gy, k, k, s, p, out=dw)) if 'wgrad' in modes else float('inf')
         print('H%-3d C%-4d K%-4d k%d s%d  %6.1f GF | fwd %7.3f ms %6.1f TF | dgrad %7.3f ms %6.1f TF | wgrad %7.3f ms %6.1f TF'
               % (H, C, K, k, s, flops / 1e9, t_f, flops / t_f / 1e9, t_d, flops / t_d / 1e9, t_w, flops / t_w / 1e9),
               flush=True)
