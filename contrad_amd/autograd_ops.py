@@ -18,6 +18,7 @@ import math
 
 import torch
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 from . import ops
 
@@ -404,6 +405,58 @@ class UpFirDn2dBackwardFn(Function):
         kernel, = ctx.saved_tensors
         up, down, pad = ctx.cfg
         return UpFirDn2dFn.apply(h, kernel, up, down, pad), None, None, None, None, None, None
+
+
+class MinibatchStddevFn(Function):
+    """The minibatch-stddev channel (stylegan2/discriminator.py:22-33) as a node of the any-order family: x (B,H,W,C) ->
+    (B,H,W,Cp) = [x | group statistic | zero padding].  Its backward is MinibatchStddevBwdFn, which is differentiable once
+    more -- the R1 penalty reaches the conv biases ONLY through this channel's curvature."""
+
+    @staticmethod
+    def forward(ctx, x, cpad, splits):
+        x = _cont(x)
+        ctx.save_for_backward(x)
+        ctx.splits = splits
+        return ops.minibatch_stddev(0, x, cpad=cpad, splits=splits)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, = ctx.saved_tensors
+        return MinibatchStddevBwdFn.apply(x, gy, ctx.splits), None, None
+
+
+class MinibatchStddevBwdFn(Function):
+    @staticmethod
+    def forward(ctx, x, gy, splits):
+        gy = _cont(gy)
+        ctx.save_for_backward(x, gy)
+        ctx.splits = splits
+        return ops.minibatch_stddev(1, x, gy=gy, splits=splits)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, h):
+        x, gy = ctx.saved_tensors
+        gx2, ggy = ops.minibatch_stddev(2, x, gy=gy, h=_cont(h), splits=ctx.splits)
+        return gx2, ggy, None
+
+
+class SumSqMeanFn(Function):
+    """mean_n sum_chw g^2 (r1_loss, train_stylegan2.py:112) in two launches; backward = g * (2 / N * grad_out), with grad_out
+    read on the device."""
+
+    @staticmethod
+    def forward(ctx, g):
+        g = _cont(g)
+        ctx.save_for_backward(g)
+        ctx.n = g.shape[0]
+        return ops.sumsq(g, 1.0 / g.shape[0])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        g, = ctx.saved_tensors
+        return ops.scale_dev(g, _cont(gout), 2.0 / ctx.n)
 
 
 class ZeroGradFn(Function):

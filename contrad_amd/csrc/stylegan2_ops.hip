@@ -612,3 +612,177 @@ extern "C" int contrad_lincomb(const float* x, const float* z, float* y, long lo
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }
+
+// ----------------------------------------------------------------------------------------------------------------------
+// Minibatch-stddev channel (_minibatch_stddev_layer, models/gan/stylegan2/discriminator.py:22-33) with its first and second
+// backward, on NHWC.  x [B][P][C] (P = H*W pixels, dense), y [B][P][Cp] with Cp >= C + 1: y[.., :C] = x, y[.., C] =
+// s[b mod M], y[.., C+1:] = 0 (the channel count padded to a multiple of 16 for the conv engine).  group G = min(B, 4),
+// M = B / G;  s[m] = mean_{p,c} sqrt( var_g( x[g*M + m, p, c] ) + 1e-8 ), var biased (as the reference: unbiased=False).
+// One block per m (1024 threads): G * P * C = 32 k ... 131 k values per block, read once; sums in a fixed order.
+// The R1 penalty differentiates D's input gradient, so the backward is itself differentiable (autograd_ops.MinibatchStddevFn):
+//   first backward   gx[g,p,c]  = gy[g,p,c] + gs * (x_g - mu) / (G * PC * sigma),  gs = sum_{g,p} gy[g,p,C]  (per m), PC = P*C
+//   second backward  (cotangent h of gx)
+//                    ggy[g,p,c] = h[g,p,c];  ggy[g,p,C] = t = sum_{g,p,c} h_g (x_g - mu) / (G * PC * sigma);  pad channels 0
+//                    gx2[k,p,c] = gs / (G * PC) * ( (h_k - mean_g h) / sigma - (x_k - mu) * sum_g h_g (x_g - mu) / (G sigma^3) )
+// ----------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int MBS_THREADS = 1024;
+constexpr int MBS_MAXG = 4;
+
+__device__ __forceinline__ float mbs_block_sum(float v, float* red) {   // fixed-order block reduction (1024 threads)
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MBS_THREADS / 64; ++i) s += red[i];
+  return s;
+}
+
+// mode 0: forward; 1: first backward; 2: second backward
+template <int MODE>
+__global__ __launch_bounds__(MBS_THREADS) void mbstd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                            const float* __restrict__ h, float* __restrict__ out,
+                                                            float* __restrict__ out2, int G, int M, int P, int C, int Cp) {
+  __shared__ float red[MBS_THREADS / 64];
+  const int m = blockIdx.x;
+  const long long PC = (long long)P * C;
+  const float invG = 1.f / (float)G;
+  float gs = 0.f;
+  if (MODE >= 1) {                       // gs = sum over the group's samples and pixels of the stddev channel of gy
+    float v = 0.f;
+    for (int i = threadIdx.x; i < G * P; i += MBS_THREADS) {
+      const int g = i / P, p = i - g * P;
+      v += gy[((long long)(g * M + m) * P + p) * Cp + C];
+    }
+    gs = mbs_block_sum(v, red);
+  }
+  const float k1 = gs / ((float)G * (float)PC);
+  float acc = 0.f;
+  for (long long e = threadIdx.x; e < PC; e += MBS_THREADS) {
+    const int p = (int)(e / C), c = (int)(e - (long long)p * C);
+    float xv[MBS_MAXG], hv[MBS_MAXG];
+    float mu = 0.f;
+#pragma unroll
+    for (int g = 0; g < MBS_MAXG; ++g)
+      if (g < G) { xv[g] = x[(long long)(g * M + m) * PC + e]; mu += xv[g]; }
+    mu *= invG;
+    float var = 0.f;
+#pragma unroll
+    for (int g = 0; g < MBS_MAXG; ++g)
+      if (g < G) { const float dd = xv[g] - mu; var += dd * dd; }
+    const float sigma = sqrtf(var * invG + 1e-8f);
+    if (MODE == 0) {
+      acc += sigma;
+#pragma unroll
+      for (int g = 0; g < MBS_MAXG; ++g)
+        if (g < G) out[((long long)(g * M + m) * P + p) * Cp + c] = xv[g];
+    } else if (MODE == 1) {
+      const float r = k1 / sigma;
+#pragma unroll
+      for (int g = 0; g < MBS_MAXG; ++g)
+        if (g < G) out[(long long)(g * M + m) * PC + e] = gy[((long long)(g * M + m) * P + p) * Cp + c] + r * (xv[g] - mu);
+    } else {
+      float hbar = 0.f, hx = 0.f;
+#pragma unroll
+      for (int g = 0; g < MBS_MAXG; ++g)
+        if (g < G) { hv[g] = h[(long long)(g * M + m) * PC + e]; hbar += hv[g]; hx += hv[g] * (xv[g] - mu); }
+      hbar *= invG;
+      const float is = 1.f / sigma;
+      acc += hx * is;
+      const float q = hx * invG * is * is * is;
+#pragma unroll
+      for (int g = 0; g < MBS_MAXG; ++g)
+        if (g < G) {
+          out[(long long)(g * M + m) * PC + e] = k1 * ((hv[g] - hbar) * is - (xv[g] - mu) * q);     // gx2
+          out2[((long long)(g * M + m) * P + p) * Cp + c] = hv[g];                                   // ggy[.., :C] = h
+        }
+    }
+  }
+  if (MODE == 1) return;
+  const float tot = mbs_block_sum(acc, red);
+  const float chan = (MODE == 0) ? tot / (float)PC : tot / ((float)G * (float)PC);
+  float* y = (MODE == 0) ? out : out2;
+  const int extra = Cp - C;              // stddev channel + zero padding
+  for (int i = threadIdx.x; i < G * P * extra; i += MBS_THREADS) {
+    const int j = i % extra, gp = i / extra;
+    const int g = gp / P, p = gp - g * P;
+    y[((long long)(g * M + m) * P + p) * Cp + C + j] = (j == 0) ? chan : 0.f;
+  }
+}
+
+// partial[b] = sum of x^2 over a fixed slice; r1_final: out = scale * sum_b partial[b]  (fixed order)
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long long n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float v = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) v += x[i] * x[i];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int nb, float scale, float* __restrict__ out) {
+  __shared__ float red[4];
+  float v = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) v += partial[i];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = scale * ((red[0] + red[1]) + (red[2] + red[3]));
+}
+// y = x * (c * s[0])   (s: a scalar in device memory -- the incoming gradient of a scalar loss term)
+__global__ __launch_bounds__(256) void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ s, float c,
+                                                        float* __restrict__ y, long long n) {
+  const float f = c * s[0];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = x[i] * f;
+}
+
+}  // namespace
+
+extern "C" int contrad_minibatch_stddev(int mode, const float* x, const float* gy, const float* h, float* out, float* out2,
+                                        int B, int P, int C, int Cp, contrad_stream_t stream) {
+  CONTRAD_ARG(x && out && B > 0 && P > 0 && C > 0 && Cp >= C + 1 && mode >= 0 && mode <= 2);
+  CONTRAD_ARG(mode == 0 || gy);
+  CONTRAD_ARG(mode != 2 || (h && out2));
+  const int G = B < MBS_MAXG ? B : MBS_MAXG;
+  CONTRAD_ARG(B % G == 0);                 // (the reference's reshape(group, -1, ...) needs it too)
+  const int M = B / G;
+  if (mode == 0)
+    hipLaunchKernelGGL(mbstd_kernel<0>, dim3(M), dim3(MBS_THREADS), 0, (hipStream_t)stream, x, gy, h, out, out2, G, M, P, C, Cp);
+  else if (mode == 1)
+    hipLaunchKernelGGL(mbstd_kernel<1>, dim3(M), dim3(MBS_THREADS), 0, (hipStream_t)stream, x, gy, h, out, out2, G, M, P, C, Cp);
+  else
+    hipLaunchKernelGGL(mbstd_kernel<2>, dim3(M), dim3(MBS_THREADS), 0, (hipStream_t)stream, x, gy, h, out, out2, G, M, P, C, Cp);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" long long contrad_sumsq_workspace_bytes(long long n) {
+  if (n <= 0) return -22;
+  long long nb = (n + 256 * 16 - 1) / (256 * 16);
+  if (nb > 1024) nb = 1024;
+  return nb * (long long)sizeof(float);
+}
+
+extern "C" int contrad_sumsq(const float* x, long long n, float scale, float* out, float* workspace,
+                             long long workspace_bytes, contrad_stream_t stream) {
+  CONTRAD_ARG(x && out && workspace && n > 0 && workspace_bytes >= contrad_sumsq_workspace_bytes(n));
+  const int nb = (int)(contrad_sumsq_workspace_bytes(n) / (long long)sizeof(float));
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, n, workspace);
+  CONTRAD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, nb, scale, out);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int contrad_scale_dev(const float* x, const float* s, float c, float* y, long long n, contrad_stream_t stream) {
+  CONTRAD_ARG(x && s && y && n > 0);
+  long long grid = (n + 256 * 8 - 1) / (256 * 8);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(scale_dev_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, x, s, c, y, n);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}

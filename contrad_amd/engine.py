@@ -161,7 +161,15 @@ def r1_loss(D, images, augment_fn):
     d_real = D(images_aug)
     with A.input_grad_only():        # this backward is asked for d / d images only: skip the parameter gradients
         grad_real, = torch.autograd.grad(outputs=d_real.sum(), inputs=images_aug, create_graph=True, retain_graph=True)
-    return grad_real.pow(2).reshape(grad_real.shape[0], -1).sum(1).mean()
+    return A.SumSqMeanFn.apply(grad_real)          # grad_real.pow(2).reshape(N, -1).sum(1).mean(), two launches
+
+
+def _sg2_fakes(G, N, style_mix):
+    """G(G.sample_latent(N), style_mix) (train_stylegan2.py:116-123); contrad_amd's Generator draws everything random of
+    that forward in one device launch (Generator.draw_inputs), any other generator goes through the reference API."""
+    if hasattr(G, 'draw_inputs'):
+        return G(**G.draw_inputs(N, style_mix))
+    return G(G.sample_latent(N), style_mix=style_mix)
 
 
 def d_step_stylegan2(P, G, D, opt_D, options, images, step, reducer=None, style_mix=0.9):
@@ -169,12 +177,12 @@ def d_step_stylegan2(P, G, D, opt_D, options, images, step, reducer=None, style_
     R1 penalty every ``P.d_reg_every`` steps weighted (0.5*lbd_r1)*r1*d_reg_every (``--no_lazy`` => every step)."""
     THROTTLE.begin()
     with torch.no_grad():
-        gen_images = G(G.sample_latent(images.size(0)), style_mix=style_mix)
+        gen_images = _sg2_fakes(G, images.size(0), style_mix)
     d_loss, aux = P.train_fn["D"](P, D, options, images, gen_images)
     loss = d_loss + aux['penalty']
     if (step % P.d_reg_every == 0) and P.lbd_r1 > 0:
         r1 = r1_loss(D, images, P.augment_fn)
-        loss = loss + (0.5 * P.lbd_r1) * r1 * P.d_reg_every
+        loss = torch.add(loss, r1, alpha=(0.5 * P.lbd_r1) * P.d_reg_every)      # one launch (and one in the backward)
         aux['r1'] = r1
     opt_D.zero_grad()
     loss.backward()
@@ -213,12 +221,12 @@ def d_step_stylegan2_contrad(P, G, D, opt_D, options, images, step, reducer=None
     N = images.size(0)
     THROTTLE.begin()
     with torch.no_grad():
-        gen_images = G(G.sample_latent(N), style_mix=style_mix)
+        gen_images = _sg2_fakes(G, N, style_mix)
     d_loss, aux = loss_D_fn_separate(P, D, options, images, gen_images)
     loss = d_loss + aux['penalty']
     if (step % P.d_reg_every == 0) and P.lbd_r1 > 0:
         r1 = r1_loss(D, images, P.augment_fn)
-        loss = loss + (0.5 * P.lbd_r1) * r1 * P.d_reg_every
+        loss = torch.add(loss, r1, alpha=(0.5 * P.lbd_r1) * P.d_reg_every)      # one launch (and one in the backward)
         aux['r1'] = r1
     opt_D.zero_grad()
     loss.backward()
@@ -397,26 +405,26 @@ class _StaticSG2Inputs(object):
 
     def __init__(self, G, N, device, style_mix):
         self.G, self.N, self.dev, self.style_mix = G, N, device, style_mix
-        self.z = torch.zeros(N, G.style_dim, device=device)
-        self.z_mix = torch.zeros(N, G.style_dim, device=device)
+        self.flat = torch.zeros(sum(G.input_sizes(N)), device=device)        # z | mixing latent | per-layer noise
         self.mix_layer = torch.zeros(N, device=device)
-        self.noise = [torch.zeros(N, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), device=device)
-                      for i in range(G.num_layers)]
+        self.mixing = G.training and style_mix > 0
+        z, z_mix, noise = G.input_views(self.flat, N)
+        self.kw = dict(input=z, style_mix=style_mix, noise=noise)
+        if self.mixing:
+            self.kw['_mix'] = (z_mix, self.mix_layer)
 
     def refresh(self):
+        """Generator.draw_inputs' draws, in its order, into the static tensors: one device normal_(), then the CPU draws."""
         from .hostio import upload
         G, N = self.G, self.N
-        self.z.normal_()
-        if G.training and self.style_mix > 0:
-            self.z_mix.normal_()
+        self.flat.normal_()
+        if self.mixing:
             nomix = torch.rand(N) >= self.style_mix
             mix_layer = torch.randint(G.n_latent, (N,)).masked_fill(nomix, G.n_latent)
             self.mix_layer.copy_(upload(mix_layer.float().view(-1, 1), self.dev).view(-1))
-        for t in self.noise:
-            t.normal_()
 
     def forward(self):
-        return self.G(self.z, style_mix=self.style_mix, noise=self.noise, _mix=(self.z_mix, self.mix_layer))
+        return self.G(**self.kw)
 
 
 class GraphedSG2DStep(object):
@@ -485,7 +493,7 @@ class GraphedSG2DStep(object):
         loss = d_loss + aux['penalty']
         if self.r1_in_graph:
             r1 = r1_loss(D, self.images, self.saug)
-            loss = loss + (0.5 * P.lbd_r1) * r1 * P.d_reg_every
+            loss = torch.add(loss, r1, alpha=(0.5 * P.lbd_r1) * P.d_reg_every)     # (as the eager step)
             aux['r1'] = r1
         self.opt.zero_grad(set_to_none=True)
         loss.backward()

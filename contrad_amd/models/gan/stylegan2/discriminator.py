@@ -73,17 +73,20 @@ class _ResBlock(nn.Module):
 
 def minibatch_stddev_batches(x, batch_splits, stddev_group=4):
     """The stddev channel with the statistics confined to consecutive sub-batches: ``batch_splits`` = sizes of the
-    discriminator calls that were merged into this one (see ResidualDiscriminatorP.call_batches)."""
-    if not batch_splits or len(batch_splits) == 1:
-        return minibatch_stddev_nhwc(x, stddev_group)
-    assert sum(batch_splits) == x.shape[0]
-    return torch.cat([minibatch_stddev_nhwc(t, stddev_group) for t in torch.split(x, list(batch_splits), dim=0)], dim=0)
+    discriminator calls that were merged into this one (see ResidualDiscriminatorP.call_batches).  One HIP launch per
+    sub-batch (autograd_ops.MinibatchStddevFn: forward, backward and the backward's backward for R1); the channel count is
+    padded with zeros to a multiple of 16 (513 -> 528: a K-tile of the lean conv loop must not straddle a filter tap)."""
+    assert stddev_group == 4
+    B, H, W, C = x.shape
+    splits = tuple(batch_splits) if batch_splits and len(batch_splits) > 1 else (B,)
+    assert sum(splits) == B
+    return A.MinibatchStddevFn.apply(x, C + 1 + ((-(C + 1)) % 16), splits)
 
 
 def minibatch_stddev_nhwc(x, stddev_group=4):
-    """_minibatch_stddev_layer (discriminator.py:22-33) on NHWC: one extra channel holding, for sample b, the
-    mean over (C,H,W) of the std over the group {b mod M, + M, + 2M, ...}, M = B / group.  (Tiny (B,4,4,512)
-    tensor; kept in differentiable torch ops so the R1 double backward through sqrt/var is exact.)  The channel
+    """_minibatch_stddev_layer (discriminator.py:22-33) on NHWC in differentiable torch ops -- the cross-check of the HIP node
+    family (tests/test_stylegan2_gpu.py); the model itself calls minibatch_stddev_batches.  One extra channel holding, for
+    sample b, the mean over (C,H,W) of the std over the group {b mod M, + M, + 2M, ...}, M = B / group.  The channel
     dimension is padded with zeros to a multiple of 16 (513 -> 528): a K-tile of the lean conv loop must not straddle a
     filter tap, and the 516-channel layout of round 1 sent last_conv to the general kernel (37 TF/s)."""
     B, H, W, C = x.shape

@@ -151,6 +151,33 @@ class Generator(nn.Module):
     def sample_latent(self, num_samples):
         return torch.randn(num_samples, self.style_dim, device=self.device)
 
+    def input_sizes(self, N):
+        """Element counts of everything a training-mode forward draws on the device: z, the mixing latent, per-layer noise."""
+        return [N * self.style_dim, N * self.style_dim] + [N * 4 ** ((i + 5) // 2) for i in range(self.num_layers)]
+
+    def input_views(self, flat, N):
+        parts = torch.split(flat, self.input_sizes(N))
+        z, z_mix = parts[0].view(N, self.style_dim), parts[1].view(N, self.style_dim)
+        noise = [parts[2 + i].view(N, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2)) for i in range(self.num_layers)]
+        return z, z_mix, noise
+
+    def draw_inputs(self, N, style_mix, flat=None):
+        """Everything random in one training-mode forward -- ``G(G.sample_latent(N), style_mix)`` draws z, then inside
+        forward() the mixing latent, the mixing layers (CPU generator) and one noise map per layer (generator.py:91-92,
+        233-234, 252-259) -- with ONE device launch: a single flat normal_() cut into views (the training loops' D- and
+        G-steps and the hipGraph replays all sample through here, so eager and replayed steps consume the same stream).
+        Returns kwargs for forward(): ``G(**G.draw_inputs(N, style_mix))``."""
+        if flat is None:
+            flat = torch.empty(sum(self.input_sizes(N)), device=self.device)
+        flat.normal_()
+        z, z_mix, noise = self.input_views(flat, N)
+        kw = dict(input=z, style_mix=style_mix, noise=noise)
+        if self.training and style_mix > 0:
+            nomix_mask = torch.rand(N) >= style_mix
+            mix_layer = torch.randint(self.n_latent, (N,)).masked_fill(nomix_mask, self.n_latent)
+            kw['_mix'] = (z_mix, mix_layer)
+        return kw
+
     def _layer_idx(self, device):
         t = getattr(self, '_layer_idx_cache', None)
         if t is None or t.device != device:

@@ -567,6 +567,62 @@ def lincomb(x, z, a, b):
     return y
 
 
+def minibatch_stddev(mode, x, gy=None, h=None, cpad=None, splits=None):
+    """contrad_minibatch_stddev (stylegan2/discriminator.py:22-33 and its two backward passes) on NHWC x (B,H,W,C).
+    mode 0 -> y (B,H,W,Cp); mode 1 (gy (B,H,W,Cp)) -> gx (B,H,W,C); mode 2 (gy, h (B,H,W,C)) -> (gx2, ggy).
+    ``splits``: sizes of consecutive sub-batches whose statistics stay separate (several discriminator calls merged into
+    one pass, ResidualDiscriminatorP.call_batches): one launch per sub-batch into slices of the same output."""
+    _chk(x, 'x')
+    B, H, W, C = x.shape
+    if not x.is_contiguous():
+        raise RuntimeError('contrad_hip: minibatch_stddev needs a dense NHWC input')
+    Cp = cpad if gy is None else gy.shape[3]
+    out2 = None
+    if mode == 0:
+        out = torch.empty((B, H, W, Cp), device=x.device, dtype=torch.float32)
+    else:
+        if not gy.is_contiguous() or tuple(gy.shape[:3]) != (B, H, W):
+            raise RuntimeError('contrad_hip: minibatch_stddev needs a dense gy of the output shape')
+        out = torch.empty_like(x)
+        if mode == 2:
+            if not h.is_contiguous() or h.shape != x.shape:
+                raise RuntimeError('contrad_hip: minibatch_stddev needs a dense h of the input shape')
+            out2 = torch.empty_like(gy)
+    splits = list(splits) if splits else [B]
+    if sum(splits) != B:
+        raise RuntimeError('contrad_hip: minibatch_stddev: splits must sum to the batch size')
+    b0 = 0
+    for n in splits:
+        sl = slice(b0, b0 + n)
+        lib().call('contrad_minibatch_stddev', int(mode), _p(x[sl]), _p(gy[sl]) if gy is not None else None,
+                   _p(h[sl]) if h is not None else None, _p(out[sl]), _p(out2[sl]) if out2 is not None else None,
+                   n, H * W, C, Cp, _stream())
+        b0 += n
+    return out if mode != 2 else (out, out2)
+
+
+def sumsq(x, scale):
+    """scale * sum(x^2) as a 0-dim tensor, fixed summation order (contrad_sumsq)."""
+    _chk(x, 'x')
+    x = x if x.is_contiguous() else x.contiguous()
+    n = x.numel()
+    out = torch.empty((), device=x.device, dtype=torch.float32)
+    nbytes = lib().raw('contrad_sumsq_workspace_bytes')(ctypes.c_longlong(n))
+    ws = _workspace(nbytes, x.device)
+    lib().call('contrad_sumsq', _p(x), ctypes.c_longlong(n), float(scale), _p(out), _p(ws), ctypes.c_longlong(ws.numel() * 4),
+               _stream())
+    return out
+
+
+def scale_dev(x, s, c):
+    """x * (c * s) with s a 0-dim device tensor (no host read)."""
+    _chk(x, 'x'); _chk(s, 's')
+    x = x if x.is_contiguous() else x.contiguous()
+    y = torch.empty_like(x)
+    lib().call('contrad_scale_dev', _p(x), _p(s), float(c), _p(y), ctypes.c_longlong(x.numel()), _stream())
+    return y
+
+
 def pixelnorm(x):
     _chk(x, 'x')
     x = x.contiguous()

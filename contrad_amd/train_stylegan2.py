@@ -28,7 +28,7 @@ import torch.distributed as dist
 
 from . import config, ops
 from .augment import get_augment
-from .engine import (GradAllReducer, GraphedSG2DStep, GraphedSG2GStep, loss_D_fn_separate, r1_loss, set_grad,
+from .engine import (GradAllReducer, GraphedSG2DStep, GraphedSG2GStep, _sg2_fakes, loss_D_fn_separate, r1_loss, set_grad,
                      setup_grad_exchange)
 from .hostio import THROTTLE
 from .models.gan import get_architecture
@@ -129,9 +129,8 @@ def accumulate(model_dst, model_src, decay=0.999):
 
 def sample_generator(G, num_samples, style_mix=0.9, enable_grad=True):
     """_sample_generator (train_stylegan2.py:116-123)."""
-    latent_samples = G.sample_latent(num_samples)
     with torch.set_grad_enabled(enable_grad):
-        return G(latent_samples, style_mix=style_mix)
+        return _sg2_fakes(G, num_samples, style_mix)     # z, mixing latent and per-layer noise in one device draw
 
 
 def loss_G_nonsat(d_gen):

@@ -319,6 +319,22 @@ int contrad_fused_bias_act(const float* x, const float* bias, const float* ref, 
 int contrad_lincomb(const float* x, const float* z, float* y, long long n, float a, float b,
                     contrad_stream_t stream);
 
+/* Minibatch-stddev channel (_minibatch_stddev_layer, models/gan/stylegan2/discriminator.py:22-33) on NHWC, with the two
+ * backward passes the R1 penalty needs (train_stylegan2.py:106-113 differentiates D's input gradient).  x [B][P][C] dense
+ * (P = H*W); the output / gy layout is [B][P][Cp], Cp >= C + 1: channels [0, C) = x, channel C = the group statistic of sample
+ * b mod (B / min(B, 4)), channels above = 0 (padding for the conv engine).
+ *   mode 0  out [B][P][Cp] = forward(x)
+ *   mode 1  out [B][P][C]  = d/dx of <forward(x), gy>                         (gy [B][P][Cp])
+ *   mode 2  out [B][P][C], out2 [B][P][Cp] = d/dx, d/dgy of <mode-1 result, h>   (h [B][P][C]) */
+int contrad_minibatch_stddev(int mode, const float* x, const float* gy, const float* h, float* out, float* out2,
+                             int B, int P, int C, int Cp, contrad_stream_t stream);
+/* out[0] = scale * sum_i x[i]^2 in a fixed summation order (r1_loss, train_stylegan2.py:112: grad.pow(2).sum / N) */
+long long contrad_sumsq_workspace_bytes(long long n);
+int contrad_sumsq(const float* x, long long n, float scale, float* out, float* workspace, long long workspace_bytes,
+                  contrad_stream_t stream);
+/* y = x * (c * s[0]), s a scalar in device memory (the backward of the line above) */
+int contrad_scale_dev(const float* x, const float* s, float c, float* y, long long n, contrad_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * StyleGAN2 generator forward helpers (models/gan/stylegan2/generator.py).
  * ---------------------------------------------------------------------------------------------- */

@@ -66,6 +66,44 @@ def test_fused_bias_act(golden):
     assert rel(gx, ref) < 1e-6
 
 
+@pytest.mark.parametrize('B,splits', [(8, None), (12, (4, 8)), (3, None), (16, (16,))])
+def test_minibatch_stddev_node_family_against_torch_ops(B, splits):
+    """The HIP minibatch-stddev channel (forward, backward, and the backward's backward that R1 needs) against the same layer
+    written in differentiable torch ops (the round-3 implementation, discriminator.py:22-33): values, first-order input
+    gradient, and both second-order gradients (w.r.t. x and w.r.t. the incoming gradient), 1e-4."""
+    from contrad_amd.models.gan.stylegan2.discriminator import minibatch_stddev_batches, minibatch_stddev_nhwc
+    g = torch.Generator(device='cuda').manual_seed(B)
+    x0 = torch.randn(B, 4, 4, 32, device=DEV, generator=g)
+
+    def ref(x):
+        if splits is None or len(splits) == 1:
+            return minibatch_stddev_nhwc(x)
+        return torch.cat([minibatch_stddev_nhwc(t) for t in torch.split(x, list(splits), dim=0)], dim=0)
+
+    outs = []
+    for fn in (lambda t: minibatch_stddev_batches(t, splits), ref):
+        x = x0.clone().requires_grad_()
+        y = fn(x)
+        gy = torch.randn(y.shape, device=DEV, generator=torch.Generator(device='cuda').manual_seed(1)).requires_grad_()
+        gx, = torch.autograd.grad(y, x, gy, create_graph=True)
+        h = torch.randn(gx.shape, device=DEV, generator=torch.Generator(device='cuda').manual_seed(2))
+        gx2, ggy = torch.autograd.grad(gx, (x, gy), h)
+        outs.append((y.detach(), gx.detach(), gx2, ggy))
+    assert outs[0][0].shape == outs[1][0].shape == (B, 4, 4, 48)
+    for a, b, what in zip(outs[0], outs[1], ('y', 'gx', 'gx2', 'ggy')):
+        assert rel(a, b) < 1e-4, (what, rel(a, b))
+
+
+def test_r1_sum_of_squares_node():
+    from contrad_amd import autograd_ops as A
+    g = torch.randn(6, 3, 32, 32, device=DEV, requires_grad=True)
+    r = A.SumSqMeanFn.apply(g)
+    ref = g.detach().pow(2).reshape(6, -1).sum(1).mean()
+    assert abs(r.item() - ref.item()) < 1e-5 * ref.item()
+    (3.0 * r).backward()
+    assert rel(g.grad, 3.0 * 2.0 / 6 * g.detach()) < 1e-6
+
+
 def build_d():
     D = ResidualDiscriminatorP(32, small32=True, mlp_linear=True, d_hidden=512)
     D.load_state_dict(S.det_fill_d(S.d_param_shapes(32, True), seed=2024))
