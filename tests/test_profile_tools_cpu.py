@@ -65,7 +65,8 @@ def test_rows_are_attributed_by_launch_order(tmp_path):
     assert '5 steps in the trace' in out
     assert 'section r1_step: 5 conv-engine launches per step, 1 trace step(s) matched' in out
     assert 'section plain_step: 5 conv-engine launches per step, 3 trace step(s) matched' in out
-    assert '1 trace step(s) matched no section' in out and 'step 0: 1 igemm launches' in out
+    assert '1 trace step(s) matched no section' in out and 'step 0 (1 conv-engine launches)' in out
+    assert 'trace 1 / table 0' in out            # the mismatch reason is spelled out (which instance x workgroups differs)
     plain_part = out.split('section plain_step')[1]
     rows = [l.split() for l in plain_part.splitlines() if l.startswith('igemm_lean_kernel<2,128,128>')]
     by_shape = {r[1]: r for r in rows}

@@ -10,6 +10,7 @@ count (C ABI: contrad_conv2d_grid_blocks).  The trace is cut into steps at the o
 dispatches agree with a section's sequence in number, instance and workgroup count, one by one, is attributed dispatch
 by dispatch (eager steps and hipGraph replays alike -- a replay preserves the stream order).  Steps that agree with no
 section (the cold first step of a process, whose plans may differ) are reported as unmatched."""
+import collections
 import json
 import re
 import sqlite3
@@ -24,7 +25,10 @@ def short(name):
 
 
 def norm(k):
-    return re.sub(r'\s+', '', k)
+    k = re.sub(r'\s+', '', k)
+    # igemm_lean_kernel<MODE,BM,BN,false|true>: the 4th argument is the balanced block order of the strided data gradient
+    # (round 4); the shape table names the instance by (MODE, BM, BN) only
+    return re.sub(r'^(igemm_lean_kernel<\d+,\d+,\d+),(?:false|true)>', r'\1>', k)
 
 
 # kernels the conv engine's C-ABI entry points launch as their MAIN dispatch (contrad_conv2d_path), i.e. the rows of
@@ -63,17 +67,36 @@ def main(db_path, table_path):
           'matrix pipe actually ran at')
     print('# %d steps in the trace (cut at the optimizer launch)' % len(steps))
     matched_steps = set()
+    reasons = {}
+    reordered = 0
     for sec, d in table['sections'].items():
         seq = d.get('sequence') or []
         keyseq = [(norm(q[0]), q[2]) for q in seq]
         agg = {}
         nmatch = 0
+        want = collections.Counter(keyseq)
+        slots = collections.defaultdict(list)       # (instance, workgroups) -> positions in the section's sequence, in order
+        for pos, key in enumerate(keyseq):
+            slots[key].append(pos)
         for si, st in enumerate(steps):
-            if len(st) != len(keyseq) or any((a[0], a[1]) != b for a, b in zip(st, keyseq)):
+            # A step belongs to the section when it launches the same MULTISET of (instance, workgroups).  The order may
+            # differ inside a step (the autograd engine is free to order independent nodes; a captured graph replays the
+            # order of ITS capture, not of the eager step the table was written from): the i-th dispatch of a key in the
+            # trace is attributed to the i-th table entry of that key.
+            got = collections.Counter((a[0], a[1]) for a in st)
+            if got != want:
+                if si not in matched_steps:
+                    diff = sorted(((got - want) + (want - got)).items(), key=lambda kv: -kv[1])[:4]
+                    reasons.setdefault(si, []).append('%s: %d vs %d launches, differing keys %s' % (
+                        sec, len(st), len(keyseq), ['%s x%d: trace %d / table %d' % (k[0], k[1], got[k], want[k]) for k, _ in diff]))
                 continue
             nmatch += 1
             matched_steps.add(si)
-            for (k, blocks, us), q in zip(st, seq):
+            reordered += any((a[0], a[1]) != b for a, b in zip(st, keyseq))
+            taken = collections.Counter()
+            for (k, blocks, us) in st:
+                q = seq[slots[(k, blocks)][taken[(k, blocks)]]]
+                taken[(k, blocks)] += 1
                 a = agg.setdefault((norm(q[0]), tuple(q[1]), q[2]), [0, 0.0, q[3], q[4] if len(q) > 4 else 1.0])
                 a[0] += 1
                 a[1] += us
@@ -103,10 +126,13 @@ def main(db_path, table_path):
         print('-- conv engine, %s: %.1f GFLOP per step in %.1f us of igemm dispatches -> %.1f TF/s (%.3f of 157.3); issued %.1f '
               'GFLOP -> %.1f TF/s (%.3f)' % (sec, tot_f, tot_t, tot_f / tot_t * 1e3, tot_f / tot_t * 1e3 / 157.3,
                                               tot_x, tot_x / tot_t * 1e3, tot_x / tot_t * 1e3 / 157.3))
+    if reordered:
+        print('\n(%d matched step(s) launched the section\'s kernels in a different order than the table\'s eager step)' % reordered)
     un = [i for i in range(len(steps)) if i not in matched_steps]
     if un:
-        print('\n== %d trace step(s) matched no section (cold first step / generator-only segments): %s ==' % (
-            len(un), ', '.join('step %d: %d igemm launches' % (i, len(steps[i])) for i in un[:8])))
+        print('\n== %d trace step(s) matched no section: ==' % len(un))
+        for i in un[:8]:
+            print('   step %d (%d conv-engine launches): %s' % (i, len(steps[i]), ' | '.join(reasons.get(i, ['-']))))
 
 
 if __name__ == '__main__':
