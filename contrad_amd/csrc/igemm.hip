@@ -23,6 +23,7 @@
 // activation tile run on the same XCD/L2.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include <utility>
 #include "../../include/contrad_hip.h"
@@ -71,6 +72,7 @@ struct IgemmArgs {
   int nwin;
   unsigned char px_order[256];   // pixel-major FWD / DGRAD: the pixel the k-th tile of an image block works on (balance, see pixel_order())
   int pixmajor;          // lean FWD / DGRAD: M-tiles are BM images at one output pixel (tiles_m = image blocks x Ho*Wo), padding taps skipped
+  int px_full;           // px_order holds the order of ALL tiles of the launch (image block * pixels + pixel), pixel_order_full()
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -1145,6 +1147,78 @@ void pixel_order(const int* taps, int npix, unsigned char* out) {
   for (int i = 0; i < npix; ++i) out[i] = (unsigned char)idx[i];
 }
 
+// Order of ALL pixel-major tiles of a launch (<= 256 of them), for launches that sit on the chip in about one round.
+// How blocks reach CUs (measured through the strided data gradient, tools/dev/dgrad_cgroup2.sh): the dispatcher deals the
+// blocks of an XCD round-robin over its 32 CUs, so with tiles_n N-tiles per M-tile the k-th M-tile of an XCD's run lands on
+// CU slot k mod R, R = 32 / tiles_n, and a CU's time is the SUM of what its slot gets.  On a 4x4 map (3x3 pad 1: tiles of
+// 9 / 6 / 4 taps) heaviest-first within an image block gave the slots 24 vs 16 tap-units where the mean is 18.75 -- the
+// whole gap between these tiles' issue rate (0.68) and the image-major tiles' (0.855).  Here: every XCD gets a contiguous
+// run of image blocks (operand locality in its L2) cut into balanced pieces, and inside the run the tiles are dealt to
+// the R slots longest-processing-time-first with equal counts, then emitted round by round.
+bool pixel_order_full(const int* taps, int npix, int nib, int tiles_n, unsigned char* out) {
+  static const bool on = []() { const char* e = contrad_dev_env("CONTRAD_PIXORDER_FULL"); return !(e && e[0] == '0'); }();
+  const int nt = nib * npix;
+  if (!on || nt > 256 || nt < 8 || tiles_n < 1 || tiles_n > 8 || (32 % tiles_n)) return false;
+  // base order: image-block major; inside a block the pixels sorted by taps and dealt round-robin into `pieces` groups, so
+  // that an XCD boundary inside a block leaves both sides the same work
+  int sorted[256];
+  for (int i = 0; i < npix; ++i) sorted[i] = i;
+  for (int i = 1; i < npix; ++i) {
+    const int v = sorted[i];
+    int j = i - 1;
+    while (j >= 0 && taps[sorted[j]] < taps[v]) { sorted[j + 1] = sorted[j]; --j; }
+    sorted[j + 1] = v;
+  }
+  const int nb = nt * tiles_n, q = nb >> 3, r = nb & 7, R = 32 / tiles_n;
+  int tstart[9];
+  for (int x = 0; x <= 8; ++x) {
+    const int b0 = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;      // first block of XCD x (xcd_remap)
+    tstart[x] = x == 8 ? nt : cdiv(b0, tiles_n);                           // first M-tile whose blocks start in its run
+  }
+  int pieces = 1;                       // an image block is cut by XCD boundaries into `pieces` equal parts (or not at all)
+  for (; pieces < npix; pieces *= 2) {
+    if (npix % pieces) { pieces = 1; break; }
+    bool ok = true;
+    for (int x = 1; x < 8; ++x) ok = ok && (tstart[x] % (npix / pieces) == 0);
+    if (ok) break;
+  }
+  if (pieces >= npix || npix % pieces) pieces = 1;
+  int base[256];
+  for (int ib = 0; ib < nib; ++ib) {
+    int k = 0;
+    for (int g = 0; g < pieces; ++g)
+      for (int i = g; i < npix; i += pieces) base[ib * npix + k++] = ib * npix + sorted[i];
+  }
+  // per XCD (xcd_remap: contiguous runs of blocks): deal its tiles to the slots
+  int pos = 0;
+  for (int x = 0; x < 8; ++x) {
+    const int t0 = tstart[x], t1 = tstart[x + 1];
+    const int n = t1 - t0;
+    if (n <= 0) continue;
+    if (cdiv(n, R) > 16) return false;
+    int idx[256], load[32] = {0}, cnt[32] = {0}, bin[32][16];
+    for (int i = 0; i < n; ++i) idx[i] = base[t0 + i];
+    for (int i = 1; i < n; ++i) {        // heaviest first (stable)
+      const int v = idx[i];
+      int j = i - 1;
+      while (j >= 0 && taps[idx[j] % npix] < taps[v % npix]) { idx[j + 1] = idx[j]; --j; }
+      idx[j + 1] = v;
+    }
+    const int cap = cdiv(n, R);
+    for (int i = 0; i < n; ++i) {
+      int best = -1;
+      for (int j = 0; j < R; ++j)
+        if (cnt[j] < cap && (best < 0 || load[j] < load[best])) best = j;
+      bin[best][cnt[best]++] = idx[i];
+      load[best] += taps[idx[i] % npix];
+    }
+    for (int round = 0; round < cap; ++round)
+      for (int j = 0; j < R; ++j)
+        if (round < cnt[j]) out[pos++] = (unsigned char)bin[j][round];
+  }
+  return pos == nt;
+}
+
 // ---- border classes -------------------------------------------------------------------------------------------------
 // Along each axis the pixels of the map fall into runs with the same set of non-padding filter rows / columns (3x3 pad 1:
 // first row, interior, last row); the products of an h-run and a w-run are rectangles whose pixels all read padding at
@@ -1418,6 +1492,11 @@ extern "C" int contrad_conv2d_fwd_add(const contrad_conv_desc* d, const float* x
         taps[ho * d->Wo + wo] = vh * vw;
       }
     pixel_order(taps, d->Ho * d->Wo, a.px_order);
+    unsigned char full[256];
+    if (pixel_order_full(taps, d->Ho * d->Wo, cdiv(d->N, p.bm), a.tiles_n, full)) {
+      memcpy(a.px_order, full, sizeof(full));
+      a.px_full = 1;
+    }
   }
   a.ptiles_per_split = p.tps;
   if (p.splits > 1) {
@@ -1483,6 +1562,11 @@ extern "C" int contrad_conv2d_dgrad_ws(const contrad_conv_desc* d, const float* 
           taps[h * d->W + w] = vh * vw;
         }
     pixel_order(taps, a.px_pixels, a.px_order);
+    unsigned char full[256];
+    if (s == 1 && pixel_order_full(taps, a.px_pixels, cdiv(d->N, bm), cdiv(d->C, bn), full)) {
+      memcpy(a.px_order, full, sizeof(full));
+      a.px_full = 1;
+    }
   }
   a.tiles_n = cdiv(d->C, bn);
   if (pl.splits > 1) {

@@ -124,7 +124,13 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
     const int HoWo = d.Ho * d.Wo;
     if (pl_pixmajor) {
       // tile_m = image block * Ho*Wo + pixel: neighbouring blocks read the same BM images
-      const int ib = tile_m / HoWo, pix = p.px_order[tile_m - ib * HoWo];
+      int ib, pix;
+      if (p.px_full) {   // the whole launch's tile order from the host (slot-balanced per XCD, igemm.hip pixel_order_full())
+        const int e = p.px_order[tile_m];
+        ib = e / HoWo; pix = e - ib * HoWo;
+      } else {
+        ib = tile_m / HoWo; pix = p.px_order[tile_m - ib * HoWo];
+      }
       const int ho = pix / d.Wo, wo = pix - ho * d.Wo;
       const int n_first = ib * BM;
       unsigned wmask = 0, valid = 0;
@@ -237,7 +243,13 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
     const int HcWc = Hc * Wc;
     if (pl_pixmajor) {
       // tile_m = image block * (pixels of the largest class) + pixel of this class: BM images at ONE dx pixel
-      const int ib = tile_m / p.px_pixels, cpix = p.px_order[tile_m - ib * p.px_pixels];
+      int ib, cpix;
+      if (p.px_full) {
+        const int e = p.px_order[tile_m];
+        ib = e / p.px_pixels; cpix = e - ib * p.px_pixels;
+      } else {
+        ib = tile_m / p.px_pixels; cpix = p.px_order[tile_m - ib * p.px_pixels];
+      }
       if (cpix >= HcWc) return;   // uniform per block, before any barrier
       const int hq = cpix / Wc, wq = cpix - hq * Wc;
       const int ah = hq + bh, aw = wq + bw;
