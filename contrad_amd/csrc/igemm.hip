@@ -1099,12 +1099,66 @@ double dgrad_valid_tap_fraction(const contrad_conv_desc* d) {
   return all ? (double)valid / (double)all : 1.0;
 }
 
+bool pixel_order_full(const int* taps, int npix, int nib, int tiles_n, unsigned char* out, int nruns);
+
+// Pixel-major tiles inside the parity classes of a STRIDED data gradient, with the slot-balanced order (pixel_order_full):
+// the launch is class-major (every class = 2 of the 8 XCD runs) and all four classes use class (0,0)'s table with the pixel
+// mirrored along their odd axes -- possible when the classes are mirror images of one another (even maps, e.g. the 4x4
+// stride-2 pad-1 layers).  Fills taps[] (valid taps per pixel of class (0,0)) and returns its pixel count, or 0.
+// Without the balanced order these tiles LOST (round 3: 0.714 -> 0.757 ms on the 8x8 -> 4x4 layer): a class tile contracts
+// over 1, 2 or 4 taps and the slots' sums were far apart.
+int dgrad_strided_class0_taps(const contrad_conv_desc* d, int* taps) {
+  const int s = d->stride;
+  if (s != 2 || (d->H & 1) || (d->W & 1)) return 0;
+  const int Hc = d->H / 2, Wc = d->W / 2;
+  if (Hc * Wc > 256) return 0;
+  int wh[2][128], ww[2][128];
+  for (int par = 0; par < 2; ++par) {
+    for (int hq = 0; hq < Hc; ++hq) {
+      int v = 0;
+      for (int kh = (par + d->pad) % s; kh < d->KH; kh += s) {
+        const int num = hq * s + par + d->pad - kh;
+        v += num >= 0 && num / s < d->Ho;
+      }
+      wh[par][hq] = v;
+    }
+    for (int wq = 0; wq < Wc; ++wq) {
+      int v = 0;
+      for (int kw = (par + d->pad) % s; kw < d->KW; kw += s) {
+        const int num = wq * s + par + d->pad - kw;
+        v += num >= 0 && num / s < d->Wo;
+      }
+      ww[par][wq] = v;
+    }
+  }
+  for (int hq = 0; hq < Hc; ++hq) if (wh[1][hq] != wh[0][Hc - 1 - hq]) return 0;      // odd class = mirror of the even one
+  for (int wq = 0; wq < Wc; ++wq) if (ww[1][wq] != ww[0][Wc - 1 - wq]) return 0;
+  for (int hq = 0; hq < Hc; ++hq)
+    for (int wq = 0; wq < Wc; ++wq) taps[hq * Wc + wq] = wh[0][hq] * ww[0][wq];
+  return Hc * Wc;
+}
+
+bool dgrad_strided_full_ok(const contrad_conv_desc* d, int bm, int bn) {
+  int taps[256];
+  const int npix = dgrad_strided_class0_taps(d, taps);
+  if (!npix) return false;
+  const int nib = cdiv(d->N, bm), tiles_n = cdiv(d->C, bn);
+  if (((long long)nib * npix * tiles_n) % 2) return false;          // a class = exactly two XCD runs
+  unsigned char tmp[256];
+  return pixel_order_full(taps, npix, nib, tiles_n, tmp, 2);
+}
+
 bool dgrad_pixmajor_ok(const contrad_conv_desc* d, int bm) {
   // stride 1 only: the kernel walks pixel-major tiles inside the parity classes of a strided layer just as well (parity
   // holds, CONTRAD_PIXMAJOR_STRIDED=1), but a class tile then contracts over 1 .. 4 taps only and the 4x4 stride-2
   // layer onto 4x4 maps ran 0.714 -> 0.757 ms at 1536 images
   static const bool strided = []() { const char* e = contrad_dev_env("CONTRAD_PIXMAJOR_STRIDED"); return e && e[0] == '1'; }();
-  if (!pixmajor_enabled() || d->H * d->W > 256 || d->N < bm || (d->stride != 1 && !strided)) return false;
+  if (!pixmajor_enabled() || d->H * d->W > 256 || d->N < bm) return false;
+  if (d->stride != 1 && !strided) {
+    int bm2, bn2;           // the tile the plan takes for this layer (the balanced order depends on its N-tile count)
+    pick_tile((long long)d->N * cdiv(d->H, d->stride) * cdiv(d->W, d->stride), d->C, true, true, 4 * d->stride * d->stride, &bm2, &bn2);
+    if (bm2 != bm || !dgrad_strided_full_ok(d, bm, bn2)) return false;
+  }
   if ((long long)bm * d->Ho * d->Wo * d->ldy * 4 >= (1ll << 30)) return false;    // row offsets inside a tile (bytes)
   if ((long long)bm * d->H * d->W * d->ldx * 4 >= (1ll << 30)) return false;      // the epilogue's row offsets
   return dgrad_valid_tap_fraction(d) <= PIXMAJOR_MAX_VALID;
@@ -1155,10 +1209,12 @@ void pixel_order(const int* taps, int npix, unsigned char* out) {
 // whole gap between these tiles' issue rate (0.68) and the image-major tiles' (0.855).  Here: every XCD gets a contiguous
 // run of image blocks (operand locality in its L2) cut into balanced pieces, and inside the run the tiles are dealt to
 // the R slots longest-processing-time-first with equal counts, then emitted round by round.
-bool pixel_order_full(const int* taps, int npix, int nib, int tiles_n, unsigned char* out) {
+bool pixel_order_full(const int* taps, int npix, int nib, int tiles_n, unsigned char* out, int nruns) {
+  // nruns: XCD runs the table's tiles are spread over (8: the whole launch; a strided layer's class-major launch gives
+  // every parity class 2 of the 8 runs and uses one table for all four classes)
   static const bool on = []() { const char* e = contrad_dev_env("CONTRAD_PIXORDER_FULL"); return !(e && e[0] == '0'); }();
   const int nt = nib * npix;
-  if (!on || nt > 256 || nt < 8 || tiles_n < 1 || tiles_n > 8 || (32 % tiles_n)) return false;
+  if (!on || nt > 256 || nt < nruns || nruns < 1 || nruns > 8 || tiles_n < 1 || tiles_n > 8 || (32 % tiles_n)) return false;
   // base order: image-block major; inside a block the pixels sorted by taps and dealt round-robin into `pieces` groups, so
   // that an XCD boundary inside a block leaves both sides the same work
   int sorted[256];
@@ -1169,17 +1225,17 @@ bool pixel_order_full(const int* taps, int npix, int nib, int tiles_n, unsigned 
     while (j >= 0 && taps[sorted[j]] < taps[v]) { sorted[j + 1] = sorted[j]; --j; }
     sorted[j + 1] = v;
   }
-  const int nb = nt * tiles_n, q = nb >> 3, r = nb & 7, R = 32 / tiles_n;
+  const int nb = nt * tiles_n, q = nb / nruns, r = nb % nruns, R = 32 / tiles_n;
   int tstart[9];
-  for (int x = 0; x <= 8; ++x) {
-    const int b0 = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;      // first block of XCD x (xcd_remap)
-    tstart[x] = x == 8 ? nt : cdiv(b0, tiles_n);                           // first M-tile whose blocks start in its run
+  for (int x = 0; x <= nruns; ++x) {
+    const int b0 = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;      // first block of run x (xcd_remap)
+    tstart[x] = x == nruns ? nt : cdiv(b0, tiles_n);                       // first M-tile whose blocks start in its run
   }
   int pieces = 1;                       // an image block is cut by XCD boundaries into `pieces` equal parts (or not at all)
   for (; pieces < npix; pieces *= 2) {
     if (npix % pieces) { pieces = 1; break; }
     bool ok = true;
-    for (int x = 1; x < 8; ++x) ok = ok && (tstart[x] % (npix / pieces) == 0);
+    for (int x = 1; x < nruns; ++x) ok = ok && (tstart[x] % (npix / pieces) == 0);
     if (ok) break;
   }
   if (pieces >= npix || npix % pieces) pieces = 1;
@@ -1191,7 +1247,7 @@ bool pixel_order_full(const int* taps, int npix, int nib, int tiles_n, unsigned 
   }
   // per XCD (xcd_remap: contiguous runs of blocks): deal its tiles to the slots
   int pos = 0;
-  for (int x = 0; x < 8; ++x) {
+  for (int x = 0; x < nruns; ++x) {
     const int t0 = tstart[x], t1 = tstart[x + 1];
     const int n = t1 - t0;
     if (n <= 0) continue;
@@ -1493,7 +1549,7 @@ extern "C" int contrad_conv2d_fwd_add(const contrad_conv_desc* d, const float* x
       }
     pixel_order(taps, d->Ho * d->Wo, a.px_order);
     unsigned char full[256];
-    if (pixel_order_full(taps, d->Ho * d->Wo, cdiv(d->N, p.bm), a.tiles_n, full)) {
+    if (pixel_order_full(taps, d->Ho * d->Wo, cdiv(d->N, p.bm), a.tiles_n, full, 8)) {
       memcpy(a.px_order, full, sizeof(full));
       a.px_full = 1;
     }
@@ -1563,9 +1619,15 @@ extern "C" int contrad_conv2d_dgrad_ws(const contrad_conv_desc* d, const float* 
         }
     pixel_order(taps, a.px_pixels, a.px_order);
     unsigned char full[256];
-    if (s == 1 && pixel_order_full(taps, a.px_pixels, cdiv(d->N, bm), cdiv(d->C, bn), full)) {
+    if (s == 1 && pixel_order_full(taps, a.px_pixels, cdiv(d->N, bm), cdiv(d->C, bn), full, 8)) {
       memcpy(a.px_order, full, sizeof(full));
       a.px_full = 1;
+    } else if (s == 2 && dgrad_strided_full_ok(d, bm, bn)) {
+      int t0[256];
+      const int npix = dgrad_strided_class0_taps(d, t0);
+      pixel_order_full(t0, npix, cdiv(d->N, bm), cdiv(d->C, bn), full, 2);
+      memcpy(a.px_order, full, sizeof(full));
+      a.px_full = 2;
     }
   }
   a.tiles_n = cdiv(d->C, bn);
@@ -1597,6 +1659,7 @@ extern "C" int contrad_conv2d_dgrad_ws(const contrad_conv_desc* d, const float* 
   // 72 -> 99, 84 -> 102, 78 -> 117, 82 -> 99 TF/s; groups of 32 / 64 lose again on layers with < ~100 M-tiles (few
   // groups -> a tail of light classes).  tools/bench_conv.py; CONTRAD_DGRAD_CGROUP=0 restores the old order.
   a.cgroup = (s > 1) ? dgrad_cgroup(a.tiles_m, a.tiles_n) : 0;
+  if (a.px_full == 2) a.cgroup = a.tiles_m;           // class-major over the whole launch: class c = XCD runs 2c, 2c + 1
   // ... and equal work per block where the classes are unequal (3x3 stride 2: 4 / 2 / 2 / 1 taps): a block of a light
   // class walks 2 / 4 consecutive M-tiles (dgrad_balance(); igemm_lean.h).  Neighbours are then equal AND every block of
   // the launch carries the same number of K-tiles, so the tail of the launch is not a few 4-tap blocks running alone.
@@ -1688,6 +1751,7 @@ extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int 
       const long long blocks = dgrad_balance(d, tiles_m, &a);
       if (blocks > 0) return blocks * tiles_n;
     }
+    if (p.pixmajor == 1 && s == 2) return (long long)tiles_m * tiles_n * s * s;     // class-major, one group (px_full == 2)
     const int cgroup = (s > 1) ? dgrad_cgroup(tiles_m, tiles_n) : 0;
     const int tm_pad = cgroup > 0 ? cdiv(tiles_m, cgroup) * cgroup : tiles_m;
     return (long long)tm_pad * tiles_n * s * s;

@@ -251,7 +251,11 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
         ib = tile_m / p.px_pixels; cpix = p.px_order[tile_m - ib * p.px_pixels];
       }
       if (cpix >= HcWc) return;   // uniform per block, before any barrier
-      const int hq = cpix / Wc, wq = cpix - hq * Wc;
+      int hq = cpix / Wc, wq = cpix - hq * Wc;
+      if (p.px_full == 2) {       // strided layer, one table for all four parity classes: the classes are mirror images of
+        if (ph) hq = Hc - 1 - hq; // class (0,0) (checked on the host), so the table's pixel is mirrored along the odd axes
+        if (pw) wq = Wc - 1 - wq;
+      }
       const int ah = hq + bh, aw = wq + bw;
       const int n_first = ib * BM;
       unsigned wmask = 0, valid = 0;

@@ -62,6 +62,11 @@ CASES = [
     (20, 11, 15, 16, 32, 3, 2, 1),     # pad 1: the class order is 1 / 2 / 2 / 4 taps, non-square odd map
     (2, 129, 129, 16, 16, 3, 2, 0),    # a long launch: 66 M-tiles per class at BM = 128 -> nine groups
     (16, 65, 65, 64, 64, 3, 2, 0),     # > 1024 blocks in the plain order: the plan itself takes the balanced order here
+    # pixel-major tiles in the slot-balanced order of the whole launch (pixel_order_full): FWD / stride-1 DGRAD on a 4x4 map,
+    # and the strided DGRAD of the 4x4 stride-2 layer (class-major launch, one table mirrored into the four parity classes)
+    (384, 4, 4, 64, 256, 3, 1, 1),     # 3 image blocks x 16 pixels, 2 / 4 N-tiles
+    (260, 8, 8, 32, 64, 4, 2, 1),      # strided: ragged last image block, one N-tile
+    (256, 8, 8, 256, 64, 4, 2, 1),     # strided: several N-tiles per M-tile
 ]
 
 
