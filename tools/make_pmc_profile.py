@@ -1,6 +1,6 @@
 """Turn the rocprofv3 --pmc passes of tools/prof_pmc.sh into profiles/<prefix>_pmc.{txt,json}.
 usage: python tools/make_pmc_profile.py <pass dir> <out prefix, e.g. r02_bench_n1> "<profiled command>"
-Passes expected in <pass dir>: fetch, write, sq, misc (one rocprofv3 run each; FETCH_SIZE and WRITE_SIZE never share a
+Passes expected in <pass dir>: fetch, write, sq, misc [, tcc: TCC_HIT_sum / TCC_MISS_sum -> l2_hit_rate] (one rocprofv3 run each; FETCH_SIZE and WRITE_SIZE never share a
 pass, no sys/hip/memory-copy trace domains beside the counters).
 """
 import io, json, os, sys
@@ -39,7 +39,8 @@ def main(d, prefix, command):
            '# per-dispatch means; counters summed over XCDs/SEs; FETCH_SIZE/WRITE_SIZE in KiB (FETCH_SIZE under-reports '
            'wide coalesced reads by 2x on gfx950, MI355X_MICROARCH.md HBM section)']
     parsed = {}
-    for p in ('fetch', 'write', 'sq', 'misc'):
+    passes = ['fetch', 'write', 'sq', 'misc'] + (['tcc'] if os.path.exists(os.path.join(d, 'tcc_results.db')) else [])
+    for p in passes:
         t = table(os.path.join(d, p + '_results.db'))
         t = '\n'.join(l for l in t.splitlines() if not l.startswith('at::') or True)
         txt.append('== pass: ' + p)
@@ -51,7 +52,11 @@ def main(d, prefix, command):
         f, w, sq, m = (parsed[p][kernel] for p in ('fetch', 'write', 'sq', 'misc'))
         cyc = m['GRBM_GUI_ACTIVE'] / 8.0                       # summed over the 8 XCDs
         traffic = (2 * f['FETCH_SIZE'] + w['WRITE_SIZE']) * 1024
+        tcc = parsed.get('tcc', {}).get(kernel, {})
+        hit, miss = tcc.get('TCC_HIT_sum'), tcc.get('TCC_MISS_sum')
         return {
+            "l2_hit_rate": (hit / max(hit + miss, 1.0)) if hit is not None and miss is not None else None,
+            "TCC_HIT_sum": hit, "TCC_MISS_sum": miss,
             "kernel": kernel, "dispatches": f['dispatches'],
             "FETCH_SIZE_KiB_per_launch": f['FETCH_SIZE'], "WRITE_SIZE_KiB_per_launch": w['WRITE_SIZE'],
             "traffic_bytes_per_launch": traffic,
@@ -80,9 +85,9 @@ def main(d, prefix, command):
     js.update(ents[dom])
     json.dump(js, open(os.path.join(ROOT, 'profiles', prefix + '_pmc.json'), 'w'), indent=1)
     for k, v in sorted(ents.items(), key=lambda kv: -kv[1]['avg_dur_us'] * kv[1]['dispatches'])[:40]:
-        print('%-46s %8.1f us  %8.1f MB  %5.2f TB/s  mfma %4.2f  clk %4.2f' % (
+        print('%-46s %8.1f us  %8.1f MB  %5.2f TB/s  mfma %4.2f  clk %4.2f  L2 hit %s' % (
             k[:46], v['avg_dur_us'], v['traffic_bytes_per_launch'] / 1e6, v['hbm_GBps'] / 1e3, v['mfma_busy_fraction'],
-            v['effective_clock_GHz']))
+            v['effective_clock_GHz'], '%.2f' % v['l2_hit_rate'] if v['l2_hit_rate'] is not None else '-'))
 
 
 if __name__ == '__main__':
