@@ -250,6 +250,15 @@ def _pmc_traffic(config, kernel):
         try:
             pmc = json.load(open(os.path.join(prof, f)))
             ent = pmc.get('kernels', {}).get(kernel)
+            if ent is None:
+                # rocprofv3 prints igemm_lean_kernel<MODE, BM, BN, false|true> (4th argument: balanced strided order);
+                # the engine names an instance by its first three
+                want = kernel.replace(' ', '')
+                for k, v in pmc.get('kernels', {}).items():
+                    kk = k.replace(' ', '').replace('(anonymousnamespace)::', '')
+                    if kk == want or kk == want[:-1] + ',false>':
+                        ent = v
+                        break
             if ent is not None:
                 if pmc.get('csrc_fingerprint') != _csrc_fingerprint():
                     # counters cannot be read inside the timed process; a summary collected on OTHER kernel sources is
@@ -521,6 +530,8 @@ def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=
         # graph, so the dominant kernel is bracketed on eager steps run right after the timed region instead
         from contrad_amd.engine import GraphedDStep, GraphedSG2DStep
         ops.PROFILE = None
+        if args.shape_table and rank == 0:
+            ops.SEQUENCE = []                # launch order of the step as it is CAPTURED (tools/rocpd_rows.py)
         try:
             if os.environ.get('CONTRAD_BENCH_FAKE_CAPTURE_HANG') and world > 1:      # test hook: a capture that never returns
                 while True:
@@ -536,7 +547,20 @@ def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=
                 # more so that its ~25 GB of buffers are cached again before the timed window (a cold process paid 0.5 s
                 # of hipMalloc inside the window for it: 96 instead of 67 ms per step over the 16-step window)
                 graphed[0](cfg['d_reg_every'])
+            if ops.SEQUENCE is not None and 'capture' in ops.SEQUENCE:
+                seq = ops.SEQUENCE[len(ops.SEQUENCE) - ops.SEQUENCE[::-1].index('capture'):]
+                per_step = [q for q in seq if q != 'capture']
+                try:
+                    tab = json.load(open(args.shape_table))
+                    sec = tab['sections'].get('plain_step')
+                    if sec is not None and len(per_step) % max(len(sec['sequence']), 1) == 0:
+                        sec['graph_sequence'] = per_step[:len(sec['sequence'])]      # (the capture body runs the step once)
+                        json.dump(tab, open(args.shape_table, 'w'), indent=1)
+                except (OSError, ValueError, KeyError):
+                    pass
+            ops.SEQUENCE = None
         except Exception as e:              # capture not available on this stack: the eager launch sequence is the same work
+            ops.SEQUENCE = None
             sys.stderr.write('bench.py: hipGraph capture failed (%r); timing the eager launch sequence\n' % (e,))
             graphed[0], use_graph = None, False
             launch = 'eager (graph capture failed: %s)' % type(e).__name__

@@ -307,6 +307,8 @@ class GraphedDStep(object):
         self.graph = torch.cuda.CUDAGraph()
         self._scratch = {}           # this graph's own conv scratch (ops.private_workspace)
         mode = _quiesce_before_capture(self.D)
+        if _ops.SEQUENCE is not None:
+            _ops.SEQUENCE.append('capture')          # (bench.py --shape-table: the launch order of the captured step follows)
         with _ops.private_workspace(self._scratch), torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.d_loss, self.aux = self._body()
         G.invalidate_cache()              # (what the capture allocated is filled by the first replay, not now)
@@ -465,6 +467,8 @@ class GraphedSG2DStep(object):
         self.graph = torch.cuda.CUDAGraph()
         self._scratch = {}           # this graph's own conv scratch (ops.private_workspace)
         mode = _quiesce_before_capture(self.D)
+        if _ops.SEQUENCE is not None:
+            _ops.SEQUENCE.append('capture')          # (bench.py --shape-table: the launch order of the captured step follows)
         with _ops.private_workspace(self._scratch), torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.d_loss, self.aux = self._body()
         G.invalidate_cache()
@@ -550,6 +554,8 @@ class GraphedGStep(object):
         self.graph = torch.cuda.CUDAGraph()
         self._scratch = {}           # this graph's own conv scratch (ops.private_workspace)
         mode = _quiesce_before_capture(self.D)
+        if _ops.SEQUENCE is not None:
+            _ops.SEQUENCE.append('capture')          # (bench.py --shape-table: the launch order of the captured step follows)
         with _ops.private_workspace(self._scratch), torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.g_loss = self._body()
         G.invalidate_cache()
@@ -596,6 +602,8 @@ class GraphedSG2GStep(object):
         self.graph = torch.cuda.CUDAGraph()
         self._scratch = {}           # this graph's own conv scratch (ops.private_workspace)
         mode = _quiesce_before_capture(self.D)
+        if _ops.SEQUENCE is not None:
+            _ops.SEQUENCE.append('capture')          # (bench.py --shape-table: the launch order of the captured step follows)
         with _ops.private_workspace(self._scratch), torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.g_loss = self._body()
         G.invalidate_cache()

@@ -69,6 +69,11 @@ def out_size(h, k, stride, pad):
 # (A WGRAD bracket spans the split-K main kernel and its wgrad_reduce_kernel: one C-ABI call launches both.)
 PROFILE = None
 PROFILE_ONLY = None
+# Optional launch log without events (legal inside a stream capture): when set to a list, every conv-engine call appends
+# (kernel_name, shape, workgroups, algorithmic GFLOP, executed share); engine.Graphed*Step appends the marker 'capture'
+# right before it captures, so bench.py --shape-table can record the launch ORDER of the captured step (a replay keeps the
+# order of its capture, which need not be the order of the eager step the event-bracketed table comes from).
+SEQUENCE = None
 
 
 def conv_kernel_name(mode, d):
@@ -87,6 +92,11 @@ def conv_kernel_name(mode, d):
 
 
 def _conv_call(mode, d, name, *args):
+    if SEQUENCE is not None:
+        SEQUENCE.append([conv_kernel_name(mode, d), [d.N, d.H, d.W, d.C, d.K, d.KH, d.KW, d.stride, d.pad],
+                         int(lib().raw('contrad_conv2d_grid_blocks')(ctypes.byref(d), mode, 1)),
+                         round(2.0 * d.N * d.Ho * d.Wo * d.K * d.C * d.KH * d.KW / 1e9, 4),
+                         round(float(lib().raw('contrad_conv2d_executed_fraction')(ctypes.byref(d), mode)), 4)])
     if PROFILE is None:
         lib().call(name, *args)
         return

@@ -69,21 +69,38 @@ def main(db_path, table_path):
     matched_steps = set()
     reasons = {}
     reordered = 0
+    approx = set()
     for sec, d in table['sections'].items():
         seq = d.get('sequence') or []
         keyseq = [(norm(q[0]), q[2]) for q in seq]
         agg = {}
         nmatch = 0
+        # launch orders this section may show: the eager step the table was written from, and (hipGraph replay) the
+        # order of the captured step (bench.py records it during the capture)
+        orders = [seq] + ([d['graph_sequence']] if d.get('graph_sequence') else [])
+        key_orders = [[(norm(q[0]), q[2]) for q in o] for o in orders]
         want = collections.Counter(keyseq)
         slots = collections.defaultdict(list)       # (instance, workgroups) -> positions in the section's sequence, in order
         for pos, key in enumerate(keyseq):
             slots[key].append(pos)
+        shapes_of = collections.defaultdict(set)
+        for q in seq:
+            shapes_of[(norm(q[0]), q[2])].add(tuple(q[1]))
         for si, st in enumerate(steps):
-            # A step belongs to the section when it launches the same MULTISET of (instance, workgroups).  The order may
-            # differ inside a step (the autograd engine is free to order independent nodes; a captured graph replays the
-            # order of ITS capture, not of the eager step the table was written from): the i-th dispatch of a key in the
-            # trace is attributed to the i-th table entry of that key.
-            got = collections.Counter((a[0], a[1]) for a in st)
+            got_seq = [(a[0], a[1]) for a in st]
+            exact = next((oi for oi, ko in enumerate(key_orders) if ko == got_seq), None)
+            if exact is not None:                   # dispatch by dispatch, in a recorded order
+                nmatch += 1
+                matched_steps.add(si)
+                for (k, blocks, us), q in zip(st, orders[exact]):
+                    a = agg.setdefault((norm(q[0]), tuple(q[1]), q[2]), [0, 0.0, q[3], q[4] if len(q) > 4 else 1.0])
+                    a[0] += 1
+                    a[1] += us
+                continue
+            # Same MULTISET of (instance, workgroups) in an order nobody recorded: the i-th dispatch of a key goes to the i-th
+            # table entry of that key -- exact where a key belongs to one shape, approximate ('~' in the table) where
+            # several shapes share instance AND workgroup count (every split-K WGRAD has ~1008 blocks)
+            got = collections.Counter(got_seq)
             if got != want:
                 if si not in matched_steps:
                     diff = sorted(((got - want) + (want - got)).items(), key=lambda kv: -kv[1])[:4]
@@ -92,7 +109,7 @@ def main(db_path, table_path):
                 continue
             nmatch += 1
             matched_steps.add(si)
-            reordered += any((a[0], a[1]) != b for a, b in zip(st, keyseq))
+            reordered += 1
             taken = collections.Counter()
             for (k, blocks, us) in st:
                 q = seq[slots[(k, blocks)][taken[(k, blocks)]]]
@@ -100,6 +117,8 @@ def main(db_path, table_path):
                 a = agg.setdefault((norm(q[0]), tuple(q[1]), q[2]), [0, 0.0, q[3], q[4] if len(q) > 4 else 1.0])
                 a[0] += 1
                 a[1] += us
+                if len(shapes_of[(k, blocks)]) > 1:
+                    approx.add((norm(q[0]), tuple(q[1]), q[2]))
         print('\n== section %s: %d conv-engine launches per step, %d trace step(s) matched ==' % (sec, len(seq), nmatch))
         if not nmatch:
             continue
@@ -116,8 +135,9 @@ def main(db_path, table_path):
             tot_t += us / nmatch
             pk = per_kernel.setdefault(k, [0.0, 0.0, 0, 0.0])
             pk[0] += gf * c / nmatch; pk[1] += us / nmatch; pk[2] += c / nmatch; pk[3] += gf * ex * c / nmatch
-            print('%-30s %-34s %7d %7.1f %8d %10.2f %11.4f %7.1f %6.3f %5.2f %6.1f' % (
-                k, ','.join(map(str, shape)), blocks, c / nmatch, c, avg, gf, tf, tf / 157.3, ex, tf * ex))
+            print('%-30s %-34s %7d %7.1f %8d %10.2f %11.4f %7.1f %6.3f %5.2f %6.1f%s' % (
+                k, ','.join(map(str, shape)), blocks, c / nmatch, c, avg, gf, tf, tf / 157.3, ex, tf * ex,
+                ' ~' if (k, shape, blocks) in approx else ''))
         print('-- per kernel instance (this section, per step):')
         for k, (gf, us, n, xf) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1]):
             print('   %-30s %5.1f launches %9.1f us %10.2f GFLOP -> %6.1f TF/s (%.3f)   issued %10.2f GFLOP -> %6.1f TF/s (%.3f)' % (
@@ -127,7 +147,8 @@ def main(db_path, table_path):
               'GFLOP -> %.1f TF/s (%.3f)' % (sec, tot_f, tot_t, tot_f / tot_t * 1e3, tot_f / tot_t * 1e3 / 157.3,
                                               tot_x, tot_x / tot_t * 1e3, tot_x / tot_t * 1e3 / 157.3))
     if reordered:
-        print('\n(%d matched step(s) launched the section\'s kernels in a different order than the table\'s eager step)' % reordered)
+        print('\n(%d matched step(s) launched their kernels in an order that was not recorded; rows marked ~ share instance and '
+              'workgroup count with another shape, their durations may be swapped among those shapes)' % reordered)
     un = [i for i in range(len(steps)) if i not in matched_steps]
     if un:
         print('\n== %d trace step(s) matched no section: ==' % len(un))
