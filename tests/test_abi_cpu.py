@@ -61,13 +61,15 @@ def test_launch_plans_are_host_logic(built):
         d = _desc(1536, H, C, K, k, s, p)
         for mode in (0, 1, 2):
             # lean loop everywhere.  Padding tap-positions are skipped (path 3): forward and stride-1 data gradient of every
-            # layer (pixel-major tiles on the 4 x 4 maps, border classes on the larger ones; strided data gradients stay
-            # image-major), the weight gradient where at most 0.85 of the tap-positions are valid
+            # layer (pixel-major tiles on the 4 x 4 maps, border classes on the larger ones); of the strided data gradients
+            # the 4x4 stride-2 layer onto the 8 x 8 dx map (0.77 of its tap-positions valid: pixel-major inside the parity
+            # classes, slot-balanced class-major order, round 4) -- the larger maps stay image-major; the weight gradient
+            # where at most 0.85 of the tap-positions are valid
             Ho = (H + 2 * p - k) // s + 1
             if mode == 2:
                 want = 3 if (Ho == 4 or (Ho == 8 and k == 3)) else 2
             else:
-                want = 3 if (mode == 0 or s == 1) else 2
+                want = 3 if (mode == 0 or s == 1 or H == 8) else 2
             assert path(ctypes.byref(d), mode) == want, (H, C, K, mode)
             assert tile(ctypes.byref(d), mode, ctypes.byref(bm), ctypes.byref(bn)) == 0
             want_bn = 64 if (mode == 1 and C == 64) else 128        # dgrad's columns are the input channels
@@ -123,7 +125,13 @@ def test_padding_skipping_tile_plans_without_gpu(built):
         Ho = (H + 2 * p - k) // s + 1
         for mode in (0, 1):
             if mode == 1 and s != 1:
-                assert frac(ctypes.byref(d), mode) == 1.0           # strided data gradient: image-major, nothing skipped
+                if H == 8:      # dx map 8 x 8 from the 4 x 4 gy: per axis 14 of 16 tap-positions valid -> pixel-major, class-major
+                    assert path(ctypes.byref(d), mode) == 3 and abs(frac(ctypes.byref(d), mode) - (14.0 / 16.0) ** 2) < 1e-12
+                    assert tile(ctypes.byref(d), mode, ctypes.byref(bm), ctypes.byref(bn)) == 0
+                    assert blocks(ctypes.byref(d), mode, 1) == -(-N // bm.value) * 16 * 4 * -(-C // bn.value)
+                    seen.add('strided pixel-major')
+                else:
+                    assert frac(ctypes.byref(d), mode) == 1.0       # larger maps: image-major, nothing skipped
                 continue
             ext, inn = (Ho, H) if mode == 0 else (H, Ho)
             runs = _axis_runs(ext, inn, k, s, p, mode)
@@ -143,7 +151,7 @@ def test_padding_skipping_tile_plans_without_gpu(built):
                 assert sum(npix for _, npix in classes) == ext * ext and len(classes) == 9
                 seen.add('border classes')
             assert blocks(ctypes.byref(d), mode, 1) == want, (H, k, mode, want)
-    assert seen == {'pixel-major', 'border classes'}
+    assert seen == {'pixel-major', 'border classes', 'strided pixel-major'}
     # too few images for a tile of the smallest class on every XCD: image-major tiles, everything issued
     d = _desc(192, 8, 256, 256, 3, 1, 1)
     assert path(ctypes.byref(d), 0) == 2 and frac(ctypes.byref(d), 0) == 1.0
