@@ -1762,6 +1762,48 @@ extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int 
   return (long long)tm * tn * splits;
 }
 
+extern "C" int contrad_conv2d_tile_order(const contrad_conv_desc* d, int mode, unsigned char* out, int capacity) {
+  if (check_desc(d) || (mode != MODE_FWD && mode != MODE_DGRAD) || !out || capacity <= 0) return -22;
+  int taps[256];
+  unsigned char full[256];
+  int nt = 0;
+  if (mode == MODE_FWD) {
+    const FwdPlan p = fwd_plan(d);
+    if (p.pixmajor != 1 || !vec_ok(d, MODE_FWD)) return 0;
+    for (int ho = 0; ho < d->Ho; ++ho)
+      for (int wo = 0; wo < d->Wo; ++wo) {
+        int vh = 0, vw = 0;
+        for (int kh = 0; kh < d->KH; ++kh) vh += (unsigned)(ho * d->stride - d->pad + kh) < (unsigned)d->H;
+        for (int kw = 0; kw < d->KW; ++kw) vw += (unsigned)(wo * d->stride - d->pad + kw) < (unsigned)d->W;
+        taps[ho * d->Wo + wo] = vh * vw;
+      }
+    if (!pixel_order_full(taps, d->Ho * d->Wo, cdiv(d->N, p.bm), cdiv(d->K, p.bn), full, 8)) return 0;
+    nt = cdiv(d->N, p.bm) * d->Ho * d->Wo;
+  } else {
+    const FwdPlan p = dgrad_plan(d, true);
+    if (p.pixmajor != 1 || p.splits > 1 || !vec_ok(d, MODE_DGRAD)) return 0;
+    if (d->stride == 1) {
+      for (int h = 0; h < d->H; ++h)
+        for (int w = 0; w < d->W; ++w) {
+          int vh = 0, vw = 0;
+          for (int kh = 0; kh < d->KH; ++kh) vh += (unsigned)(h + d->pad - kh) < (unsigned)d->Ho;
+          for (int kw = 0; kw < d->KW; ++kw) vw += (unsigned)(w + d->pad - kw) < (unsigned)d->Wo;
+          taps[h * d->W + w] = vh * vw;
+        }
+      if (!pixel_order_full(taps, d->H * d->W, cdiv(d->N, p.bm), cdiv(d->C, p.bn), full, 8)) return 0;
+      nt = cdiv(d->N, p.bm) * d->H * d->W;
+    } else {
+      const int npix = dgrad_strided_class0_taps(d, taps);
+      if (!npix || !dgrad_strided_full_ok(d, p.bm, p.bn)) return 0;
+      pixel_order_full(taps, npix, cdiv(d->N, p.bm), cdiv(d->C, p.bn), full, 2);
+      nt = cdiv(d->N, p.bm) * npix;
+    }
+  }
+  if (nt > capacity) return -22;
+  memcpy(out, full, (size_t)nt);
+  return nt;
+}
+
 extern "C" long long contrad_conv2d_wgrad_workspace_bytes(const contrad_conv_desc* d) {
   if (check_desc(d)) return -22;
   if (wgrad_c32_ok(d))

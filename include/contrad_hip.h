@@ -101,6 +101,13 @@ double contrad_conv2d_executed_fraction(const contrad_conv_desc* d, int mode);
  * *_ws entry points use, i.e. split-K allowed).  Profiling aid: lets a rocprofv3 kernel trace, which names only the
  * template instance, be joined to the layer shape a dispatch served (tools/rocpd_rows.py); negative = bad descriptor. */
 long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int mode, int with_workspace);
+/* Pixel-major launches (path 3, mode 0 / 1) with at most 256 M-tiles per table: the order in which the launch walks its
+ * M-tiles, out[i] = image block * pixels + pixel of the i-th M-tile (for the strided data gradient: of every parity class,
+ * the pixel mirrored along the class's odd axes), chosen so that the tiles a CU is dealt -- an XCD's blocks go round-robin
+ * over its 32 CUs -- carry equal work.  Returns the number of entries written, 0 when the launch uses no such table
+ * (image-major tiles, border classes, more than 256 tiles), negative = bad argument.  Host logic only; lets the plan be
+ * tested without a GPU (tests/test_abi_cpu.py). */
+int contrad_conv2d_tile_order(const contrad_conv_desc* d, int mode, unsigned char* out, int capacity);
 int contrad_conv2d_wgrad(const contrad_conv_desc* d, const float* x, const float* gy, float* dwp,
                          float* dbias, float* workspace, long long workspace_bytes, contrad_stream_t stream);
 

@@ -170,3 +170,63 @@ def test_shipped_library_reads_no_environment(built):
         return subprocess.run(['nm', '-D', path], capture_output=True, text=True, check=True).stdout
     assert 'CONTRAD_' not in names(build.LIB) and 'getenv' not in imports(build.LIB)
     assert 'CONTRAD_TILEMODE' in names(build.DEV_LIB) and 'getenv' in imports(build.DEV_LIB)
+
+
+def test_slot_balanced_tile_order_without_gpu(built):
+    """Round 4's block order of the pixel-major launches is host logic ("How blocks reach CUs"): the
+    table must be a permutation of the launch's M-tiles, and under the dispatch model it was derived from -- an XCD owns a
+    contiguous run of blocks (xcd_remap), dealt round-robin over its 32 CUs -- every CU of the headline launches gets the same
+    work to within one tap-unit (3x3 on a 4x4 map at 1 536 images: 18 or 19 of them; heaviest-first gave 24 vs 16)."""
+    order = built.raw('contrad_conv2d_tile_order')
+    tile = built.raw('contrad_conv2d_tile')
+    bm, bn = ctypes.c_int(0), ctypes.c_int(0)
+
+    def taps_fwd(H, k, s, p, Ho):
+        ax = [sum(0 <= o * s - p + t < H for t in range(k)) for o in range(Ho)]
+        return [a * b for a in ax for b in ax]
+
+    def taps_dgrad(H, k, p, Ho):            # stride 1
+        ax = [sum(0 <= h + p - t < Ho for t in range(k)) for h in range(H)]
+        return [a * b for a in ax for b in ax]
+
+    def cu_loads(table, taps, npix, tiles_n, runs, mirror=None):
+        nb = len(table) * tiles_n
+        q, r = divmod(nb, runs)
+        loads = []
+        for x in range(runs):
+            b0 = x * (q + 1) if x < r else r * (q + 1) + (x - r) * q
+            b1 = b0 + q + (1 if x < r else 0)
+            cu = [0] * 32
+            for b in range(b0, b1):
+                cu[(b - b0) % 32] += taps[table[b // tiles_n] % npix]
+            loads += cu
+        return loads
+
+    buf = (ctypes.c_ubyte * 256)()
+    N = 1536
+    # 3x3 pad 1, 512 -> 512 on a 4x4 map: forward and data gradient
+    for mode in (0, 1):
+        d = _desc(N, 4, 512, 512, 3, 1, 1)
+        n = order(ctypes.byref(d), mode, buf, 256)
+        assert tile(ctypes.byref(d), mode, ctypes.byref(bm), ctypes.byref(bn)) == 0
+        assert n == -(-N // bm.value) * 16 and sorted(buf[:n]) == list(range(n))
+        taps = taps_fwd(4, 3, 1, 1, 4) if mode == 0 else taps_dgrad(4, 3, 1, 4)
+        loads = cu_loads(list(buf[:n]), taps, 16, 512 // bn.value, 8)
+        assert max(loads) - min(loads) <= 1 and max(loads) == 19, (mode, min(loads), max(loads))
+    # 4x4 stride 2 pad 1, 256 -> 512, 8x8 -> 4x4: forward (one table) ...
+    d = _desc(N, 8, 256, 512, 4, 2, 1)
+    n = order(ctypes.byref(d), 0, buf, 256)
+    assert tile(ctypes.byref(d), 0, ctypes.byref(bm), ctypes.byref(bn)) == 0
+    assert n == -(-N // bm.value) * 16 and sorted(buf[:n]) == list(range(n))
+    loads = cu_loads(list(buf[:n]), taps_fwd(8, 4, 2, 1, 4), 16, 512 // bn.value, 8)
+    assert max(loads) <= 1.08 * sum(loads) / len(loads)
+    # ... and its data gradient: class-major launch, one table for the four parity classes (each = two XCD runs)
+    n = order(ctypes.byref(d), 1, buf, 256)
+    assert tile(ctypes.byref(d), 1, ctypes.byref(bm), ctypes.byref(bn)) == 0
+    assert n == -(-N // bm.value) * 16 and sorted(buf[:n]) == list(range(n))
+    ax = [1, 2, 2, 2]                        # class (0,0): valid taps per dx row / column of the class (hq = 0 loses one)
+    loads = cu_loads(list(buf[:n]), [a * b for a in ax for b in ax], 16, 256 // bn.value, 2)
+    assert max(loads) <= 1.10 * sum(loads) / len(loads)
+    # launches without such a table
+    assert order(ctypes.byref(_desc(N, 16, 128, 128, 3, 1, 1)), 0, buf, 256) == 0     # border classes
+    assert order(ctypes.byref(_desc(N, 32, 64, 128, 4, 2, 1)), 1, buf, 256) == 0      # strided, image-major
