@@ -323,7 +323,7 @@ def _csrc_fingerprint():
     return h.hexdigest()[:16]
 
 
-def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=None):
+def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=None, graph=None, eager_line=None):
     from contrad_amd import config, ops
     from contrad_amd.augment import get_augment
     from contrad_amd.engine import (GradAllReducer, OverlappedGradReducer, d_step, d_step_stylegan2,
@@ -372,7 +372,8 @@ def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=
     counter = [cfg['d_reg_every'] - 1 if cfg['d_reg_every'] > 1 else 0]
     graphed = [None]
     # hipGraph replay also with a process group: the collectives are captured with the step (engine.GraphedDStep)
-    use_graph = args.graph != 'off'
+    use_graph = (graph or args.graph) != 'off'
+    graph_failed = False
     if name == 'c10_b512':
         def one_step():
             if graphed[0] is not None:
@@ -510,19 +511,18 @@ def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=
             out["config"]["r1_steps_in_window"] = steps // cfg['d_reg_every']
         return out
 
-    # With more than one rank the EAGER launch sequence is timed FIRST and its result kept where main()'s watchdog can
-    # print it: a hipGraph with captured RCCL collectives has never been built on several ranks at once on this stack,
-    # and a capture that HANGS -- unlike one that raises -- cannot be caught.  The capture then runs under that per-rank
-    # watchdog (--graph-timeout); if it completes, the replayed steps are timed the same way and are the reported figure,
-    # with the eager one beside it (config.eager_ms_per_step).
+    # With more than one rank main() runs every workload EAGERLY first (graph='off') and keeps those lines; this call
+    # (graph on) only adds the replayed figure: a hipGraph with captured RCCL collectives has never been built on several
+    # ranks at once on this stack, a capture that HANGS cannot be caught, and one that RAISES leaves the process in a state
+    # nothing else should be measured in (measured with gloo: the stream stays "capture invalidated", the device RNG stays
+    # in capture mode).  From arm() to disarm() a per-rank watchdog (--graph-timeout) reports instead of waiting.
     eager = None
     if use_graph and world > 1:
-        dt_e, finite_e = timed_region()
-        eager = (dt_e, finite_e, ops.PROFILE)
-        ops.PROFILE = []
-        if rank == 0:
-            keep(name, make_out(dt_e, finite_e, eager[2], steps, 'eager (graph capture timed out)', dom_name, wagg, wsteps))
-        arm(name)                            # from here until disarm(): a rank that stops making progress is reported, not waited for
+        if rank == 0 and eager_line is not None:
+            line = json.loads(json.dumps(eager_line))
+            line["config"]["launch"] = 'eager (graph capture timed out)'
+            keep(name, line)
+        arm(name)
 
     launch = 'hipGraph replay' if use_graph else 'eager'
     if use_graph:
@@ -565,21 +565,35 @@ def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=
             graphed[0], use_graph = None, False
             launch = 'eager (graph capture failed: %s)' % type(e).__name__
             ops.PROFILE = []
-    if eager is not None and not use_graph:
-        dt, finite, prof = eager            # the eager steps were timed above; nothing to repeat
-        nprof_steps = steps
-        ops.PROFILE = None
-    else:
-        dt, finite = timed_region()
-        if use_graph:                       # same kernels, same shapes, eager launches with the dominant kernel bracketed
-            graphed[0] = None
-            ops.PROFILE = []
-            for _ in range(max(3, steps // 4)):
-                one_step()
-            torch.cuda.synchronize()
-        prof, ops.PROFILE = ops.PROFILE, None
-        nprof_steps = max(3, steps // 4) if use_graph else steps
-    if eager is not None:
+            graph_failed = True
+            # torch.cuda.graph's side stream is still the current stream (its __exit__ raised before restoring it), and the
+            # runtime holds a pending error that the next synchronising call re-raises
+            torch.cuda.set_stream(torch.cuda.default_stream(dev))
+            for _ in range(4):
+                try:
+                    torch.cuda.synchronize()
+                    break
+                except Exception:
+                    pass
+    if graph_failed and world > 1:
+        # the eager line of this workload exists already (main(), phase 1); nothing more is measured in this process
+        disarm(name)
+        ops.PROFILE, ops.PROFILE_ONLY = None, None
+        out = None
+        if rank == 0 and eager_line is not None:
+            out = json.loads(json.dumps(eager_line))
+            out["config"]["launch"] = launch
+        return out, False
+    dt, finite = timed_region()
+    if use_graph:                           # same kernels, same shapes, eager launches with the dominant kernel bracketed
+        graphed[0] = None
+        ops.PROFILE = []
+        for _ in range(max(3, steps // 4)):
+            one_step()
+        torch.cuda.synchronize()
+    prof, ops.PROFILE = ops.PROFILE, None
+    nprof_steps = max(3, steps // 4) if use_graph else steps
+    if use_graph and world > 1:
         disarm(name)
     ops.PROFILE_ONLY = None
     peak_box[0] = torch.cuda.max_memory_allocated(dev)
@@ -622,8 +636,8 @@ def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=
     out = None
     if rank == 0:
         out = make_out(dt, finite, prof, nprof_steps, launch, dom_name, wagg, wsteps)
-        if eager is not None:
-            out["config"]["eager_ms_per_step"] = round(eager[0] / steps * 1e3, 3)
+        if eager_line is not None:
+            out["config"]["eager_ms_per_step"] = eager_line["ms_per_step"]
         if g_step is not None:
             out["g_step"] = g_step
     # release this workload's memory before the next one
@@ -631,7 +645,7 @@ def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=
     ops._ws_cache.clear()
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats(dev)
-    return out
+    return out, True
 
 
 def main():
@@ -709,22 +723,44 @@ def main():
             out["other_configs"] = rest
         print(json.dumps(out), flush=True)
 
-    # Fallback order with more than one rank: (1) the eager steps of a workload are timed and kept,
-    # (2) graph capture + replay run under this watchdog, (3) if they do not finish within --graph-timeout every rank
-    # leaves through os._exit(0) -- a rank blocked inside a collective cannot be unwound -- and rank 0 first prints the
-    # line with what it has: finished workloads as they are, the current one with its eager result.
+    # Order with more than one rank: (1) EVERY workload is run and timed with eager launches and its
+    # line kept; (2) then, workload by workload, the step is captured with its collectives and the replay is timed under a
+    # watchdog -- a replay that completes replaces the eager line (the eager figure stays beside it); (3) a capture that
+    # raises ends phase 2 (the process state is not trusted any more), one that hangs past --graph-timeout makes every rank
+    # leave through os._exit(0) after rank 0 has printed the line: in both cases everything not replayed keeps its eager line.
     wd = _GraphWatchdog(rank, args.graph_timeout, results, emit)
-    for i, name in enumerate(names):
-        if i == 0:
-            results[name] = run_config(name, args, world, rank, dev, multi, wd.keep, wd.arm, wd.disarm)
-            continue
+    two_phase = world > 1 and args.graph != 'off'
+
+    def guarded(name, first, **kw):
+        if first:
+            return run_config(name, args, world, rank, dev, multi, wd.keep, wd.arm, wd.disarm, **kw)
         try:                                     # a side workload must never take the headline line down
-            results[name] = run_config(name, args, world, rank, dev, multi, wd.keep, wd.arm, wd.disarm)
+            return run_config(name, args, world, rank, dev, multi, wd.keep, wd.arm, wd.disarm, **kw)
         except Exception as e:
-            results[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}, True
+
+    for i, name in enumerate(names):
+        results[name], _ok = guarded(name, i == 0, graph='off' if two_phase else None)
+    if two_phase:
+        for i, name in enumerate(names):
+            if rank == 0 and "error" in (results[name] or {}):
+                continue
+            try:
+                out, ok = run_config(name, args, world, rank, dev, multi, wd.keep, wd.arm, wd.disarm, graph='on',
+                                     eager_line=results[name])
+            except Exception as e:               # (anything else that goes wrong in the graph phase: keep the eager lines)
+                sys.stderr.write('bench.py: graph phase of %s failed (%r); keeping the eager lines\n' % (name, e))
+                break
+            if rank == 0 and out is not None:
+                results[name] = out
+            if not ok:
+                break
     if multi:
-        dist.barrier()
-        dist.destroy_process_group()             # before the JSON line: nothing RCCL prints can follow or split it
+        try:
+            dist.barrier()
+            dist.destroy_process_group()         # before the JSON line: nothing RCCL prints can follow or split it
+        except Exception as e:                   # (after a failed capture the process group may be unusable: still print)
+            sys.stderr.write('bench.py: process-group shutdown failed (%r)\n' % (e,))
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             for name in names:

@@ -13,10 +13,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra, env_extra=None, timeout=600):
+def _run(extra, env_extra=None, timeout=600, config='c10_b512'):
     env = dict(os.environ)
     env.update(env_extra or {})
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dev-backend', 'gloo', '--config', 'c10_b512',
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dev-backend', 'gloo', '--config', config,
            '--steps', '2', '--warmup', '1', '--no-cpu-baseline'] + extra
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
@@ -44,3 +44,18 @@ def test_graph_capture_that_never_returns_reports_the_eager_result():
     assert out['n_gpus'] == 2 and out['config']['launch'] == 'eager (graph capture timed out)'
     assert out['config']['losses_finite'] and out['value'] > 0 and out['steps'] == 2
     assert 'did not get through graph capture' in r.stderr
+
+
+def test_graph_capture_that_raises_keeps_every_workloads_eager_line():
+    """A gloo collective cannot be captured: the capture of the FIRST workload raises and leaves the process in a state in
+    which nothing else can be measured (stream "capture invalidated", device RNG in capture mode).  All three workloads
+    were timed eagerly before any capture was attempted, so the line still carries every one of them."""
+    r, lines = _run(['--graph', 'on', '--graph-timeout', '120'], config='all', timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['config']['launch'].startswith('eager (graph capture failed') and out['value'] > 0
+    assert set(out['other_configs']) == {'sg2_32', 'sg2_512'}
+    for name, w in out['other_configs'].items():
+        assert 'error' not in w and w['value'] > 0 and w['config']['launch'] == 'eager' and w['config']['losses_finite'], name
+    assert out['other_configs']['sg2_512']['scaling'] == 'weak' and out['other_configs']['sg2_512']['config']['global_batch'] == 32
