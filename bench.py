@@ -4,7 +4,9 @@
     python bench.py [--gpus N --steps K --warmup W] [--config c10_b512|sg2_32|sg2_512|all]
 
 ``--gpus N`` (N > 1) spawns one process per GPU itself (re-exec under ``torch.distributed.run`` on 127.0.0.1, as the
-reference's ``mp.spawn`` does, train_gan.py:331) unless it already runs inside such a launch (WORLD_SIZE set).
+reference's ``mp.spawn`` does, train_gan.py:331) unless it already runs inside such a launch (WORLD_SIZE set).  With N > 1
+every workload is first timed with eager launches; capture + replay of the step with its RCCL collectives comes second,
+under a watchdog: the line always carries a number for every workload.
 
 Workloads (BASELINE.json configs):
   c10_b512  SNDCGAN + ContraD, CIFAR-10 32x32, GLOBAL batch 512, simclr aug (configs[1]; [2] = the same over N GPUs)
@@ -666,8 +668,8 @@ def main():
     ap.add_argument('--dev-local-batch', type=int, default=0,
                     help='dev: single-GPU run at this batch (what one rank of an N-GPU job sees); not the headline config')
     ap.add_argument('--graph-timeout', type=float, default=240.0,
-                    help='N > 1: seconds a workload may spend between the end of its eager timed region and the end of its '
-                         'graph-replay timed region; past that every rank stops and rank 0 prints the line with the eager result')
+                    help='N > 1: seconds a workload may spend on capturing its step and timing the replay (every workload has '
+                         'been timed eagerly before); past that every rank stops and rank 0 prints the line with the eager results')
     ap.add_argument('--dev-backend', default='nccl', choices=['nccl', 'gloo'],
                     help="dev: process-group backend.  'gloo' lets several ranks share ONE GPU (RCCL refuses that), so the "
                          "self-launch, the barriers, the MAX over ranks and the fallback order can be exercised on a 1-GPU box")
