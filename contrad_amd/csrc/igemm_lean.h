@@ -594,6 +594,8 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
     const int c = n0 + wn * WN + j * 32 + l31;
     colpart[j] = (c < Ncol) ? (unsigned)c * 4u : COL_OOB;
   }
+  // epilogue rows whose second operand is in flight together (see below); the balanced 128 x 128 instance has room for 4
+  constexpr int EPI_G = (BAL && BM * BN > 128 * 64) ? 4 : 8;
   const bool rowtab = (MODE == MODE_DGRAD) || (MODE == MODE_FWD && pl_nwin > 0);   // rows scattered over the output map
   if (rowtab) {
     // row -> byte offset of the output pixel (dx for DGRAD, y for a FWD border class) relative to the tile's first image
@@ -639,27 +641,45 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
       const int c = n0 + wn * WN + jj * 32 + l31;
       bj[jj] = (MODE == MODE_FWD && p.bias && c < Ncol) ? p.bias[c] : 0.f;
     }
+    // The second operand (act_ref / addend) is fetched for EPI_G rows at a time -- EPI_G x TN loads in flight -- BEFORE that
+    // group's first store.  (Round 4: written as "load, use, store" per element the compiler kept that order -- it cannot
+    // move a buffer load across a buffer store -- and waited vmcnt(0) 64 times per thread, i.e. paid the full memory latency
+    // of a load AND of the preceding store per element: a block's epilogue lasted as long as ~30 K-tiles.  A whole 32-row
+    // group in flight spills the 128 x 128 instances: 8 rows keep them inside 128 VGPRs.)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned off = rowoff[wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
+      for (int r0 = 0; r0 < 16; r0 += EPI_G) {
+        unsigned offs[EPI_G];
 #pragma unroll
-        for (int jj = 0; jj < TN; ++jj) {
-          const unsigned vo = off + colpart[jj];
-          float v = acc[i][jj][r];
-          if constexpr (MODE == MODE_DGRAD) {
-            if (ref) {   // uniform
-              const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)vo, 0, 0));
-              v *= (a > 0.f) ? g1 : g0;
+        for (int q = 0; q < EPI_G; ++q) {
+          const int r = r0 + q;
+          offs[q] = rowoff[wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
+        }
+        float rv[EPI_G][TN];
+        if (ref) {   // uniform
+#pragma unroll
+          for (int q = 0; q < EPI_G; ++q)
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj)
+              rv[q][jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)(offs[q] + colpart[jj]), 0, 0));
+        }
+#pragma unroll
+        for (int q = 0; q < EPI_G; ++q) {
+#pragma unroll
+          for (int jj = 0; jj < TN; ++jj) {
+            const unsigned vo = offs[q] + colpart[jj];
+            float v = acc[i][jj][r0 + q];
+            if constexpr (MODE == MODE_DGRAD) {
+              if (ref) v *= (rv[q][jj] > 0.f) ? g1 : g0;
+            } else {
+              v += bj[jj];
+              v = (v > 0.f) ? v : v * p.slope;
+              v *= p.gain;
+              if (ref) v += rv[q][jj];
             }
-          } else {
-            v += bj[jj];
-            v = (v > 0.f) ? v : v * p.slope;
-            v *= p.gain;
-            if (ref) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)vo, 0, 0));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)vo, 0, 0);
           }
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)vo, 0, 0);
         }
       }
   } else {
@@ -684,23 +704,54 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
       const int c = n0 + wn * WN + j * 32 + l31;
       bj[j] = (MODE == MODE_FWD && !slab && p.bias && c < Ncol) ? p.bias[c] : 0.f;
     }
+    if constexpr (MODE == MODE_FWD) {
+      // (residual addend fetched EPI_F rows at a time before that group's stores: see the row-table branch above; the
+      // 128 x 128 instance has registers for 4 rows)
+      constexpr int EPI_F = (BM * BN > 128 * 64) ? 4 : EPI_G;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned rowpart = (unsigned)((wave_row + i * 32 + (r & 3) + 8 * (r >> 2)) * pitch) * 4u;   // wave-uniform
+        for (int r0 = 0; r0 < 16; r0 += EPI_F) {
+          unsigned rowpart[EPI_F];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          float v = acc[i][j][r];
-          if (MODE == MODE_FWD && !slab) {
-            v += bj[j];
-            v *= (v > 0.f) ? g1 : g0;
-            if (has_add)
-              v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, (int)(lanepart[j] + rowpart), 0, 0));
+          for (int q = 0; q < EPI_F; ++q) {
+            const int r = r0 + q;
+            rowpart[q] = (unsigned)((wave_row + i * 32 + (r & 3) + 8 * (r >> 2)) * pitch) * 4u;   // wave-uniform
           }
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)(lanepart[j] + rowpart), 0, 0);
+          float rv[EPI_F][TN];
+          if (has_add) {   // uniform
+#pragma unroll
+            for (int q = 0; q < EPI_F; ++q)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                rv[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, (int)(lanepart[j] + rowpart[q]), 0, 0));
+          }
+#pragma unroll
+          for (int q = 0; q < EPI_F; ++q)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              float v = acc[i][j][r0 + q];
+              if (!slab) {
+                v += bj[j];
+                v *= (v > 0.f) ? g1 : g0;
+                if (has_add) v += rv[q][j];
+              }
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)(lanepart[j] + rowpart[q]), 0, 0);
+            }
         }
-      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned rowpart = (unsigned)((wave_row + i * 32 + (r & 3) + 8 * (r >> 2)) * pitch) * 4u;   // wave-uniform
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float v = acc[i][j][r];   // (a named copy: __builtin_bit_cast applied to the vector element directly read element 0 for every r -- hipcc 7.2)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)(lanepart[j] + rowpart), 0, 0);
+          }
+        }
+    }
     if constexpr (MODE == MODE_WGRAD) {
       if (do_bias) {
         float* red = smem;   // [B_RPP][BN]; the main-loop buffers are free after the last barrier
