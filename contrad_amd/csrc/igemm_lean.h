@@ -29,6 +29,7 @@
 constexpr unsigned LEAN_OOB = 0x80000000u;       // voffset of an element that must read as zero: out of range whether or
                                                  // not the hardware adds soffset (< 2^31) before the range check
 constexpr unsigned LEAN_RANGE = 0x80000000u;     // num_records of every descriptor (offsets are block-relative)
+constexpr unsigned WB_TOP = 2u, WB_BOT = 4u, WB_LEFT = 8u, WB_RIGHT = 16u;   // WGRAD border flags (inv / edge / wskip)
 
 __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   // (the builtin returns a GCC vector_size(16) type; bit_cast it, an implicit conversion to an ext_vector splats .x)
@@ -332,12 +333,12 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
       const int kh = tap0 / d.KW, kw = tap0 - kh * d.KW;
       const int chh = kh - d.pad, cww = kw - d.pad;
       const int hb = (d.Ho - 1) * d.stride, wb = (d.Wo - 1) * d.stride;
-      wskip = ((unsigned)chh < (unsigned)d.H ? 0u : 1u) | ((unsigned)(hb + chh) < (unsigned)d.H ? 0u : 2u) |
-              ((unsigned)cww < (unsigned)d.W ? 0u : 4u) | ((unsigned)(wb + cww) < (unsigned)d.W ? 0u : 8u);
+      wskip = ((unsigned)chh < (unsigned)d.H ? 0u : WB_TOP) | ((unsigned)(hb + chh) < (unsigned)d.H ? 0u : WB_BOT) |
+              ((unsigned)cww < (unsigned)d.W ? 0u : WB_LEFT) | ((unsigned)(wb + cww) < (unsigned)d.W ? 0u : WB_RIGHT);
       if (p.bias_ws != nullptr && tile_m == 0) wskip = 0;
       int hh = u_h, ww = u_w, cnt = 0, first = -1;
       for (int q = 0; q < T; ++q) {            // scalar: <= a few hundred patches per split
-        const unsigned e = (hh == 0 ? 1u : 0u) | (hh == d.Ho - 1 ? 2u : 0u) | (ww == 0 ? 4u : 0u) | (ww == d.Wo - 1 ? 8u : 0u);
+        const unsigned e = (hh == 0 ? WB_TOP : 0u) | (hh == d.Ho - 1 ? WB_BOT : 0u) | (ww == 0 ? WB_LEFT : 0u) | (ww == d.Wo - 1 ? WB_RIGHT : 0u);
         if (!(wskip & e)) { ++cnt; if (first < 0) first = q; }
         if (++ww == d.Wo) { ww = 0; if (++hh == d.Ho) hh = 0; }
       }
@@ -359,8 +360,8 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
       const int dw = r % gw, dh = (r / gw) % gh, dn = r / (gw * gh);
       const int chh = dh * d.stride - d.pad + kh, cww = dw * d.stride - d.pad + kw;   // input coords at patch origin 0
       const int hb = (d.Ho - gh) * d.stride, wb = (d.Wo - gw) * d.stride;
-      inv[i] = ((unsigned)chh < (unsigned)d.H ? 0u : 1u) | ((unsigned)(hb + chh) < (unsigned)d.H ? 0u : 2u) |
-               ((unsigned)cww < (unsigned)d.W ? 0u : 4u) | ((unsigned)(wb + cww) < (unsigned)d.W ? 0u : 8u);
+      inv[i] = ((unsigned)chh < (unsigned)d.H ? 0u : WB_TOP) | ((unsigned)(hb + chh) < (unsigned)d.H ? 0u : WB_BOT) |
+               ((unsigned)cww < (unsigned)d.W ? 0u : WB_LEFT) | ((unsigned)(wb + cww) < (unsigned)d.W ? 0u : WB_RIGHT);
       va[i] = colok ? (unsigned)((((dn * d.H + dh * d.stride + kh) * d.W + dw * d.stride + kw) * d.ldx + c) * 4)
                     : LEAN_OOB;     // a column past Kg never validates
     }
@@ -376,6 +377,13 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
   float4 ra[PA], rb[PB];
   unsigned soffA = 0, soffB = 0;
   unsigned edge = 0;   // WGRAD: which borders of the output grid the next patch touches (bits as in inv)
+  // ... and the same word for the walk's current position.  The four flags are 2 / 4 / 8 / 16, not 1 / 2 / 4 / 8: the
+  // compiler turns "cond ? 1 : 0" of a scalar compare into a VECTOR select (v_cndmask + v_or per K-tile in every wave),
+  // any other constant stays an s_cselect_b32
+  auto wgrad_pos_edge = [&]() -> unsigned {
+    return (u_h == 0 ? WB_TOP : 0u) | (u_h == d.Ho - gh ? WB_BOT : 0u) | (u_w == 0 ? WB_LEFT : 0u) | (u_w == d.Wo - gw ? WB_RIGHT : 0u);
+  };
+  unsigned pos_edge = (MODE == MODE_WGRAD) ? wgrad_pos_edge() : 0u;
   int t_next = 0;
   __amdgpu_buffer_rsrc_t rsA = lean_rsrc(baseA, false), rsB = lean_rsrc(baseB, false);
 
@@ -395,7 +403,7 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
       soffA = (unsigned)(((((u_n - n_begin) * d.H + u_h * d.stride) * d.W + u_w * d.stride) * d.ldx) * 4);
       soffB = pl_pixmajor ? (unsigned)((((u_n - n_begin) * d.Ho + u_h) * d.Wo + u_w) * d.ldy * 4)
                          : (unsigned)(t_next * BK * d.ldy * 4);
-      edge = (u_h == 0 ? 1u : 0u) | (u_h == d.Ho - gh ? 2u : 0u) | (u_w == 0 ? 4u : 0u) | (u_w == d.Wo - gw ? 8u : 0u);
+      edge = pos_edge;   // (of the patch at (u_h, u_w): kept up to date by the walk, end_tile)
     }
   };
   auto end_tile = [&]() {   // advance the walk to the tile after t_next
@@ -415,12 +423,11 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
         if (u_b == ntw) { u_b = 0; ++u_a; if (u_a == nth) { u_a = 0; u_tap = 0; u_c0 += BK; } }
       } while (!((tapmask >> u_tap) & 1u));
     } else {
-      unsigned e;
       do {   // (pixel-major: on to the next K-tile whose pixel is not padding for this tile's tap)
         u_w += gw;
         if (u_w == d.Wo) { u_w = 0; u_h += gh; if (u_h == d.Ho) { u_h = 0; u_n += gn; } }
-        e = (u_h == 0 ? 1u : 0u) | (u_h == d.Ho - gh ? 2u : 0u) | (u_w == 0 ? 4u : 0u) | (u_w == d.Wo - gw ? 8u : 0u);
-      } while (wskip & e);
+        pos_edge = wgrad_pos_edge();
+      } while (wskip & pos_edge);
     }
   };
   auto load_a_piece = [&](int i) {
@@ -512,8 +519,15 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
   constexpr int A_LD0 = 0, B_LD0 = PA, A_ST0 = KS - PA - PB - IGEMM_ST_SHIFT, B_ST0 = KS - PB - IGEMM_ST_SHIFT;
   static_assert(A_ST0 >= A_LD0 + PA - 1 && B_ST0 >= B_LD0 + PB - 1 && A_ST0 >= 0,
                 "a piece must be stored after its own load was issued");
-  for (int t = 0; t < T; ++t) {
-    const int cur = (t & 1) * BUF, nxt = BUF - cur;
+  // One K-tile out of LDS buffer PAR (compile-time): the loop below is unrolled by two so that every LDS address of the
+  // loop is "per-thread base register + immediate" -- selecting the buffer at run time cost 3 SALU + 6 v_add per K-tile in
+  // every wave (round 4: each VALU instruction between MFMAs takes matrix-pipe time, §3).
+  // (The 128 x 128 FWD instance and the balanced 128 x 128 DGRAD spill > 80 registers when unrolled: they keep the run-time
+  // buffer select.)
+  constexpr bool UNROLL2 = !(BM * BN > 128 * 64 && (MODE == MODE_FWD || BAL));
+  auto k_tile = [&](auto par, const int t) {
+    const int cur = (int)par * BUF, nxt = BUF - cur;   // (par: std::integral_constant when unrolled -> folds to immediates)
+    (void)t;
     float fa[2][TM][4], fb[2][TN][4];
 #if defined(LEAN_ABLATE_FRAGS)
 #pragma unroll
@@ -579,6 +593,15 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
 #if !defined(LEAN_ABLATE_BARRIER)
     __syncthreads();
 #endif
+  };
+  if constexpr (UNROLL2) {
+    for (int t = 0; t < T; t += 2) {
+      k_tile(std::integral_constant<int, 0>{}, t);
+      if (t + 1 >= T) break;
+      k_tile(std::integral_constant<int, 1>{}, t + 1);
+    }
+  } else {
+    for (int t = 0; t < T; ++t) k_tile(t & 1, t);
   }
 
   // ---------------- epilogue ----------------
