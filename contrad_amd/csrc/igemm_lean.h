@@ -384,6 +384,20 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
     return (u_h == 0 ? WB_TOP : 0u) | (u_h == d.Ho - gh ? WB_BOT : 0u) | (u_w == 0 ? WB_LEFT : 0u) | (u_w == d.Wo - gw ? WB_RIGHT : 0u);
   };
   unsigned pos_edge = (MODE == MODE_WGRAD) ? wgrad_pos_edge() : 0u;
+  // WGRAD: byte offsets of the walk position in x and gy, stepped with the walk (additions; as closed forms they were four
+  // s_mul and a pixel-major branch per K-tile): one patch to the right / down a patch row (from past the last column) /
+  // on to the next image group (from past the last row); gy positions are consecutive except across image groups of the
+  // pixel-major walk (one pixel of 16 images -> the next pixel; after the last pixel 15 images further)
+  unsigned pos_offA = 0, pos_offB = 0, wk_aw = 0, wk_ah = 0, wk_an = 0, wk_b = 0, wk_bn = 0;
+  if constexpr (MODE == MODE_WGRAD) {
+    pos_offA = (unsigned)(((((u_n - n_begin) * d.H + u_h * d.stride) * d.W + u_w * d.stride) * d.ldx) * 4);
+    pos_offB = pl_pixmajor ? (unsigned)((((u_n - n_begin) * d.Ho + u_h) * d.Wo + u_w) * d.ldy * 4) : 0u;
+    wk_aw = (unsigned)(gw * d.stride * d.ldx * 4);
+    wk_ah = (unsigned)((gh * d.stride * d.W - d.Wo * d.stride) * d.ldx * 4);
+    wk_an = (unsigned)((gn * d.H - d.Ho * d.stride) * d.W * d.ldx * 4);
+    wk_b = (unsigned)((pl_pixmajor ? 1 : BK) * d.ldy * 4);
+    wk_bn = pl_pixmajor ? (unsigned)((gn - 1) * d.Ho * d.Wo * d.ldy * 4) : 0u;
+  }
   int t_next = 0;
   __amdgpu_buffer_rsrc_t rsA = lean_rsrc(baseA, false), rsB = lean_rsrc(baseB, false);
 
@@ -400,10 +414,9 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
       const int tapflat = (kh0 + d.stride * u_a) * d.KW + (kw0 + d.stride * u_b);
       soffB = (unsigned)((tapflat * d.C * d.ldw + u_c0) * 4);
     } else {
-      soffA = (unsigned)(((((u_n - n_begin) * d.H + u_h * d.stride) * d.W + u_w * d.stride) * d.ldx) * 4);
-      soffB = pl_pixmajor ? (unsigned)((((u_n - n_begin) * d.Ho + u_h) * d.Wo + u_w) * d.ldy * 4)
-                         : (unsigned)(t_next * BK * d.ldy * 4);
-      edge = pos_edge;   // (of the patch at (u_h, u_w): kept up to date by the walk, end_tile)
+      soffA = pos_offA;   // (offsets and border word of the patch at (u_n, u_h, u_w): kept up to date by the walk, end_tile)
+      soffB = pos_offB;
+      edge = pos_edge;
     }
   };
   auto end_tile = [&]() {   // advance the walk to the tile after t_next
@@ -424,8 +437,11 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
       } while (!((tapmask >> u_tap) & 1u));
     } else {
       do {   // (pixel-major: on to the next K-tile whose pixel is not padding for this tile's tap)
-        u_w += gw;
-        if (u_w == d.Wo) { u_w = 0; u_h += gh; if (u_h == d.Ho) { u_h = 0; u_n += gn; } }
+        u_w += gw; pos_offA += wk_aw; pos_offB += wk_b;
+        if (u_w == d.Wo) {
+          u_w = 0; u_h += gh; pos_offA += wk_ah;
+          if (u_h == d.Ho) { u_h = 0; u_n += gn; pos_offA += wk_an; pos_offB += wk_bn; }
+        }
         pos_edge = wgrad_pos_edge();
       } while (wskip & pos_edge);
     }
@@ -525,7 +541,7 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
   // (The 128 x 128 FWD instance and the balanced 128 x 128 DGRAD spill > 80 registers when unrolled: they keep the run-time
   // buffer select.)
   constexpr bool UNROLL2 = !(BM * BN > 128 * 64 && (MODE == MODE_FWD || BAL));
-  auto k_tile = [&](auto par, const int t) {
+  auto k_tile = [&](auto par, auto with_mfma, const int t) {
     const int cur = (int)par * BUF, nxt = BUF - cur;   // (par: std::integral_constant when unrolled -> folds to immediates)
     (void)t;
     float fa[2][TM][4], fb[2][TN][4];
@@ -577,7 +593,7 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
       __builtin_amdgcn_sched_barrier(0);
       // ragged last M-tile (WGRAD with Kg = 288 = 2.25 x 128: the 32-channel 3x3 layers): a wave whose rows all lie
       // past M holds zero fills only -- its MFMAs are skipped, the matrix pipe goes to the other blocks' waves on this SIMD
-      if (!RAGGED_SKIP || wave_on) {
+      if constexpr (decltype(with_mfma)::value) {   // (a wave of rows past M: selected once per block, below)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -594,14 +610,23 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
     __syncthreads();
 #endif
   };
-  if constexpr (UNROLL2) {
-    for (int t = 0; t < T; t += 2) {
-      k_tile(std::integral_constant<int, 0>{}, t);
-      if (t + 1 >= T) break;
-      k_tile(std::integral_constant<int, 1>{}, t + 1);
+  auto k_loop = [&](auto with_mfma) {
+    if constexpr (UNROLL2) {
+      for (int t = 0; t < T; t += 2) {
+        k_tile(std::integral_constant<int, 0>{}, with_mfma, t);
+        if (t + 1 >= T) break;
+        k_tile(std::integral_constant<int, 1>{}, with_mfma, t + 1);
+      }
+    } else {
+      for (int t = 0; t < T; ++t) k_tile(t & 1, with_mfma, t);
     }
+  };
+  // RAGGED_SKIP: a wave whose rows all lie past M runs a copy of the loop without MFMAs (one branch per block; testing
+  // wave_on at every k-step was 8 branches per K-tile in every wave of the narrow WGRAD instances)
+  if constexpr (RAGGED_SKIP) {
+    if (wave_on) k_loop(std::true_type{}); else k_loop(std::false_type{});
   } else {
-    for (int t = 0; t < T; ++t) k_tile(t & 1, t);
+    k_loop(std::true_type{});
   }
 
   // ---------------- epilogue ----------------
