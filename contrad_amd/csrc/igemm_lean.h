@@ -388,7 +388,28 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
   // s_mul and a pixel-major branch per K-tile): one patch to the right / down a patch row (from past the last column) /
   // on to the next image group (from past the last row); gy positions are consecutive except across image groups of the
   // pixel-major walk (one pixel of 16 images -> the next pixel; after the last pixel 15 images further)
-  unsigned pos_offA = 0, pos_offB = 0, wk_aw = 0, wk_ah = 0, wk_an = 0, wk_b = 0, wk_bn = 0;
+  // FWD / DGRAD: the same for the (tap, 16-channel chunk) walk -- one tap to the right / on to the next tap row (from past
+  // the last tap of a row) / on to the next chunk (from past the last tap row)
+  unsigned pos_offA = 0, pos_offB = 0, wk_aw = 0, wk_ah = 0, wk_an = 0, wk_b = 0, wk_bh = 0, wk_bn = 0;
+  (void)wk_bh;
+  if constexpr (MODE == MODE_FWD) {
+    pos_offA = (unsigned)(((u_a * d.W + u_b) * d.ldx + u_c0) * 4);
+    pos_offB = (unsigned)((u_tap * d.C + u_c0) * d.ldw * 4);
+    wk_aw = (unsigned)(d.ldx * 4);
+    wk_ah = (unsigned)((d.W - d.KW) * d.ldx * 4);
+    wk_an = (unsigned)((BK - d.KH * d.W * d.ldx) * 4);
+    wk_b = (unsigned)(d.C * d.ldw * 4);
+    wk_bn = (unsigned)((BK - d.KH * d.KW * d.C) * d.ldw * 4);
+  } else if constexpr (MODE == MODE_DGRAD) {
+    pos_offA = (unsigned)((((nth - 1 - u_a) * d.Wo + (ntw - 1 - u_b)) * d.ldy + u_c0) * 4);
+    pos_offB = (unsigned)((((kh0 + d.stride * u_a) * d.KW + (kw0 + d.stride * u_b)) * d.C * d.ldw + u_c0) * 4);
+    wk_aw = (unsigned)(-d.ldy * 4);
+    wk_ah = (unsigned)((ntw - d.Wo) * d.ldy * 4);
+    wk_an = (unsigned)((nth * d.Wo * d.ldy + BK) * 4);
+    wk_b = (unsigned)(d.stride * d.C * d.ldw * 4);
+    wk_bh = (unsigned)(d.stride * (d.KW - ntw) * d.C * d.ldw * 4);
+    wk_bn = (unsigned)((BK - d.stride * nth * d.KW * d.C * d.ldw) * 4);
+  }
   if constexpr (MODE == MODE_WGRAD) {
     pos_offA = (unsigned)(((((u_n - n_begin) * d.H + u_h * d.stride) * d.W + u_w * d.stride) * d.ldx) * 4);
     pos_offB = pl_pixmajor ? (unsigned)((((u_n - n_begin) * d.Ho + u_h) * d.Wo + u_w) * d.ldy * 4) : 0u;
@@ -406,18 +427,9 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
     const bool on = t_next < T;          // past the last tile: descriptors with 0 records -> every load is a zero fill
     rsA = lean_rsrc(baseA, on);
     rsB = lean_rsrc(baseB, on);
-    if constexpr (MODE == MODE_FWD) {
-      soffA = (unsigned)(((u_a * d.W + u_b) * d.ldx + u_c0) * 4);
-      soffB = (unsigned)((u_tap * d.C + u_c0) * d.ldw * 4);
-    } else if constexpr (MODE == MODE_DGRAD) {
-      soffA = (unsigned)((((nth - 1 - u_a) * d.Wo + (ntw - 1 - u_b)) * d.ldy + u_c0) * 4);
-      const int tapflat = (kh0 + d.stride * u_a) * d.KW + (kw0 + d.stride * u_b);
-      soffB = (unsigned)((tapflat * d.C * d.ldw + u_c0) * 4);
-    } else {
-      soffA = pos_offA;   // (offsets and border word of the patch at (u_n, u_h, u_w): kept up to date by the walk, end_tile)
-      soffB = pos_offB;
-      edge = pos_edge;
-    }
+    soffA = pos_offA;   // (offsets -- and WGRAD's border word -- of the walk position: kept up to date by the walk, end_tile)
+    soffB = pos_offB;
+    if constexpr (MODE == MODE_WGRAD) edge = pos_edge;
   };
   auto end_tile = [&]() {   // advance the walk to the tile after t_next
     ++t_next;
@@ -427,13 +439,19 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
       // input window (all channels) once per tap, 128 blocks per XCD x ~100 KB did not fit the 4 MB L2, and the
       // kernel fetched 5x its algorithmic bytes from HBM.
       do {   // (pixel-major tiles: on to the next tap that is not padding; otherwise every tap is visited)
-        ++u_tap; ++u_b;
-        if (u_b == d.KW) { u_b = 0; ++u_a; if (u_a == d.KH) { u_a = 0; u_tap = 0; u_c0 += BK; } }
+        ++u_tap; ++u_b; pos_offA += wk_aw; pos_offB += wk_b;
+        if (u_b == d.KW) {
+          u_b = 0; ++u_a; pos_offA += wk_ah;
+          if (u_a == d.KH) { u_a = 0; u_tap = 0; pos_offA += wk_an; pos_offB += wk_bn; }
+        }
       } while (!((tapmask >> u_tap) & 1u));
     } else if constexpr (MODE == MODE_DGRAD) {
       do {
-        ++u_tap; ++u_b;
-        if (u_b == ntw) { u_b = 0; ++u_a; if (u_a == nth) { u_a = 0; u_tap = 0; u_c0 += BK; } }
+        ++u_tap; ++u_b; pos_offA += wk_aw; pos_offB += wk_b;
+        if (u_b == ntw) {
+          u_b = 0; ++u_a; pos_offA += wk_ah; pos_offB += wk_bh;
+          if (u_a == nth) { u_a = 0; u_tap = 0; pos_offA += wk_an; pos_offB += wk_bn; }
+        }
       } while (!((tapmask >> u_tap) & 1u));
     } else {
       do {   // (pixel-major: on to the next K-tile whose pixel is not padding for this tile's tap)
@@ -538,9 +556,9 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
   // One K-tile out of LDS buffer PAR (compile-time): the loop below is unrolled by two so that every LDS address of the
   // loop is "per-thread base register + immediate" -- selecting the buffer at run time cost 3 SALU + 6 v_add per K-tile in
   // every wave (round 4: each VALU instruction between MFMAs takes matrix-pipe time, §3).
-  // (The 128 x 128 FWD instance and the balanced 128 x 128 DGRAD spill > 80 registers when unrolled: they keep the run-time
-  // buffer select.)
-  constexpr bool UNROLL2 = !(BM * BN > 128 * 64 && (MODE == MODE_FWD || BAL));
+  // (The 128 x 128 FWD / DGRAD instances sit at the 128-VGPR limit and spill 25 ... 215 registers in every unrolled shape
+  // tried -- break in the middle, or an even tile count with a zero-filled last tile: they keep the run-time buffer select.)
+  constexpr bool UNROLL2 = !(BM * BN > 128 * 64 && MODE != MODE_WGRAD);
   auto k_tile = [&](auto par, auto with_mfma, const int t) {
     const int cur = (int)par * BUF, nxt = BUF - cur;   // (par: std::integral_constant when unrolled -> folds to immediates)
     (void)t;
