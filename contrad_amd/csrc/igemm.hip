@@ -864,6 +864,15 @@ bool vec_ok(const contrad_conv_desc* d, int mode) {
   return c4 && k4;                                      // WGRAD: x rows and gy rows
 }
 
+// Dev library only (tools/tune_plans.py): the next plans take this tile / split count instead of the model's (0 = model).
+struct PlanOverride { int bm, bn, splits; };
+PlanOverride g_plan_override = {0, 0, 0};
+#if defined(CONTRAD_DEV_SWITCHES)
+}  // namespace
+extern "C" void contrad_dev_plan_override(int bm, int bn, int splits) { g_plan_override = PlanOverride{bm, bn, splits}; }
+namespace {
+#endif
+
 // Tile choice: the biggest tile that still yields >= 3 blocks per CU (4 are resident); measured on the lean
 // kernels at 3N = 192 / 384 / 1536 images (tools/ab_tile.sh): below that fill the 64x64 tile (TM = TN = 1) wins even
 // though it does 4x the LDS traffic per flop.  mult4 / 4 = independent grids of this size (DGRAD parity classes: 4; in the
@@ -877,6 +886,7 @@ void pick_tile(long long M, int Ncol, bool vec, bool lean, int mult4, int* bm, i
   if (lean && Ncol <= 32) { *bm = 128; *bn = 32; return; }
   static const int forced = []() { const char* e = contrad_dev_env("CONTRAD_IGEMM_TILE"); return e ? atoi(e) : 0; }();  // dev: "128064"
   if (forced) { *bm = forced / 1000; *bn = forced % 1000; return; }
+  if (g_plan_override.bm > 0) { *bm = g_plan_override.bm; *bn = g_plan_override.bn; return; }
   static const int cand[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
   for (int i = (Ncol > 64 ? 0 : 2); i < 4; ++i) {
     *bm = cand[i][0]; *bn = cand[i][1];
@@ -931,6 +941,7 @@ int wgrad_plan(const contrad_conv_desc* d, int* bm, int* bn, int* tiles_m, int* 
   *bm = (Kg > 64) ? 128 : 64;
   static const int forced = []() { const char* e = contrad_dev_env("CONTRAD_WGRAD_TILE"); return e ? atoi(e) : 0; }();  // dev
   if (forced) { *bm = forced / 1000; *bn = forced % 1000; }
+  if (g_plan_override.bm > 0) { *bm = g_plan_override.bm; *bn = g_plan_override.bn; }
   static const int target = []() { const char* e = contrad_dev_env("CONTRAD_WGRAD_BLOCKS"); return e ? atoi(e) : 1024; }();  // dev
   if (!vec_ok(d, MODE_WGRAD)) { *bm = 64; *bn = 64; }
   *tiles_m = cdiv(Kg, *bm);
@@ -939,6 +950,7 @@ int wgrad_plan(const contrad_conv_desc* d, int* bm, int* bn, int* tiles_m, int* 
   // 2 blocks are resident per CU (LDS): aim at <= 1024 blocks = two full rounds of the 256 CUs, never a ragged
   // third one (9 x 114 = 1026 blocks cost +30 % on the 3x3 layers before this was a floor)
   long long want = target / ((long long)(*tiles_m) * (*tiles_n));
+  if (g_plan_override.splits > 0) want = g_plan_override.splits;   // dev: split count from the tuner
   if (want < 1) want = 1;
   long long pps = cdivll(ptiles, want);
   if (pps < 4) pps = 4;  // at least 128 positions per split
@@ -1002,6 +1014,13 @@ void split_plan(long long M, int Ncol, int t_total, double flops, FwdPlan* p) {
   static const int cand[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
   static const double rate[4] = {135e12, 128e12, 128e12, 115e12};
   static const int sp[8] = {1, 2, 3, 4, 6, 8, 12, 16};
+  if (g_plan_override.bm > 0) {   // dev: tile and split count from the tuner
+    const int s_ = std::max(1, g_plan_override.splits);
+    p->bm = g_plan_override.bm; p->bn = g_plan_override.bn;
+    p->tps = cdiv(t_total, s_);
+    p->splits = cdiv(t_total, p->tps);
+    return;
+  }
   double best = 1e30;
   for (int i = (Ncol > 64 ? 0 : 2); i < 4; ++i)
     for (int j = 0; j < 8; ++j) {
