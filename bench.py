@@ -684,6 +684,9 @@ def main():
         env.setdefault('OMP_NUM_THREADS', '4')
         raise SystemExit(subprocess.call(cmd, env=env))
 
+    # (dmabuf IPC: the hosts of this pool support nothing else, and RCCL / tensor sharing across processes fail without it;
+    # the HIP runtime reads it at its first call, which comes after this line)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
