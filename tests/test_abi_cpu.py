@@ -170,6 +170,29 @@ def test_shipped_library_reads_no_environment(built):
         return subprocess.run(['nm', '-D', path], capture_output=True, text=True, check=True).stdout
     assert 'CONTRAD_' not in names(build.LIB) and 'getenv' not in imports(build.LIB)
     assert 'CONTRAD_TILEMODE' in names(build.DEV_LIB) and 'getenv' in imports(build.DEV_LIB)
+    # the tuner's plan override (tools/tune_plans.py) is an entry point of the development library only
+    assert 'contrad_dev_plan_override' in imports(build.DEV_LIB) and 'contrad_dev_plan_override' not in imports(build.LIB)
+
+
+def test_plan_override_changes_the_reported_plan():
+    """tools/tune_plans.py forces tile and split count through contrad_dev_plan_override (dev library): the plan queries
+    must report what was forced (they share the plan functions with the launchers), and 0, 0, 0 must restore the model."""
+    from contrad_amd import build, ops
+    dev = ctypes.CDLL(build.DEV_LIB)
+    dev.contrad_dev_plan_override.restype, dev.contrad_dev_plan_override.argtypes = None, [ctypes.c_int] * 3
+    d = ops.make_desc(192, 8, 8, 256, 256, 3, 3, 1, 1, 256, 256, 256)
+    bm, bn = ctypes.c_int(0), ctypes.c_int(0)
+    plans = {}
+    for forced in ((0, 0, 0), (64, 64, 1), (128, 64, 1), (0, 0, 0)):
+        dev.contrad_dev_plan_override(*forced)
+        per_mode = []
+        for mode in (0, 1, 2):
+            assert dev.contrad_conv2d_tile(ctypes.byref(d), mode, ctypes.byref(bm), ctypes.byref(bn)) == 0
+            per_mode.append((bm.value, bn.value))
+        plans.setdefault(forced, []).append(per_mode)
+        if forced[0]:
+            assert all(t == forced[:2] for t in per_mode), (forced, per_mode)
+    assert plans[(0, 0, 0)][0] == plans[(0, 0, 0)][1]          # the model's plan is back
 
 
 def test_slot_balanced_tile_order_without_gpu(built):
