@@ -266,11 +266,11 @@ def _pmc_traffic(config, kernel):
                     # counters cannot be read inside the timed process; a summary collected on OTHER kernel sources is
                     # not this build's traffic -> null, and say why
                     return None, 'stale: profiles/%s was collected on kernel sources %s, this build is %s' % (
-                        f, pmc.get('csrc_fingerprint'), _csrc_fingerprint())
-                return ent['traffic_bytes_per_launch'], 'profiles/' + f
+                        f, pmc.get('csrc_fingerprint'), _csrc_fingerprint()), None
+                return ent['traffic_bytes_per_launch'], 'profiles/' + f, ent
         except (OSError, ValueError, KeyError):
             pass
-    return None, None
+    return None, None, None
 
 
 def _write_shape_table(path, name, cfg, warm_prof, marks, n_local):
@@ -468,35 +468,53 @@ def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=
         achieved = fsum / max(tsum, 1e-12) / 1e12
         executed = xsum / max(tsum, 1e-12) / 1e12
         conv_time_per_step = sum(a[0] for a in wagg_.values()) / wsteps_
-        traffic, traffic_src = _pmc_traffic(name, dom) if world == 1 else (None, None)
+        issued_share_step = sum(a[3] for a in wagg_.values()) / max(sum(a[1] for a in wagg_.values()), 1.0)
+        traffic, traffic_src, pmc_ent = _pmc_traffic(name, dom) if world == 1 else (None, None, None)
         fpi = cfg['flop_per_image']
         if cfg['d_reg_every'] > 1:      # lazy R1: price the R1 steps actually inside the timed window, not 1 / period
             fpi = cfg['flop_plain'] + cfg['flop_r1'] * (steps // cfg['d_reg_every']) / steps
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic,
+        clock = (pmc_ent or {}).get('effective_clock_GHz')
+        # `achieved` / `frac`: the multiply-adds the kernel ISSUES per second against the fp32 MFMA peak -- a roofline
+        # fraction in the strict sense (<= 1 by construction).  `nominal_*`: the same time priced on the dense layer's count
+        # 2*N*Ho*Wo*K*C*KH*KW (what every earlier round quoted as `frac`); it exceeds the issued figure where
+        # pixel-major tiles skip tap-positions that read zero padding, i.e. it is a speed-up over the dense algorithm,
+        # not a utilisation.
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(executed, 2), "peak": PEAK_FP32_MFMA,
+                    "unit": "TFLOP/s", "frac": round(executed / PEAK_FP32_MFMA, 4),
+                    "nominal_achieved": round(achieved, 2), "nominal_frac": round(achieved / PEAK_FP32_MFMA, 4),
+                    "issued_share_of_nominal": round(xsum / max(fsum, 1.0), 4),
+                    "traffic": traffic,
                     "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                    "effective_clock_GHz": None if clock is None else round(clock, 3),
+                    "peak_at_effective_clock": None if clock is None else round(PEAK_FP32_MFMA * clock / 2.4, 1),
+                    "frac_at_effective_clock": None if clock is None else round(executed / (PEAK_FP32_MFMA * clock / 2.4), 4),
+                    "mfma_busy_fraction": (pmc_ent or {}).get('mfma_busy_fraction'),
+                    "l2_hit_rate": (pmc_ent or {}).get('l2_hit_rate'),
                     "launches_per_step": cnt / nprof_steps, "avg_launch_ms": round(tsum / cnt * 1e3, 4),
-                    "algorithmic_gflop_per_launch": round(fsum / cnt / 1e9, 2),
-                    "flop_convention": "achieved / frac are quoted on the layer's nominal count 2*N*Ho*Wo*K*C*KH*KW (SURVEY.md "
-                                       "8d: the dense layer of the reference, tap-positions that read zero padding "
-                                       "included); `executed` prices only the multiply-adds the kernel issues -- its "
-                                       "pixel-major tiles (contrad_conv2d_path == 3) skip the padding tap-positions of "
-                                       "the layers on 4x4 / 8x8 maps",
-                    "executed": {"gflop_per_launch": round(xsum / cnt / 1e9, 2), "tflops": round(executed, 2),
-                                 "frac_of_peak": round(executed / PEAK_FP32_MFMA, 4),
-                                 "share_of_nominal": round(xsum / max(fsum, 1.0), 4)},
+                    "algorithmic_gflop_per_launch": round(xsum / cnt / 1e9, 2),
+                    "nominal_gflop_per_launch": round(fsum / cnt / 1e9, 2),
+                    "flop_convention": "achieved / frac price the multiply-adds the kernel issues (pixel-major tiles, "
+                                       "contrad_conv2d_path == 3, skip the tap-positions that read zero padding on the 4x4 "
+                                       "/ 8x8 maps: contrad_conv2d_executed_fraction); nominal_* price the same time on the "
+                                       "dense layer 2*N*Ho*Wo*K*C*KH*KW of the reference (SURVEY.md 8d) and may exceed the "
+                                       "issued figure; peak = 157.3 TFLOP/s at 2.4 GHz, the clock the counters measured "
+                                       "under this kernel is effective_clock_GHz (from the PMC summary in traffic_source)",
                     "bracket": "HIP events around the C-ABI call on its stream" +
                                (" (igemm WGRAD kernel + its wgrad_reduce_kernel)" if "<2," in dom else "") +
                                ("; the timed region replays one captured hipGraph per step, so the bracketed launches are "
                                 "those of %d eager steps run right after it" % nprof_steps if graph_run else ""),
                     "conv_engine_share_of_step": round(conv_time_per_step / (dt / steps), 3),
-                    "all_kernels_warmup": {k: {"tflops": round(v[1] / v[0] / 1e12, 1),
-                                               "executed_tflops": round(v[3] / v[0] / 1e12, 1),
+                    "all_kernels_warmup": {k: {"tflops": round(v[3] / v[0] / 1e12, 1),
+                                               "nominal_tflops": round(v[1] / v[0] / 1e12, 1),
                                                "ms_per_step": round(v[0] / wsteps_ * 1e3, 3)}
                                            for k, v in sorted(wagg_.items())},
-                    "step_level": {"achieved": round(value / world * fpi / 1e12, 2),
-                                   "frac": round(value / world * fpi / 1e12 / PEAK_FP32_MFMA, 4),
-                                   "flop_per_image": fpi}}
+                    "step_level": {"nominal_achieved": round(value / world * fpi / 1e12, 2),
+                                   "nominal_frac": round(value / world * fpi / 1e12 / PEAK_FP32_MFMA, 4),
+                                   "frac": round(value / world * fpi / 1e12 / PEAK_FP32_MFMA * issued_share_step, 4),
+                                   "issued_share_of_nominal": round(issued_share_step, 4),
+                                   "flop_per_image": fpi,
+                                   "note": "whole step (every kernel, every gap) priced at SURVEY's nominal FLOPs per "
+                                           "image; frac scales it by the issued / nominal share of the conv launches"}}
         out = {"metric": "discriminator-step images/sec (ContraD, SimCLR aug)", "value": round(value, 1),
                "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
@@ -523,6 +541,7 @@ def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=
         if rank == 0 and eager_line is not None:
             line = json.loads(json.dumps(eager_line))
             line["config"]["launch"] = 'eager (graph capture timed out)'
+            line["config"]["graph_hung"] = True        # explicit: the process leaves through os._exit(0)
             keep(name, line)
         arm(name)
 

@@ -414,7 +414,10 @@ class MinibatchStddevFn(Function):
 
     @staticmethod
     def forward(ctx, x, cpad, splits):
-        x = _cont(x)
+        if not x.is_contiguous():
+            # a silent copy here would be saved WITHOUT autograd history: the double backward's gradient w.r.t. x (R1's
+            # only path to the trunk through this channel) would be dropped
+            raise ValueError('MinibatchStddevFn expects a dense NHWC activation (got strides %s)' % (x.stride(),))
         ctx.save_for_backward(x)
         ctx.splits = splits
         return ops.minibatch_stddev(0, x, cpad=cpad, splits=splits)
@@ -472,11 +475,16 @@ class ZeroGradFn(Function):
 
     @staticmethod
     def backward(ctx, g):
-        if _INPUT_GRAD_ONLY:
+        need = ctx.needs_input_grad[1:]
+        if _INPUT_GRAD_ONLY or not any(need):          # frozen D (generator step), R1's first backward: nothing to fill
             return (g,) + (None,) * len(ctx.shapes)
-        flat = torch.zeros(sum(int(torch.Size(s).numel()) for s in ctx.shapes), device=g.device, dtype=g.dtype)
+        flat = torch.zeros(sum(int(torch.Size(s).numel()) for s, nd in zip(ctx.shapes, need) if nd),
+                           device=g.device, dtype=g.dtype)
         outs, o = [], 0
-        for s in ctx.shapes:
+        for s, nd in zip(ctx.shapes, need):
+            if not nd:
+                outs.append(None)
+                continue
             n = int(torch.Size(s).numel())
             outs.append(flat[o:o + n].view(s))
             o += n

@@ -1130,7 +1130,7 @@ int dgrad_strided_class0_taps(const contrad_conv_desc* d, int* taps) {
   const int s = d->stride;
   if (s != 2 || (d->H & 1) || (d->W & 1)) return 0;
   const int Hc = d->H / 2, Wc = d->W / 2;
-  if (Hc * Wc > 256) return 0;
+  if (Hc * Wc > 256 || Hc > 128 || Wc > 128) return 0;      // (the per-axis bound makes wh / ww safe on their own)
   int wh[2][128], ww[2][128];
   for (int par = 0; par < 2; ++par) {
     for (int hq = 0; hq < Hc; ++hq) {

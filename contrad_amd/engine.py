@@ -253,7 +253,7 @@ def _quiesce_before_capture(*modules):
     torch.cuda.synchronize()
     if dist.is_available() and dist.is_initialized():
         import time
-        time.sleep(0.5)
+        time.sleep(1.0)          # (the full second stays until thread_local mode is proven on W > 1 hardware)
         torch.cuda.synchronize()
         return 'thread_local'
     return 'global'

@@ -41,7 +41,7 @@ def test_graph_capture_that_never_returns_reports_the_eager_result():
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out['n_gpus'] == 2 and out['config']['launch'] == 'eager (graph capture timed out)'
+    assert out['n_gpus'] == 2 and out['config']['launch'] == 'eager (graph capture timed out)' and out['config']['graph_hung'] is True
     assert out['config']['losses_finite'] and out['value'] > 0 and out['steps'] == 2
     assert 'did not get through graph capture' in r.stderr
 

@@ -37,10 +37,10 @@ def _relerr(got, ref):
     return abs(float(got) - float(ref)) / max(abs(float(ref)), 1e-30)
 
 
-def test_config2_sndcgan_step_at_batch_512_against_oracle(margin):
-    """BASELINE configs[1]: SNDCGAN + ContraD, 32x32, N = 512 (1 536 images through D), simclr augmentation."""
+def _sndcgan_step_against_oracle(N, tag, margin):
+    """One SNDCGAN + ContraD discriminator step at batch N (3N images through D, simclr augmentation) against the oracle:
+    fakes, both losses, d_real / d_gen, all 26 gradient norms and the power-iteration vectors."""
     _threads()
-    N = 512
     G, D = get_architecture('sndcgan', (32, 32, 3))
     dsd = O.det_fill(O.sndcgan_d_param_shapes(), seed=21)
     gsd_fill = O.det_fill(O.sndcgan_g_param_shapes(), seed=22)
@@ -66,22 +66,36 @@ def test_config2_sndcgan_step_at_batch_512_against_oracle(margin):
     torch.manual_seed(31); np.random.seed(31)
     with torch.no_grad():
         ofake = O.sndcgan_g_forward(gsd_fill, O.sample_latent_sndcgan(N))
-    margin('config2/fakes (G forward, max-abs)', (fake.cpu() - ofake).abs().max().item(), TOL)
+    margin(tag + '/fakes (G forward, max-abs)', (fake.cpu() - ofake).abs().max().item(), TOL)
     p = O.sample_simclr_params(3 * N, 32, 32, O.SIMCLR_CIFAR)
     aug = O.simclr_apply(torch.cat([x, x, fake.cpu()]), p)
     closs, gloss, d_real, d_gen = O.contrad_loss_d(lambda t: O.sndcgan_d_forward(osd, t, sg_linear=True)[:3], aug, N)
     (closs + gloss).backward()
 
-    margin('config2/contrad_loss', _relerr(d_loss.item(), closs.item()), TOL)
-    margin('config2/gan_loss', _relerr(aux['penalty'].item(), gloss.item()), TOL)
-    margin('config2/d_real', abs(aux['d_real'].item() - d_real.item()), TOL * max(1.0, abs(d_real.item())))
-    margin('config2/d_gen', abs(aux['d_gen'].item() - d_gen.item()), TOL * max(1.0, abs(d_gen.item())))
+    margin(tag + '/contrad_loss', _relerr(d_loss.item(), closs.item()), TOL)
+    margin(tag + '/gan_loss', _relerr(aux['penalty'].item(), gloss.item()), TOL)
+    margin(tag + '/d_real', abs(aux['d_real'].item() - d_real.item()), TOL * max(1.0, abs(d_real.item())))
+    margin(tag + '/d_gen', abs(aux['d_gen'].item() - d_gen.item()), TOL * max(1.0, abs(d_gen.item())))
     for k, prm in D.named_parameters():
-        margin('config2/gradnorm/' + k, _relerr(prm.grad.norm().item(), osd[k].grad.norm().item()), TOL)
+        margin(tag + '/gradnorm/' + k, _relerr(prm.grad.norm().item(), osd[k].grad.norm().item()), TOL)
     # the power-iteration vectors after the step
     for k, b in D.named_buffers():
         if k.endswith('weight_u') or k.endswith('weight_v'):
-            margin('config2/' + k, (b.cpu() - osd[k]).abs().max().item(), TOL)
+            margin(tag + '/' + k, (b.cpu() - osd[k]).abs().max().item(), TOL)
+
+
+def test_config2_sndcgan_step_at_batch_512_against_oracle(margin):
+    """BASELINE configs[1]: SNDCGAN + ContraD, 32x32, N = 512 (1 536 images through D), simclr augmentation."""
+    _sndcgan_step_against_oracle(512, 'config2', margin)
+
+
+def test_config3_sndcgan_step_at_the_per_rank_batch_64_against_oracle(margin):
+    """BASELINE configs[2] as ONE of its eight ranks sees it (train_gan.py:245-247: 512 // 8 = 64 reals, 192 images through
+    D): the launch plans of 192-image GEMMs -- 64x64 tiles, split-K forward / data-gradient workspaces, no pixel-major
+    tiles -- differ from those at 1 536 images, so the whole step is compared at this size too.  (The 8-rank exchange
+    itself is covered by tests/test_dp_two_ranks_gpu.py at the same per-rank batch, against the oracle on the global
+    batch.)"""
+    _sndcgan_step_against_oracle(64, 'config3_rank', margin)
 
 
 def test_config4_stylegan2_32_step_with_r1_at_batch_64_against_oracle(margin):
@@ -130,14 +144,16 @@ def test_config4_stylegan2_32_step_with_r1_at_batch_64_against_oracle(margin):
         margin('config4/gradnorm/' + k, _relerr(prm.grad.norm().item(), osd[k].grad.norm().item()), TOL)
 
 
-def test_config5_stylegan2_512_losses_and_r1_at_512_against_oracle(margin):
+def test_config5_stylegan2_512_step_at_512_against_oracle(margin):
     """BASELINE configs[4] at the AFHQ resolution, simclr_hq, the call structure of train_stylegan2_contraD.py (fakes N and
-    real views 2N through D separately, r1 on its own call): the three losses, d_real / d_gen and r1.  N = 4 keeps the
-    oracle's 512^2 forward + R1 gradient inside a minute of host time (N = 16 would take four); the N = 16 step itself is
-    checked for finiteness / bitwise determinism in tests/test_stylegan2_512_gpu.py and its gradients against the
-    reference golden at N = 2."""
+    real views 2N through D separately, r1 on its own call, weight (0.5 * lbd_r1) * d_reg_every = 80 as in the lazy-R1
+    step): the three losses, d_real / d_gen, r1 AND every parameter-gradient norm of the whole step.  N = 4 keeps the
+    oracle's 512^2 forward + R1 double backward + backward at about a minute and a half of host time (8 cores: 80 s;
+    N = 16 would take five); the N = 16 step itself is checked for finiteness / bitwise determinism in
+    tests/test_stylegan2_512_gpu.py and its gradient ENTRIES against the reference golden at N = 2."""
     _threads()
     N = 4
+    w_r1 = (0.5 * 10.0) * 16
     hq = dict(scale=(0.08, 1.0), brightness=0.8, contrast=0.8, saturation=0.8, hue=0.2, p_blur=0.5,
               sigma_range=(0.1, 2.0))
     G, D = get_architecture('stylegan2_512', (512, 512, 3))
@@ -150,28 +166,34 @@ def test_config5_stylegan2_512_losses_and_r1_at_512_against_oracle(margin):
     fake = seeded_images(N, 512, 13)          # (G(512)'s forward has its own golden; any image batch serves as fakes)
 
     torch.manual_seed(51); np.random.seed(51)
-    with torch.no_grad():
-        d_loss, aux = loss_D_fn_separate(P, D, {'loss': 'nonsat'}, x.to(DEV), fake.to(DEV))
+    d_loss, aux = loss_D_fn_separate(P, D, {'loss': 'nonsat'}, x.to(DEV), fake.to(DEV))
     r1 = r1_loss(D, x.to(DEV), P.augment_fn)
+    D.zero_grad()
+    torch.add(d_loss + aux['penalty'], r1, alpha=w_r1).backward()
     torch.cuda.synchronize()
 
     osd = {k: v.clone() for k, v in sd.items()}
+    for k in osd:
+        if not k.endswith('kernel'):
+            osd[k].requires_grad_()
     torch.manual_seed(51); np.random.seed(51)
     aug_f = O.simclr_apply(fake, O.sample_simclr_params(N, 512, 512, O.SIMCLR_HQ_AFHQ))
     aug_r = O.simclr_apply(torch.cat([x, x]), O.sample_simclr_params(2 * N, 512, 512, O.SIMCLR_HQ_AFHQ))
     aug_r1 = O.simclr_apply(x, O.sample_simclr_params(N, 512, 512, O.SIMCLR_HQ_AFHQ))
-    with torch.no_grad():
-        d_gen, pf, p2f, _ = S.d_forward(osd, aug_f, 512, sg_linear=True)
-        d_rs, pr, p2r, _ = S.d_forward(osd, aug_r, 512, sg_linear=True)
-        views_r, reals = F.normalize(pr), F.normalize(p2r)
-        others, fakes = F.normalize(pf), F.normalize(p2f)
-        simclr = O.nt_xent(views_r[:N], views_r[N:], 0.1)
-        sup = O.supcon_fake(reals[:N], reals[N:], fakes, 0.1)
-        gan = F.softplus(d_gen).mean() + F.softplus(-d_rs[:N]).mean()
+    d_gen, pf, p2f, _ = S.d_forward(osd, aug_f, 512, sg_linear=True)
+    d_rs, pr, p2r, _ = S.d_forward(osd, aug_r, 512, sg_linear=True)
+    views_r, reals = F.normalize(pr), F.normalize(p2r)
+    others, fakes = F.normalize(pf), F.normalize(p2f)
+    simclr = O.nt_xent(views_r[:N], views_r[N:], 0.1)
+    sup = O.supcon_fake(reals[:N], reals[N:], fakes, 0.1)
+    gan = F.softplus(d_gen).mean() + F.softplus(-d_rs[:N]).mean()
     or1 = S.r1_penalty(lambda t: S.d_forward(osd, t, 512)[0], aug_r1)
+    (simclr + sup + gan + w_r1 * or1).backward()
 
     margin('config5/contrad_loss', _relerr(d_loss.item(), (simclr + sup).item()), TOL)
     margin('config5/gan_loss', _relerr(aux['penalty'].item(), gan.item()), TOL)
     margin('config5/d_real', abs(aux['d_real'].item() - d_rs[:N].mean().item()), TOL * max(1.0, abs(d_rs[:N].mean().item())))
     margin('config5/d_gen', abs(aux['d_gen'].item() - d_gen.mean().item()), TOL * max(1.0, abs(d_gen.mean().item())))
     margin('config5/r1', _relerr(r1.item(), or1.item()), TOL)
+    for k, prm in D.named_parameters():
+        margin('config5/gradnorm/' + k, _relerr(prm.grad.norm().item(), osd[k].grad.norm().item()), TOL)

@@ -72,7 +72,14 @@ def test_rows_are_attributed_by_launch_order(tmp_path):
     by_shape = {r[1]: r for r in rows}
     # 20 GFLOP in 200 us = 100 TF/s; 40 GFLOP in 400 us = 100 TF/s: each shape got ITS dispatches (same instance + grid)
     assert abs(float(by_shape['4,8,8,16,16,3,3,1,1'][5]) - 200.0) < 1e-6 and abs(float(by_shape['4,4,4,32,32,3,3,1,1'][5]) - 400.0) < 1e-6
-    assert abs(float(by_shape['4,8,8,16,16,3,3,1,1'][7]) - 100.0) < 0.1 and abs(float(by_shape['4,4,4,32,32,3,3,1,1'][7]) - 100.0) < 0.1
-    assert '80.0 GFLOP per step in 802.0 us of igemm dispatches' in plain_part and 'issued 60.0 GFLOP' in plain_part
-    assert abs(float(by_shape['4,4,4,32,32,3,3,1,1'][9]) - 0.5) < 1e-6 and abs(float(by_shape['4,4,4,32,32,3,3,1,1'][10]) - 50.0) < 0.1
+    # columns: kernel shape blocks n/step calls avg_us GFLOP/call exec TF/s(issued) frac(issued) nominalTF/s
+    assert abs(float(by_shape['4,8,8,16,16,3,3,1,1'][10]) - 100.0) < 0.1 and abs(float(by_shape['4,4,4,32,32,3,3,1,1'][10]) - 100.0) < 0.1
+    assert 'issued 60.0 GFLOP per step in 802.0 us of igemm dispatches' in plain_part and 'nominal 80.0 GFLOP' in plain_part
+    assert abs(float(by_shape['4,4,4,32,32,3,3,1,1'][7]) - 0.5) < 1e-6 and abs(float(by_shape['4,4,4,32,32,3,3,1,1'][8]) - 50.0) < 0.1
+    assert abs(float(by_shape['4,4,4,32,32,3,3,1,1'][9]) - 50.0 / 157.3) < 1e-3
+    # no fraction above 1 is ever printed in the frac column (issued work cannot exceed the peak)
+    for l in plain_part.splitlines():
+        f = l.split()
+        if len(f) >= 11 and l.startswith(('igemm', 'wgrad_c32', 'conv_c32', 'fwd_k1')) and f[9] != 'ambig':
+            assert float(f[9]) <= 1.0, l
     assert any(l.startswith('wgrad_c32_kernel') and abs(float(l.split()[5]) - 100.0) < 1e-6 for l in plain_part.splitlines())

@@ -60,11 +60,12 @@ def main(db_path, table_path):
     table = json.load(open(table_path))
     print('# %s: rocprofv3 kernel trace joined with the shape table of `bench.py --config %s` (per-GPU batch %d)' % (
         db_path.split('/')[-1], table['config'], table['per_gpu_batch']))
-    print('# TF/s = GFLOP per launch / rocprof average duration of the igemm dispatch alone (a WGRAD call\'s '
-          'wgrad_reduce_kernel is a separate trace row); FLOP rule: %s; frac = TF/s / 157.3' % table['flop_rule'])
-    print('# exec = share of those nominal FLOPs the kernel issues: pixel-major tiles (contrad_conv2d_path 3, small maps) skip '
-          'the tap-positions that read zero padding, which the FLOP rule counts -- xTF/s = TF/s * exec is the rate the '
-          'matrix pipe actually ran at')
+    print('# GFLOP/call = the layer\'s NOMINAL (dense) count, FLOP rule: %s; exec = share of it the kernel issues: pixel-major '
+          'tiles (contrad_conv2d_path 3, small maps) skip the tap-positions that read zero padding, which the rule counts'
+          % table['flop_rule'])
+    print('# TF/s = GFLOP/call * exec / rocprof average duration of the igemm dispatch alone (a WGRAD call\'s '
+          'wgrad_reduce_kernel is a separate trace row) = the rate the matrix pipe ran at; frac = TF/s / 157.3 (fp32 MFMA peak '
+          'at 2.4 GHz); nominalTF/s = GFLOP/call / duration: a speed-up over the dense algorithm, not a utilisation')
     print('# %d steps in the trace (cut at the optimizer launch)' % len(steps))
     matched_steps = set()
     reasons = {}
@@ -122,9 +123,11 @@ def main(db_path, table_path):
         print('\n== section %s: %d conv-engine launches per step, %d trace step(s) matched ==' % (sec, len(seq), nmatch))
         if not nmatch:
             continue
-        print('%-30s %-34s %7s %7s %8s %10s %11s %7s %6s %5s %6s' % ('kernel', 'shape N,H,W,C,K,KH,KW,s,p', 'blocks', 'n/step',
-                                                                   'calls', 'avg_us', 'GFLOP/call', 'TF/s', 'frac', 'exec',
-                                                                   'xTF/s'))
+        # TF/s and frac are on the multiply-adds ISSUED (GFLOP/call * exec); the last column prices the same duration on
+        # the layer's nominal (dense) count and is labelled as such -- it is not a utilisation and may exceed the peak
+        print('%-30s %-34s %7s %7s %8s %10s %11s %5s %7s %6s %12s' % ('kernel', 'shape N,H,W,C,K,KH,KW,s,p', 'blocks', 'n/step',
+                                                                   'calls', 'avg_us', 'GFLOP/call', 'exec', 'TF/s', 'frac',
+                                                                   'nominalTF/s'))
         tot_f = tot_t = tot_x = 0.0
         per_kernel = {}
         for (k, shape, blocks), (c, us, gf, ex) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
@@ -135,17 +138,21 @@ def main(db_path, table_path):
             tot_t += us / nmatch
             pk = per_kernel.setdefault(k, [0.0, 0.0, 0, 0.0])
             pk[0] += gf * c / nmatch; pk[1] += us / nmatch; pk[2] += c / nmatch; pk[3] += gf * ex * c / nmatch
-            print('%-30s %-34s %7d %7.1f %8d %10.2f %11.4f %7.1f %6.3f %5.2f %6.1f%s' % (
-                k, ','.join(map(str, shape)), blocks, c / nmatch, c, avg, gf, tf, tf / 157.3, ex, tf * ex,
+            xf_ = tf * ex / 157.3
+            # an issued fraction above 1 is impossible: it only appears on '~' rows whose durations were swapped among
+            # shapes sharing instance and workgroup count -- printed as 'ambig' instead of a number
+            print('%-30s %-34s %7d %7.1f %8d %10.2f %11.4f %5.2f %7.1f %6s %12.1f%s' % (
+                k, ','.join(map(str, shape)), blocks, c / nmatch, c, avg, gf, ex, tf * ex,
+                ('%.3f' % xf_) if xf_ <= 1.0 else 'ambig', tf,
                 ' ~' if (k, shape, blocks) in approx else ''))
         print('-- per kernel instance (this section, per step):')
         for k, (gf, us, n, xf) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1]):
-            print('   %-30s %5.1f launches %9.1f us %10.2f GFLOP -> %6.1f TF/s (%.3f)   issued %10.2f GFLOP -> %6.1f TF/s (%.3f)' % (
-                k, n, us, gf, gf / us * 1e3 if us else 0, gf / us * 1e3 / 157.3 if us else 0,
-                xf, xf / us * 1e3 if us else 0, xf / us * 1e3 / 157.3 if us else 0))
-        print('-- conv engine, %s: %.1f GFLOP per step in %.1f us of igemm dispatches -> %.1f TF/s (%.3f of 157.3); issued %.1f '
-              'GFLOP -> %.1f TF/s (%.3f)' % (sec, tot_f, tot_t, tot_f / tot_t * 1e3, tot_f / tot_t * 1e3 / 157.3,
-                                              tot_x, tot_x / tot_t * 1e3, tot_x / tot_t * 1e3 / 157.3))
+            print('   %-30s %5.1f launches %9.1f us   issued %10.2f GFLOP -> %6.1f TF/s (%.3f of 157.3)   nominal %10.2f GFLOP -> %6.1f TF/s (nominal %.3f)' % (
+                k, n, us, xf, xf / us * 1e3 if us else 0, xf / us * 1e3 / 157.3 if us else 0,
+                gf, gf / us * 1e3 if us else 0, gf / us * 1e3 / 157.3 if us else 0))
+        print('-- conv engine, %s: issued %.1f GFLOP per step in %.1f us of igemm dispatches -> %.1f TF/s (%.3f of 157.3); nominal '
+              '%.1f GFLOP -> %.1f TF/s (nominal %.3f)' % (sec, tot_x, tot_t, tot_x / tot_t * 1e3, tot_x / tot_t * 1e3 / 157.3,
+                                                        tot_f, tot_f / tot_t * 1e3, tot_f / tot_t * 1e3 / 157.3))
     if reordered:
         print('\n(%d matched step(s) launched their kernels in an order that was not recorded; rows marked ~ share instance and '
               'workgroup count with another shape, their durations may be swapped among those shapes)' % reordered)
