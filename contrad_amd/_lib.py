@@ -46,6 +46,21 @@ class AdamBatch(ctypes.Structure):
                 ('block_start', ctypes.c_int * (ADAM_MAX_TENSORS + 1))]
 
 
+MODCONV_MAX_LAYERS = 32
+
+
+class ModconvLayer(ctypes.Structure):
+    """contrad_modconv_layer."""
+    _fields_ = [('w', ctypes.c_void_p), ('wp', ctypes.c_void_p), ('wsq', ctypes.c_void_p),
+                ('Cout', ctypes.c_int), ('Cin', ctypes.c_int), ('T', ctypes.c_int), ('ldw', ctypes.c_int),
+                ('transposed', ctypes.c_int), ('scale', ctypes.c_float)]
+
+
+class ModconvBatch(ctypes.Structure):
+    """contrad_modconv_batch."""
+    _fields_ = [('n', ctypes.c_int), ('layers', ModconvLayer * MODCONV_MAX_LAYERS)]
+
+
 _CTYPES = {
     'int': ctypes.c_int,
     'float': ctypes.c_float,

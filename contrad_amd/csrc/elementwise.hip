@@ -231,8 +231,10 @@ __global__ void bn_relu_bwd_apply_kernel(const float* __restrict__ dy, const flo
 
 __global__ void bn_running_update_kernel(const float* __restrict__ stats, float count, int K,
                                          const float* __restrict__ conv_bias, float momentum,
-                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
+                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                         long long* __restrict__ num_batches_tracked) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;      // (nn.BatchNorm2d's counter: was an ATen launch per layer)
   if (c >= K) return;
   const float mean = stats[c] / count;
   const float var = fmaxf(stats[K + c] / count - mean * mean, 0.f);
@@ -431,10 +433,10 @@ extern "C" int contrad_bn_relu_bwd_apply(const float* dy, const float* x, float*
 
 extern "C" int contrad_bn_running_update(const float* stats, float count, int K, const float* conv_bias,
                                          float momentum, float* running_mean, float* running_var,
-                                         contrad_stream_t stream) {
+                                         long long* num_batches_tracked, contrad_stream_t stream) {
   CONTRAD_ARG(stats && running_mean && running_var && K > 0 && count >= 1.f);
   hipLaunchKernelGGL(bn_running_update_kernel, dim3(cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, stats,
-                     count, K, conv_bias, momentum, running_mean, running_var);
+                     count, K, conv_bias, momentum, running_mean, running_var, num_batches_tracked);
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }

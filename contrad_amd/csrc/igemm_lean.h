@@ -26,6 +26,10 @@
 // parity tests compare each against the fp32 oracle with the stated tolerance.
 #pragma once
 
+#ifndef LEAN_QPAD
+#define LEAN_QPAD 8      // dwords between the four k-quad planes of a quad-layout LDS tile beyond 4 * rows (see lean_tile)
+#endif
+
 constexpr unsigned LEAN_OOB = 0x80000000u;       // voffset of an element that must read as zero: out of range whether or
                                                  // not the hardware adds soffset (< 2^31) before the range check
 constexpr unsigned LEAN_RANGE = 0x80000000u;     // num_records of every descriptor (offsets are block-relative)
@@ -62,7 +66,15 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
   const int pl_pixmajor = BAL ? 0 : p.pixmajor, pl_nwin = BAL ? 0 : p.nwin, pl_dsplits = BAL ? 0 : p.dsplits;
   constexpr bool A_Q = (MODE != MODE_WGRAD);   // A K-contiguous in memory -> quad layout
   constexpr bool B_Q = (MODE == MODE_DGRAD);
-  constexpr int QSA = BM * 4 + 16, QSB = BN * 4 + 16;   // quad stride (+16: the 4 quads of a row-group hit 4 bank groups)
+  // quad stride = 4 * rows + LEAN_QPAD dwords.  ds_write_b128 is serviced in 8-lane groups and banks at (dword address)
+  // mod 32 (MI355X_MICROARCH.md, LDS): the 8 lanes of a group are the 4 k-quads of two consecutive rows, so the four
+  // planes must start 8 banks apart -- pad = 8 (mod 32).  (Rounds 1 - 4 used + 16, chosen for 64 banks: planes 0 / 2 and
+  // 1 / 3 then collide, every quad store took two passes -- the "LDS bank-conflict fraction 0.333" of every DGRAD
+  // instance and 0.11 - 0.17 of FWD in profiles/r0[2-4]_*_pmc.json.  Round 5, `tools/pmc_lds.sh base qpad8`, 3x3 256 -> 256
+  // at 1 536 images: SQ_LDS_BANK_CONFLICT 24.0 M -> 0 (DGRAD), 12.0 M -> 0 (FWD), SQ_LDS_IDX_ACTIVE 72 M -> 48 M / 60 M;
+  // the kernels' durations and every step time are unchanged -- the LDS array was never the limiter)
+  // Reads stay conflict-free for any 16-byte-aligned stride: a ds_read_b128 lane group holds 16 consecutive rows of ONE plane.
+  constexpr int QSA = BM * 4 + LEAN_QPAD, QSB = BN * 4 + LEAN_QPAD;
   constexpr int LDB = BN < 64 ? 64 : BN;                // row layout: >= 64 columns so the XOR-32 swizzle stays inside a row
   constexpr int A_SZ = A_Q ? 4 * QSA : 16 * BM;
   constexpr int B_SZ = B_Q ? 4 * QSB : 16 * LDB;
@@ -916,8 +928,8 @@ __global__ __launch_bounds__(NTHREADS, IGEMM_MIN_WAVES) void igemm_lean_kernel(c
 // smem: two buffers of A + B (<= 2 * (2112 + 2112) floats = 33 KB), or the epilogue's row table
 template <int MODE, int BM, int BN>
 constexpr size_t lean_smem_bytes() {
-  const int a = (MODE != MODE_WGRAD) ? 4 * (BM * 4 + 16) : 16 * BM;
-  const int b = (MODE == MODE_DGRAD) ? 4 * (BN * 4 + 16) : 16 * (BN < 64 ? 64 : BN);
+  const int a = (MODE != MODE_WGRAD) ? 4 * (BM * 4 + LEAN_QPAD) : 16 * BM;
+  const int b = (MODE == MODE_DGRAD) ? 4 * (BN * 4 + LEAN_QPAD) : 16 * (BN < 64 ? 64 : BN);
   size_t main_loop = 2 * (size_t)(a + b) * sizeof(float);
   size_t epi = (size_t)BM * sizeof(long long);
   return main_loop > epi ? main_loop : epi;

@@ -26,6 +26,13 @@ struct UpfirdnArgs {
   const float* act_ref;
   float* out2;
   float slope, gain;
+  // modulated-conv epilogue (contrad_upfirdn2d_modconv; mc_bias != NULL selects it):
+  // out = sqrt2 * lrelu_0.2(v * mc_demod[m,c] + mc_noise_w[0] * mc_noise[m,oy,ox] + mc_bias[c]) * mc_post[m,c]
+  const float* mc_demod;
+  const float* mc_noise;
+  const float* mc_noise_w;
+  const float* mc_bias;
+  const float* mc_post;
 };
 
 // epilogue store of VW consecutive channels at flat element offset `off` of the output
@@ -51,6 +58,25 @@ __device__ __forceinline__ void uf_store(const UpfirdnArgs& a, size_t off, float
 __device__ __forceinline__ void uf_store4(const UpfirdnArgs& a, size_t off, float4 v) {
   float t[4] = {v.x, v.y, v.z, v.w};
   uf_store<4>(a, off, t);
+}
+// the modulated-conv epilogue on 4 channels c..c+3 of output pixel `pix` (= (m * out_h + oy) * out_w + ox): the same
+// operations in the same order as modconv_epilogue_kernel (+ its post_scale), so the fused launch is bitwise the two passes
+__device__ __forceinline__ void mc_store4(const UpfirdnArgs& a, int m, size_t pix, int c, float4 v) {
+  const float g = 1.4142135623730951f;
+  if (a.mc_demod) {
+    const float4 d = *reinterpret_cast<const float4*>(a.mc_demod + (size_t)m * a.minor + c);
+    v.x *= d.x; v.y *= d.y; v.z *= d.z; v.w *= d.w;
+  }
+  const float nz = (a.mc_noise && a.mc_noise_w) ? a.mc_noise_w[0] * a.mc_noise[pix] : 0.f;
+  const float4 b = *reinterpret_cast<const float4*>(a.mc_bias + c);
+  v.x += nz + b.x; v.y += nz + b.y; v.z += nz + b.z; v.w += nz + b.w;
+  v.x = (v.x > 0.f ? v.x : 0.2f * v.x) * g; v.y = (v.y > 0.f ? v.y : 0.2f * v.y) * g;
+  v.z = (v.z > 0.f ? v.z : 0.2f * v.z) * g; v.w = (v.w > 0.f ? v.w : 0.2f * v.w) * g;
+  if (a.mc_post) {
+    const float4 q = *reinterpret_cast<const float4*>(a.mc_post + (size_t)m * a.minor + c);
+    v.x *= q.x; v.y *= q.y; v.z *= q.z; v.w *= q.w;
+  }
+  *reinterpret_cast<float4*>(a.out + pix * a.minor + c) = v;
 }
 
 constexpr int MAX_FIR = 8;
@@ -209,6 +235,15 @@ __global__ __launch_bounds__(256) void upfirdn4_u1d1_kernel(UpfirdnArgs a) {
       }
     }
   }
+  if (a.mc_bias) {       // uniform: the generator's upsampling StyledConv tail (blur -> demod + noise + bias + lrelu)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (oy0 + r < a.out_h && ox0 + q < a.out_w)
+          mc_store4(a, m, ((size_t)m * a.out_h + oy0 + r) * a.out_w + ox0 + q, c, acc[r][q]);
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -360,6 +395,48 @@ __global__ void lincomb_kernel(const float* __restrict__ x, const float* __restr
     y[i] = a * x[i] + bc * z[i];
 }
 
+// Weight tables of all modulated convs in one launch (contrad_modconv_tables): block = one 32 (cout) x 32 (cin) tile of one
+// layer, all T <= 9 taps; W[co][ci][t] rows are read contiguously (32 * T floats per cout), staged in LDS and written out
+// as rows of the packed layout (32 consecutive columns per row piece) in either orientation, plus the tile of wsq.
+struct ModconvMap { int start[CONTRAD_MODCONV_MAX_LAYERS + 1]; };
+constexpr int MCT_TAPS = 9;
+
+__global__ __launch_bounds__(256) void modconv_tables_kernel(contrad_modconv_batch b, ModconvMap map) {
+  __shared__ float tile[32][32 * MCT_TAPS + 1];
+  int l = 0;
+  while (l + 1 < b.n && (int)blockIdx.x >= map.start[l + 1]) ++l;
+  const contrad_modconv_layer& L = b.layers[l];
+  const int blk = blockIdx.x - map.start[l];
+  const int tiles_ci = (L.Cin + 31) / 32;
+  const int co0 = (blk / tiles_ci) * 32, ci0 = (blk % tiles_ci) * 32;
+  const int T = L.T;
+  const int ncoi = min(32, L.Cout - co0), ncii = min(32, L.Cin - ci0);
+  const int roww = ncii * T;                       // contiguous floats of one cout row inside the tile
+  for (int e = threadIdx.x; e < 32 * roww; e += 256) {
+    const int co = e / roww, r = e - co * roww;
+    tile[co][r] = (co < ncoi) ? L.w[((size_t)(co0 + co) * L.Cin + ci0) * T + r] * L.scale : 0.f;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < T * 1024; e += 256) {
+    const int t = e >> 10, a = (e >> 5) & 31, q = e & 31;          // q = fastest index (the output column)
+    if (!L.transposed) {                                             // row (t, ci = a), column co = q
+      if (a < ncii && q < ncoi) L.wp[((size_t)t * L.Cin + ci0 + a) * L.ldw + co0 + q] = tile[q][a * T + t];
+    } else {                                                         // row (t, co = a), column ci = q
+      if (a < ncoi && q < ncii) L.wp[((size_t)t * L.Cout + co0 + a) * L.ldw + ci0 + q] = tile[a][q * T + t];
+    }
+  }
+  if (L.wsq) {
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+      const int ci = e >> 5, co = e & 31;
+      if (ci < ncii && co < ncoi) {
+        float ss = 0.f;
+        for (int t = 0; t < T; ++t) { const float v = tile[co][ci * T + t]; ss = fmaf(v, v, ss); }
+        L.wsq[(size_t)(ci0 + ci) * L.Cout + co0 + co] = ss;
+      }
+    }
+  }
+}
+
 // PixelNorm: one wave per row
 __global__ void pixelnorm_kernel(const float* __restrict__ x, float* __restrict__ y, int M, int K) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -388,8 +465,8 @@ __global__ void nhwc_scale_kernel(const float* __restrict__ x, const float* __re
 
 __global__ void modconv_epilogue_kernel(const float* __restrict__ x, const float* __restrict__ demod,
                                         const float* __restrict__ noise, const float* __restrict__ noise_w,
-                                        const float* __restrict__ bias, float* __restrict__ y, int N, long long HW,
-                                        int K) {
+                                        const float* __restrict__ bias, const float* __restrict__ post,
+                                        float* __restrict__ y, int N, long long HW, int K) {
   const int k4n = K >> 2;
   const long long total = (long long)N * HW * k4n;
   const float nw = (noise && noise_w) ? noise_w[0] : 0.f;
@@ -409,6 +486,10 @@ __global__ void modconv_epilogue_kernel(const float* __restrict__ x, const float
     v.x += nz + b.x; v.y += nz + b.y; v.z += nz + b.z; v.w += nz + b.w;
     v.x = (v.x > 0.f ? v.x : 0.2f * v.x) * g; v.y = (v.y > 0.f ? v.y : 0.2f * v.y) * g;
     v.z = (v.z > 0.f ? v.z : 0.2f * v.z) * g; v.w = (v.w > 0.f ? v.w : 0.2f * v.w) * g;
+    if (post) {            // the consumer's weight modulation (its nhwc_scale pass) folded into this store
+      const float4 q = *reinterpret_cast<const float4*>(post + (size_t)n * K + k4 * 4);
+      v.x *= q.x; v.y *= q.y; v.z *= q.z; v.w *= q.w;
+    }
     reinterpret_cast<float4*>(y)[e] = v;
   }
 }
@@ -511,22 +592,38 @@ extern "C" int contrad_nhwc_dot(const float* a, const float* b, float* out, int 
   return 0;
 }
 
-extern "C" int contrad_modconv_epilogue(const float* x, const float* demod, const float* noise,
-                                        const float* noise_w, const float* bias, float* y, int N, long long HW,
-                                        int K, contrad_stream_t stream) {
-  CONTRAD_ARG(x && bias && y && N > 0 && HW > 0 && K > 0 && (K & 3) == 0);
-  long long grid = ((long long)N * HW * (K / 4) + 255) / 256;
-  if (grid > 16384) grid = 16384;
-  hipLaunchKernelGGL(modconv_epilogue_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, x, demod, noise,
-                     noise_w, bias, y, N, HW, K);
+extern "C" int contrad_modconv_tables(const contrad_modconv_batch* b, contrad_stream_t stream) {
+  CONTRAD_ARG(b && b->n > 0 && b->n <= CONTRAD_MODCONV_MAX_LAYERS);
+  ModconvMap map{};
+  for (int l = 0; l < b->n; ++l) {
+    const contrad_modconv_layer& L = b->layers[l];
+    CONTRAD_ARG(L.w && L.wp && L.Cout > 0 && L.Cin > 0 && L.T > 0 && L.T <= MCT_TAPS);
+    CONTRAD_ARG(L.ldw >= (L.transposed ? L.Cin : L.Cout));
+    map.start[l + 1] = map.start[l] + cdiv(L.Cout, 32) * cdiv(L.Cin, 32);
+  }
+  hipLaunchKernelGGL(modconv_tables_kernel, dim3(map.start[b->n]), dim3(256), 0, (hipStream_t)stream, *b, map);
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }
 
+extern "C" int contrad_modconv_epilogue(const float* x, const float* demod, const float* noise,
+                                        const float* noise_w, const float* bias, const float* post_scale, float* y,
+                                        int N, long long HW, int K, contrad_stream_t stream) {
+  CONTRAD_ARG(x && bias && y && N > 0 && HW > 0 && K > 0 && (K & 3) == 0);
+  long long grid = ((long long)N * HW * (K / 4) + 255) / 256;
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(modconv_epilogue_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, x, demod, noise,
+                     noise_w, bias, post_scale, y, N, HW, K);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+struct ModconvEpi { const float *demod, *noise, *noise_w, *bias, *post; };
+
 static int upfirdn2d_launch(const float* input, const float* kernel, float* out, int major, int in_h, int in_w,
                             int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
                             int pad_x1, int pad_y0, int pad_y1, const float* addend, const float* act_ref, float slope,
-                            float gain, float* out2, contrad_stream_t stream) {
+                            float gain, float* out2, contrad_stream_t stream, const ModconvEpi* mc = nullptr) {
   CONTRAD_ARG(input && kernel && (out || out2) && major > 0 && in_h > 0 && in_w > 0 && minor > 0);
   CONTRAD_ARG(kh > 0 && kw > 0 && kh <= MAX_FIR && kw <= MAX_FIR);
   CONTRAD_ARG(up_x > 0 && up_y > 0 && down_x > 0 && down_y > 0);
@@ -539,6 +636,7 @@ static int upfirdn2d_launch(const float* input, const float* kernel, float* out,
   a.out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) / down_y + 1;   // op/upfirdn2d_kernel.cu:227-228
   a.out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
   a.addend = addend; a.act_ref = act_ref; a.out2 = out2; a.slope = slope; a.gain = gain;
+  if (mc) { a.mc_demod = mc->demod; a.mc_noise = mc->noise; a.mc_noise_w = mc->noise_w; a.mc_bias = mc->bias; a.mc_post = mc->post; }
   CONTRAD_ARG(a.out_h > 0 && a.out_w > 0);
   hipStream_t s = (hipStream_t)stream;
   const bool vec = (minor & 3) == 0;
@@ -549,6 +647,7 @@ static int upfirdn2d_launch(const float* input, const float* kernel, float* out,
     CONTRAD_CHECK_LAUNCH();
     return 0;
   }
+  CONTRAD_ARG(!mc);          // the modulated-conv epilogue exists on the 4x4-FIR blur path only
   if (fir4 && ((up_x == 1 && down_x == 2) || (up_x == 2 && down_x == 1))) {
     const long long tot = (long long)major * ((a.out_h + 1) / 2) * ((a.out_w + 1) / 2) * (minor / 4);
     if (down_x == 2) hipLaunchKernelGGL(upfirdn4_u1d2_kernel, dim3((unsigned)cdivll(tot, 256)), dim3(256), 0, s, a);
@@ -587,6 +686,16 @@ extern "C" int contrad_upfirdn2d_fused(const float* input, const float* kernel, 
                                        contrad_stream_t stream) {
   return upfirdn2d_launch(input, kernel, out, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0,
                           pad_x1, pad_y0, pad_y1, addend, act_ref, slope, gain, out2, stream);
+}
+
+extern "C" int contrad_upfirdn2d_modconv(const float* input, const float* kernel, float* y, int N, int in_h, int in_w,
+                                         int K, int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* demod,
+                                         const float* noise, const float* noise_w, const float* bias,
+                                         const float* post_scale, contrad_stream_t stream) {
+  CONTRAD_ARG(y && bias && K > 0 && (K & 3) == 0);
+  const ModconvEpi mc{demod, noise, noise_w, bias, post_scale};
+  return upfirdn2d_launch(input, kernel, y, N, in_h, in_w, K, 4, 4, 1, 1, 1, 1, pad_x0, pad_x1, pad_y0, pad_y1, nullptr,
+                          nullptr, 1.f, 1.f, nullptr, stream, &mc);
 }
 
 extern "C" int contrad_fused_bias_act(const float* x, const float* bias, const float* ref, float* y, long long n,

@@ -329,8 +329,8 @@ class _BNReLUFn(torch.autograd.Function):
             dist.all_reduce(stats)
             count *= dist.get_world_size()
         if bn.training:
-            ops.bn_running_update(stats, count, conv_bias, bn.momentum, bn.running_mean, bn.running_var)
-            bn.num_batches_tracked += 1
+            ops.bn_running_update(stats, count, conv_bias, bn.momentum, bn.running_mean, bn.running_var,
+                                  bn.num_batches_tracked)
         y = torch.empty_like(x2d)
         ops.bn_relu_apply(x2d, y, stats, count, gamma, beta, bn.eps)
         ctx.save_for_backward(x2d, stats, gamma, beta)
@@ -430,8 +430,8 @@ class G_SNDCGAN(nn.Module):
             dist.all_reduce(stats)
             count *= dist.get_world_size()
         if self.training:
-            ops.bn_running_update(stats, count, conv_bias, bn.momentum, bn.running_mean, bn.running_var)
-            bn.num_batches_tracked += 1
+            ops.bn_running_update(stats, count, conv_bias, bn.momentum, bn.running_mean, bn.running_var,
+                                  bn.num_batches_tracked)
         ops.bn_relu_apply(x2d, out2d, stats, count, bn.weight, bn.bias, bn.eps, perm_hw)
 
     def _forward_with_grad(self, z):

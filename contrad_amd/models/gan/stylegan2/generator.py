@@ -26,6 +26,12 @@ from .... import autograd_ops as A
 from ....hostio import upload
 
 
+# dev / test switch: the forward-only path with the upsampling StyledConv's blur + epilogue in one launch and the next
+# layer's modulation folded into the producer's store (True), or as separate passes (False; bitwise the same images)
+LEGACY_PREP = __import__('os').environ.get('CONTRAD_DEV_G_PREP', '') == 'legacy'       # (same-box A/B runs of bench.py)
+FUSE_TAIL = __import__('os').environ.get('CONTRAD_DEV_G_FUSE', '1') != '0'      # (same-box A/B runs of bench.py)
+
+
 class _EqualLinearParams(nn.Module):
     """EqualLinear (stylegan2/layers.py:132-154)."""
 
@@ -215,46 +221,126 @@ class Generator(nn.Module):
             return len(groups) - 1
 
         c = {'style': [], 'mod': {}, 'conv': {}, 'wsq': {}, 'differentiable': differentiable}
-        with torch.set_grad_enabled(differentiable):
-            for m in list(self.style)[1:]:
-                c['style'].append((add(m.weight, m.weight.shape[0], m.weight.shape[1], 1, m.scale),
-                                   (m.bias * m.lr_mul).contiguous()))
-            for mc in self._modconvs():
-                mod = mc.modulation
-                c['mod'][mc] = (add(mod.weight, mod.weight.shape[0], mod.weight.shape[1], 1, mod.scale),
-                                (mod.bias * mod.lr_mul + mod.bias_init).contiguous())
-                w = mc.weight[0]                                  # (Cout, Cin, k, k)
-                k = mc.kernel_size
-                if mc.upsample or mc.out_channel == 3:            # transposed conv / ToRGB == dgrad of the
-                    #                                               (K = Cin, C = Cout) conv: pack rows (tap, cout), cols cin
-                    c['conv'][mc] = add(w.transpose(0, 1).contiguous(), mc.in_channel, mc.out_channel, k * k, mc.scale)
-                else:
-                    c['conv'][mc] = add(w.contiguous(), mc.out_channel, mc.in_channel, k * k, mc.scale)
-                if mc.demodulate:                                 # Wsq[c][k] = scale^2 * sum_taps W[k,c,:,:]^2
-                    c['wsq'][mc] = ((w * mc.scale).pow(2).sum((2, 3)).t().contiguous())
-            if not differentiable:
-                # all modulation linears side by side in ONE [style_dim][sum C_in] matrix: the forward-only path gets every
-                # layer's style vector from a single GEMM over the (B * n_latent) latent rows instead of one split-K GEMM
-                # + reduce per layer (11 / 19 launch pairs of ~29 us at 32^2 / 512^2)
-                mcs = self._modconvs()
-                tot = sum(mc.in_channel for mc in mcs)
-                groups.append((self.style_dim, ops.round_up(tot, 4)))
-                gi, off, c['mod_cols'] = len(groups) - 1, 0, {}
-                for mc in mcs:
-                    mod = mc.modulation
-                    ws.append(mod.weight)
-                    entries.append((mc.in_channel, self.style_dim, 1, mod.scale, gi, off))
-                    c['mod_cols'][mc] = (off, mc.in_channel)
-                    off += mc.in_channel
-                c['mod_all'] = gi
-                pad = ops.round_up(tot, 4) - tot
-                c['mod_bias_all'] = torch.cat([c['mod'][mc][1] for mc in mcs] +
-                                              ([torch.zeros(pad, device=dev)] if pad else []))
-            packed = A.PackWeightsFn.apply(A.PackMeta(entries, groups), *ws)
-        c['packed'] = packed
-        if not differentiable:
+        if not differentiable and not LEGACY_PREP:
+            with torch.no_grad():
+                self._prepare_forward_only(c, add, ws, entries, groups, dev)
             self._cache_key, self._cache = key, c
+            return c
+        if not differentiable:          # dev A/B only: the per-layer ATen construction of rounds 1 - 4 under no_grad
+            with torch.no_grad():
+                self._prepare_legacy(c, add, ws, entries, groups, dev)
+            self._cache_key, self._cache = key, c
+            return c
+        self._prepare_per_layer(c, add)
+        c['packed'] = A.PackWeightsFn.apply(A.PackMeta(entries, groups), *ws)
         return c
+
+    def _prepare_per_layer(self, c, add):
+        for m in list(self.style)[1:]:
+            c['style'].append((add(m.weight, m.weight.shape[0], m.weight.shape[1], 1, m.scale),
+                               (m.bias * m.lr_mul).contiguous()))
+        for mc in self._modconvs():
+            mod = mc.modulation
+            c['mod'][mc] = (add(mod.weight, mod.weight.shape[0], mod.weight.shape[1], 1, mod.scale),
+                            (mod.bias * mod.lr_mul + mod.bias_init).contiguous())
+            w = mc.weight[0]                                  # (Cout, Cin, k, k)
+            k = mc.kernel_size
+            if mc.upsample or mc.out_channel == 3:            # transposed conv / ToRGB == dgrad of the
+                #                                               (K = Cin, C = Cout) conv: pack rows (tap, cout), cols cin
+                c['conv'][mc] = add(w.transpose(0, 1).contiguous(), mc.in_channel, mc.out_channel, k * k, mc.scale)
+            else:
+                c['conv'][mc] = add(w.contiguous(), mc.out_channel, mc.in_channel, k * k, mc.scale)
+            if mc.demodulate:                                 # Wsq[c][k] = scale^2 * sum_taps W[k,c,:,:]^2
+                c['wsq'][mc] = ((w * mc.scale).pow(2).sum((2, 3)).t().contiguous())
+
+    def _prepare_legacy(self, c, add, ws, entries, groups, dev):
+        self._prepare_per_layer(c, add)
+        mcs = self._modconvs()
+        tot = sum(mc.in_channel for mc in mcs)
+        groups.append((self.style_dim, ops.round_up(tot, 4)))
+        gi, off, c['mod_cols'] = len(groups) - 1, 0, {}
+        for mc in mcs:
+            mod = mc.modulation
+            ws.append(mod.weight)
+            entries.append((mc.in_channel, self.style_dim, 1, mod.scale, gi, off))
+            c['mod_cols'][mc] = (off, mc.in_channel)
+            off += mc.in_channel
+        c['mod_all'] = gi
+        pad = ops.round_up(tot, 4) - tot
+        c['mod_bias_all'] = torch.cat([c['mod'][mc][1] for mc in mcs] + ([torch.zeros(pad, device=dev)] if pad else []))
+        c['packed'] = A.PackWeightsFn.apply(A.PackMeta(entries, groups), *ws)
+
+    def _prepare_forward_only(self, c, add, ws, entries, groups, dev):
+        """The tables of the no-grad forward in a handful of launches (G moves between two discriminator steps, so a captured
+        D-step rebuilds them on every replay): every bias of the mapping network and of the modulation linears from ONE
+        concatenation + ONE multiply-add against cached constant vectors (was: 1 - 2 elementwise launches per layer); the
+        mapping weights and all modulation linears side by side -- ONE [style_dim][sum C_in] matrix, so every layer's
+        style vector comes from a single GEMM over the (B * n_latent) latent rows -- through the batched pack kernel; the
+        shared conv weights in their GEMM layouts and the demodulation tables Wsq from ONE launch
+        (contrad_modconv_tables; was: a transposed copy per upsampling / ToRGB layer and mul, pow, sum, transpose-copy
+        per demodulated layer: ~130 launches at 512^2, ~65 at 32^2)."""
+        mcs = self._modconvs()
+        styles = list(self.style)[1:]
+        # -- biases
+        raw = [m.bias for m in styles] + [mc.modulation.bias for mc in mcs]
+        sizes = [b.numel() for b in raw]
+        tot = sum(mc.in_channel for mc in mcs)
+        pad = ops.round_up(tot, 4) - tot
+        kc = (tuple(sizes), pad, str(dev))
+        if getattr(self, '_bias_consts_key', None) != kc:
+            mul = torch.cat([torch.full((m.bias.numel(),), float(m.lr_mul)) for m in styles] +
+                            [torch.full((mc.modulation.bias.numel(),), float(mc.modulation.lr_mul)) for mc in mcs] +
+                            [torch.zeros(pad)])
+            addv = torch.cat([torch.zeros(m.bias.numel()) for m in styles] +
+                             [torch.full((mc.modulation.bias.numel(),), float(mc.modulation.bias_init)) for mc in mcs] +
+                             [torch.zeros(pad)])
+            self._bias_consts, self._bias_consts_key = (mul.to(dev), addv.to(dev)), kc
+        mul, addv = self._bias_consts
+        flat = torch.cat(raw + ([addv[:pad]] if pad else []))
+        biases = torch.addcmul(addv, flat, mul)                     # bias * lr_mul + bias_init, all layers at once
+        off = 0
+        for m in styles:
+            n = m.bias.numel()
+            c['style'].append((add(m.weight, m.weight.shape[0], m.weight.shape[1], 1, m.scale), biases[off:off + n]))
+            off += n
+        c['mod_bias_all'] = biases[off:]
+        # -- all modulation linears as one packed matrix
+        groups.append((self.style_dim, ops.round_up(tot, 4)))
+        gi, off, c['mod_cols'] = len(groups) - 1, 0, {}
+        for mc in mcs:
+            mod = mc.modulation
+            ws.append(mod.weight)
+            entries.append((mc.in_channel, self.style_dim, 1, mod.scale, gi, off))
+            c['mod_cols'][mc] = (off, mc.in_channel)
+            off += mc.in_channel
+        c['mod_all'] = gi
+        packed = list(A.PackWeightsFn.apply(A.PackMeta(entries, groups), *ws))
+        # -- shared conv weights + demodulation tables: one flat buffer each, one launch
+        shapes, wsq_n = [], 0
+        for mc in mcs:
+            T = mc.kernel_size ** 2
+            tr = bool(mc.upsample or mc.out_channel == 3)
+            rows, cols = (T * mc.out_channel, mc.in_channel) if tr else (T * mc.in_channel, mc.out_channel)
+            shapes.append((rows, ops.round_up(cols, 4), cols, tr))
+            wsq_n += mc.in_channel * mc.out_channel if mc.demodulate else 0
+        if any(ld != cols for _, ld, cols, _ in shapes):
+            raise NotImplementedError('modulated conv with a channel count that is not a multiple of 4')
+        wflat = torch.empty(sum(r * ld for r, ld, _, _ in shapes), device=dev, dtype=torch.float32)
+        qflat = torch.empty(max(wsq_n, 4), device=dev, dtype=torch.float32)
+        layers, wo, qo = [], 0, 0
+        for mc, (rows, ld, cols, tr) in zip(mcs, shapes):
+            wp = wflat[wo:wo + rows * ld].view(rows, ld)
+            wo += rows * ld
+            wsq = None
+            if mc.demodulate:
+                wsq = qflat[qo:qo + mc.in_channel * mc.out_channel].view(mc.in_channel, mc.out_channel)
+                qo += mc.in_channel * mc.out_channel
+                c['wsq'][mc] = wsq
+            packed.append(wp)
+            c['conv'][mc] = len(packed) - 1
+            layers.append((mc.weight[0], wp, wsq, tr, mc.scale))
+        ops.modconv_tables(layers)
+        c['packed'] = packed
 
     def _all_styles(self, latents, c):
         """Forward-only path: ({modconv: (B, C_in) style}, {modconv: (B, C_out) demodulation factor}).  One GEMM over the
@@ -364,7 +450,12 @@ class Generator(nn.Module):
             out = out + up.view(B, C, 2 * H, 2 * W)
         return out
 
-    def _styled_conv(self, layer, x, w_lat, noise, c, s=None, demod=None):
+    def _styled_conv(self, layer, x, w_lat, noise, c, s=None, demod=None, post=None, prescaled=False):
+        """Forward-only StyledConv.  ``post``: the style vector of the ONE layer that consumes the output -- its weight
+        modulation rides on this layer's epilogue store (the upsampling conv of a resolution feeds only that resolution's
+        second conv; outputs that also feed a ToRGB stay unscaled); ``prescaled``: x arrived already modulated that way.
+        The upsampling layer's blur and its epilogue are one launch (ops.upfirdn2d_modconv): per resolution two passes
+        over the activation less than blur -> epilogue -> nhwc_scale (FUSE_TAIL = False restores them: same bits)."""
         mc = layer.conv
         B, H, W, _ = x.shape
         if s is None:
@@ -373,18 +464,24 @@ class Generator(nn.Module):
             wsq = c['wsq'][mc]
             d = ops.conv2d_fwd((s * s).view(B, 1, 1, -1), wsq, None, mc.out_channel, 1, 1, 1, 0).view(B, -1)
             demod = torch.rsqrt(d + 1e-8)
-        xm = ops.nhwc_scale(x, s)
+        xm = x if prescaled else ops.nhwc_scale(x, s)
         wp = c['packed'][c['conv'][mc]]
+        oh, ow = (2 * H, 2 * W) if mc.upsample else (H, W)
+        if noise is None:
+            noise = torch.empty(B, 1, oh, ow, device=x.device).normal_()                   # generator.py:91-92
+        noise = noise.expand(B, 1, oh, ow).contiguous()
         if mc.upsample:
             y = ops.conv2d_dgrad(xm, wp, (B, 2 * H + 1, 2 * W + 1, mc.out_channel), 3, 3, 2, 0)
             p0, p1 = mc.blur.pad
+            if FUSE_TAIL and mc.out_channel % 4 == 0:
+                return ops.upfirdn2d_modconv(y, mc.blur.kernel, (p0, p1, p0, p1), demod, noise, layer.noise.weight,
+                                             layer.activate.bias, post)
             y = ops.upfirdn2d(y, mc.blur.kernel, 1, 1, (p0, p1, p0, p1))
         else:
             y = ops.conv2d_fwd(xm, wp, None, mc.out_channel, 3, 3, 1, 1)
-        if noise is None:
-            noise = torch.empty(B, 1, y.shape[1], y.shape[2], device=y.device).normal_()   # generator.py:91-92
-        noise = noise.expand(B, 1, y.shape[1], y.shape[2]).contiguous()
-        return ops.modconv_epilogue_(y, demod, noise, layer.noise.weight, layer.activate.bias)
+        if post is not None and not FUSE_TAIL:
+            return ops.nhwc_scale(ops.modconv_epilogue_(y, demod, noise, layer.noise.weight, layer.activate.bias), post)
+        return ops.modconv_epilogue_(y, demod, noise, layer.noise.weight, layer.activate.bias, post_scale=post)
 
     def _to_rgb(self, trgb, x, w_lat, skip, c, final=False, s=None):
         mc = trgb.conv
@@ -453,8 +550,11 @@ class Generator(nn.Module):
         skip = self._to_rgb(self.to_rgb1, x, None, None, c, final=last, s=st[self.to_rgb1.conv])
         for j in range(len(self.to_rgbs)):
             la, lb, tr = self.layers[2 * j], self.layers[2 * j + 1], self.to_rgbs[j]
-            x = self._styled_conv(la, x, None, noise[1 + 2 * j], c, s=st[la.conv], demod=dm.get(la.conv))
-            x = self._styled_conv(lb, x, None, noise[2 + 2 * j], c, s=st[lb.conv], demod=dm.get(lb.conv))
+            # la's output feeds lb only: lb's weight modulation is la's post-scale, lb takes its input as it comes
+            x = self._styled_conv(la, x, None, noise[1 + 2 * j], c, s=st[la.conv], demod=dm.get(la.conv),
+                                  post=st[lb.conv])
+            x = self._styled_conv(lb, x, None, noise[2 + 2 * j], c, s=st[lb.conv], demod=dm.get(lb.conv),
+                                  prescaled=True)
             skip = self._to_rgb(tr, x, None, skip, c, final=(j == len(self.to_rgbs) - 1), s=st[tr.conv])
         image = skip                                                                        # 0.5*x+0.5 fused above
         if not self.training:

@@ -416,10 +416,12 @@ def bn_relu_apply(x2d, y2d, stats, count, gamma, beta, eps=1e-5, perm_hw=1):
     return y2d
 
 
-def bn_running_update(stats, count, conv_bias, momentum, running_mean, running_var):
+def bn_running_update(stats, count, conv_bias, momentum, running_mean, running_var, num_batches_tracked=None):
     K = running_mean.numel()
+    if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
+        raise RuntimeError('contrad_hip: num_batches_tracked must be an int64 tensor on the device')
     lib().call('contrad_bn_running_update', _p(stats), float(count), K, _p(conv_bias), float(momentum),
-               _p(running_mean), _p(running_var), _stream())
+               _p(running_mean), _p(running_var), _p(num_batches_tracked), _stream())
 
 
 GAN_LOSS_KINDS = {'nonsat': 0, 'wgan': 1, 'hinge': 2, 'lsgan': 3}
@@ -650,12 +652,46 @@ def nhwc_scale(x, s):
     return y
 
 
-def modconv_epilogue_(x, demod, noise, noise_w, bias, out=None):
-    """sqrt2 * lrelu_0.2(x * demod + noise_w * noise + bias) on x (N,H,W,K); in place unless ``out`` is given."""
+def modconv_tables(layers):
+    """``layers``: list of (w [Cout][Cin][T] contiguous, wp packed view, wsq [Cin][Cout] or None, transposed, scale).
+    One launch (per 32 layers) writes every packed shared weight and demodulation table of the generator."""
+    from ._lib import ModconvBatch, MODCONV_MAX_LAYERS
+    for start in range(0, len(layers), MODCONV_MAX_LAYERS):
+        chunk = layers[start:start + MODCONV_MAX_LAYERS]
+        b = ModconvBatch()
+        b.n = len(chunk)
+        for j, (w, wp, wsq, transposed, scale) in enumerate(chunk):
+            _chk(w, 'w'); _chk(wp, 'wp'); _chk(wsq, 'wsq')
+            if not w.is_contiguous() or wp.stride(1) != 1 or (wsq is not None and not wsq.is_contiguous()):
+                raise RuntimeError('contrad_hip: modconv_tables needs a contiguous weight / table and unit-stride packed columns')
+            L = b.layers[j]
+            L.w, L.wp, L.wsq = w.data_ptr(), wp.data_ptr(), (wsq.data_ptr() if wsq is not None else None)
+            L.Cout, L.Cin, L.T = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+            L.ldw, L.transposed, L.scale = wp.stride(0), int(bool(transposed)), float(scale)
+        lib().call('contrad_modconv_tables', ctypes.byref(b), _stream())
+
+
+def modconv_epilogue_(x, demod, noise, noise_w, bias, out=None, post_scale=None):
+    """sqrt2 * lrelu_0.2(x * demod + noise_w * noise + bias) [* post_scale[n,k]] on x (N,H,W,K); in place unless ``out``
+    is given.  ``post_scale``: the consuming layer's style vector (its nhwc_scale pass folded into this store)."""
     N, H, W, K = x.shape
     out = x if out is None else out
-    lib().call('contrad_modconv_epilogue', _p(x), _p(demod), _p(noise), _p(noise_w), _p(bias), _p(out), N,
+    lib().call('contrad_modconv_epilogue', _p(x), _p(demod), _p(noise), _p(noise_w), _p(bias), _p(post_scale), _p(out), N,
                ctypes.c_longlong(H * W), K, _stream())
+    return out
+
+
+def upfirdn2d_modconv(x, kernel, pad, demod, noise, noise_w, bias, post_scale=None):
+    """Blur (4x4 FIR, up = down = 1, pad = (x0, x1, y0, y1)) followed by modconv_epilogue_ in ONE launch: the tail of the
+    generator's upsampling StyledConv (generator.py:80-83,97-118).  x (N,H,W,K) NHWC -> (N,H',W',K)."""
+    _chk(x, 'x'); _chk(kernel, 'kernel')
+    if tuple(kernel.shape) != (4, 4) or not x.is_contiguous():
+        raise RuntimeError('contrad_hip: upfirdn2d_modconv needs a dense NHWC input and the 4x4 FIR')
+    N, H, W, K = x.shape
+    oh, ow = H + pad[2] + pad[3] - 4 + 1, W + pad[0] + pad[1] - 4 + 1
+    out = torch.empty(N, oh, ow, K, device=x.device, dtype=torch.float32)
+    lib().call('contrad_upfirdn2d_modconv', _p(x), _p(kernel), _p(out), N, H, W, K, int(pad[0]), int(pad[1]), int(pad[2]),
+               int(pad[3]), _p(demod), _p(noise), _p(noise_w), _p(bias), _p(post_scale), _stream())
     return out
 
 

@@ -218,8 +218,11 @@ int contrad_bn_relu_bwd_stats(const float* dy, const float* x, long long M, int 
 int contrad_bn_relu_bwd_apply(const float* dy, const float* x, float* dx, long long M, int K, int ld,
                               const float* stats, float count, const float* gamma, const float* beta, float eps,
                               const float* bstats, contrad_stream_t stream);
+/* running_mean / running_var update of nn.BatchNorm2d in train mode (unbiased variance); num_batches_tracked (int64
+ * scalar on the device, may be NULL) is incremented by the same launch. */
 int contrad_bn_running_update(const float* stats, float count, int K, const float* conv_bias, float momentum,
-                              float* running_mean, float* running_var, contrad_stream_t stream);
+                              float* running_mean, float* running_var, long long* num_batches_tracked,
+                              contrad_stream_t stream);
 /* contrad.loss_D_fn's GAN term (training/gan/contrad.py:51-64) on logits[3N] (stride ld): kind 0 nonsat,
  * 1 wgan, 2 hinge, 3 lsgan.  out3 = {loss, mean d_real, mean d_gen}; grad[3N] = d loss / d logits. */
 int contrad_gan_d_loss(const float* logits, int ld, int N, int kind, float* out3, float* grad,
@@ -345,6 +348,28 @@ int contrad_scale_dev(const float* x, const float* s, float c, float* y, long lo
 /* ------------------------------------------------------------------------------------------------
  * StyleGAN2 generator forward helpers (models/gan/stylegan2/generator.py).
  * ---------------------------------------------------------------------------------------------- */
+/* Forward-only weight tables of every ModulatedConv2d of the generator in ONE launch (generator.py:52-82): the packed
+ * shared weight wp = scale * W in the GEMM layout the conv engine reads, and the demodulation table
+ * wsq[c][k] = sum_taps (scale * W[k][c][tap])^2  (demod[n][k] = rsqrt(sum_c style[n][c]^2 wsq[c][k] + 1e-8)).
+ * W is ModulatedConv2d.weight[0] = [Cout][Cin][T] as stored (no transposed copy):
+ *   transposed == 0: wp[(tap * Cin + c)][k]  (k = cout; a plain conv: contrad_conv2d_fwd),
+ *   transposed != 0: wp[(tap * Cout + k)][c] (the upsampling layers' transposed conv = contrad_conv2d_dgrad, and ToRGB =
+ *                    contrad_rgb_conv_dgrad).  ldw = leading dimension of wp; columns past the last one are not written.
+ * wsq may be NULL (ToRGB does not demodulate). */
+#define CONTRAD_MODCONV_MAX_LAYERS 32
+typedef struct {
+  const float* w;
+  float* wp;
+  float* wsq;        /* [Cin][Cout] or NULL */
+  int Cout, Cin, T, ldw;
+  int transposed;
+  float scale;
+} contrad_modconv_layer;
+typedef struct {
+  int n;
+  contrad_modconv_layer layers[CONTRAD_MODCONV_MAX_LAYERS];
+} contrad_modconv_batch;
+int contrad_modconv_tables(const contrad_modconv_batch* b, contrad_stream_t stream);
 /* PixelNorm (stylegan2/layers.py:14-19): y = x * rsqrt(mean_c(x^2) + 1e-8) over rows of [M][K]. */
 int contrad_pixelnorm(const float* x, float* y, int M, int K, contrad_stream_t stream);
 /* y[n,h,w,c] = x[n,h,w,c] * s[n,c]: weight modulation moved onto the input channels of the shared-weight conv
@@ -353,9 +378,19 @@ int contrad_nhwc_scale(const float* x, const float* s, float* y, int N, long lon
                        contrad_stream_t stream);
 /* y = sqrt2 * lrelu_0.2( x * demod[n,k] + noise_w[0] * noise[n,h,w] + bias[k] ), in place allowed:
  * demodulation (generator.py:62-64) + NoiseInjection (:85-94) + FusedLeakyReLU (:113-118) in one pass.
- * demod / noise may be NULL. */
+ * demod / noise may be NULL.  post_scale [N,K] (may be NULL): y is additionally multiplied by post_scale[n,k] -- the
+ * style vector of the layer that consumes y, i.e. that layer's contrad_nhwc_scale pass folded into this store. */
 int contrad_modconv_epilogue(const float* x, const float* demod, const float* noise, const float* noise_w,
-                             const float* bias, float* y, int N, long long HW, int K, contrad_stream_t stream);
+                             const float* bias, const float* post_scale, float* y, int N, long long HW, int K,
+                             contrad_stream_t stream);
+/* The upsampling StyledConv's tail in ONE pass (generator.py:80-83,97-118: Blur after the transposed conv, then
+ * demodulation + NoiseInjection + FusedLeakyReLU):  y = modconv_epilogue( upfirdn2d(input; 4x4 FIR, up = down = 1) ),
+ * input [N,in_h,in_w,K] -> y [N,out_h,out_w,K]; demod [N,K] / noise [N,out_h,out_w] / post_scale [N,K] may be NULL.
+ * post_scale is the NEXT layer's style vector: its weight modulation (contrad_nhwc_scale) rides on this store. */
+int contrad_upfirdn2d_modconv(const float* input, const float* kernel, float* y, int N, int in_h, int in_w, int K,
+                              int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* demod, const float* noise,
+                              const float* noise_w, const float* bias, const float* post_scale,
+                              contrad_stream_t stream);
 /* out[n,c] = sum_hw a[n,hw,c] * b[n,hw,c] (b_per_channel != 0) or sum_hw a[n,hw,c] * b[n,hw] (b broadcast over the
  * channels): the gradients of the style vector, the demodulation factor and the noise strength in the backward of
  * ModulatedConv2d / NoiseInjection (generator.py:52-94; the reference gets them from autograd over its grouped

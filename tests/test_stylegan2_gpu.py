@@ -229,6 +229,87 @@ def test_generator_forward_against_reference(golden):
         assert out.shape == (5, 3, 32, 32) and torch.isfinite(out).all()
 
 
+@pytest.mark.parametrize('size,small32,n', [(32, True, 5), (64, False, 3)])
+def test_generator_fused_tail_equals_the_separate_passes(size, small32, n):
+    """The forward-only generator with the upsampling StyledConv's blur + demod / noise / bias / lrelu epilogue in one launch
+    and the next layer's weight modulation folded into the producer's store (generator.FUSE_TAIL) is BITWISE the sequence
+    blur -> modconv_epilogue -> nhwc_scale it replaces (same operations in the same order per element)."""
+    import contrad_amd.models.gan.stylegan2.generator as gen
+    G = gen.Generator(size=size, n_mlp=8, small32=small32).to(DEV).train()
+    torch.manual_seed(3)
+    z = torch.randn(n, G.style_dim, device=DEV)
+    noise = [torch.randn(n, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), device=DEV) for i in range(G.num_layers)]
+    mix = (torch.randn(n, G.style_dim, device=DEV), torch.randint(G.n_latent, (n,)))
+    saved = gen.FUSE_TAIL
+    try:
+        outs = []
+        for flag in (True, False):
+            gen.FUSE_TAIL = flag
+            with torch.no_grad():
+                outs.append(G(z, style_mix=0.9, noise=noise, _mix=mix).clone())
+    finally:
+        gen.FUSE_TAIL = saved
+    assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('shape', [(2, 9, 9, 8), (3, 17, 33, 32), (1, 65, 65, 64)])
+@pytest.mark.parametrize('with_opt', [True, False])
+def test_upfirdn2d_modconv_against_plain_torch(shape, with_opt):
+    """contrad_upfirdn2d_modconv (blur pad (1,1) + demod + noise + bias + lrelu * sqrt2 [* post]) against torch ops."""
+    from contrad_amd import ops
+    import torch.nn.functional as F
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, H, W, C, generator=g)
+    k1 = torch.tensor([1., 3., 3., 1.]); k = (k1[:, None] * k1[None, :]); k = k / k.sum() * 4.0
+    demod = torch.rand(B, C, generator=g) + 0.5 if with_opt else None
+    post = torch.randn(B, C, generator=g) if with_opt else None
+    nw = torch.tensor([0.3])
+    bias = torch.randn(C, generator=g)
+    oh, ow = H - 1, W - 1
+    noise = torch.randn(B, 1, oh, ow, generator=g) if with_opt else None
+    dv = lambda t: None if t is None else t.to(DEV)
+    got = ops.upfirdn2d_modconv(dv(x), dv(k), (1, 1, 1, 1), dv(demod), dv(noise), dv(nw), dv(bias), dv(post)).cpu()
+    ref = _upfirdn_ref(x, k, 1, 1, (1, 1, 1, 1))
+    if demod is not None:
+        ref = ref * demod[:, None, None, :]
+    if noise is not None:
+        ref = ref + nw * noise.view(B, oh, ow, 1)
+    ref = F.leaky_relu(ref + bias, 0.2) * math.sqrt(2.0)
+    if post is not None:
+        ref = ref * post[:, None, None, :]
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_modconv_tables_against_torch():
+    """contrad_modconv_tables: packed shared weights in both orientations + the demodulation tables of several layers
+    (ragged channel counts, 1x1 and 3x3, a 3-channel ToRGB) from one launch, against torch ops on the same weights."""
+    g = torch.Generator().manual_seed(8)
+    cfgs = [(64, 32, 3, False, True), (32, 64, 3, True, True), (3, 48, 1, True, False), (40, 36, 3, False, True),
+            (512, 512, 3, True, True), (128, 256, 1, False, False)]          # (Cout, Cin, k, transposed, demodulate)
+    layers, refs = [], []
+    for co, ci, k, tr, dm in cfgs:
+        w = torch.randn(co, ci, k, k, generator=g)
+        scale = 1.0 / math.sqrt(ci * k * k)
+        rows, cols = (k * k * co, ci) if tr else (k * k * ci, co)
+        wp = torch.full((rows, cols), float('nan'), device=DEV)
+        wsq = torch.full((ci, co), float('nan'), device=DEV) if dm else None
+        layers.append((w.to(DEV), wp, wsq, tr, scale))
+        ws = w * scale
+        if tr:       # rows (tap, cout), cols cin
+            ref_wp = ws.permute(2, 3, 0, 1).reshape(k * k * co, ci)
+        else:        # rows (tap, cin), cols cout
+            ref_wp = ws.permute(2, 3, 1, 0).reshape(k * k * ci, co)
+        refs.append((ref_wp, ws.pow(2).sum((2, 3)).t() if dm else None))
+    ops.modconv_tables(layers)
+    for (w, wp, wsq, tr, scale), (ref_wp, ref_wsq) in zip(layers, refs):
+        assert torch.equal(wp.cpu(), ref_wp)                      # one multiply per element: exact
+        if wsq is not None:
+            assert rel(wsq, ref_wsq) < 1e-6
+
+
 def _upfirdn_ref(x, k, up, down, pad):
     """Plain-torch upfirdn2d on NHWC (B,H,W,C) with pad = (x0, x1, y0, y1): zero insertion, (possibly negative) padding,
     correlation with the flipped kernel, decimation -- the contract of op/upfirdn2d_kernel.cu:209-243."""
