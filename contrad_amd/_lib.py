@@ -61,6 +61,17 @@ class ModconvBatch(ctypes.Structure):
     _fields_ = [('n', ctypes.c_int), ('layers', ModconvLayer * MODCONV_MAX_LAYERS)]
 
 
+class DemodLayer(ctypes.Structure):
+    """contrad_demod_layer."""
+    _fields_ = [('style', ctypes.c_void_p), ('wsq', ctypes.c_void_p), ('out', ctypes.c_void_p),
+                ('Cin', ctypes.c_int), ('K', ctypes.c_int)]
+
+
+class DemodBatch(ctypes.Structure):
+    """contrad_demod_batch."""
+    _fields_ = [('n', ctypes.c_int), ('B', ctypes.c_int), ('layers', DemodLayer * MODCONV_MAX_LAYERS)]
+
+
 _CTYPES = {
     'int': ctypes.c_int,
     'float': ctypes.c_float,

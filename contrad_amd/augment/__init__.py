@@ -86,6 +86,8 @@ class SimCLRAugment(nn.Module):
         if p_cutout is not None and (cutout_length is None or cutout_length % 2 == 0):
             raise ValueError("Currently CutOut only accepts odd lengths: length % 2 == 1")        # spatial.py:156-157
 
+    supports_out = True          # forward(x, out=...): the last stage writes into the caller's buffer (no-grad path)
+
     # ---- host-side sampling, reference draw order ----
     def sample(self, B, dim2, dim3):
         """Returns (params (B,12) CPU float tensor, contrast_first, sigma or None)."""
@@ -152,7 +154,7 @@ class SimCLRAugment(nn.Module):
         g = torch.exp(-xs.pow(2) / (2 * sigma ** 2))
         return radius, g / g.sum()
 
-    def apply(self, inputs, P, contrast_first, sigma=None):
+    def apply(self, inputs, P, contrast_first, sigma=None, out=None):
         """Deterministic device part."""
         Pd = upload(P, inputs.device)      # (B,12) parameter block (asynchronous pinned upload, contrad_amd/hostio.py)
         if inputs.requires_grad and torch.is_grad_enabled():
@@ -161,24 +163,28 @@ class SimCLRAugment(nn.Module):
                 radius, g = self.blur_kernel(inputs.shape[2], sigma)
                 if radius > 0:
                     blur = (radius, g.to(inputs.device))
+            if out is not None:
+                raise RuntimeError('augmentation: out= is a forward-only option')
             return _SimCLRFn.apply(inputs.contiguous().float(), Pd, contrast_first, self.r_c is not None, blur,
                                    self.cutout_length if self.p_cutout is not None else None)
         x = inputs.detach().contiguous().float()
-        out = ops.simclr_augment(x, Pd, contrast_first, self.r_c is not None)
+        radius = 0
         if sigma is not None:
             radius, g = self.blur_kernel(x.shape[2], sigma)
-            if radius > 0:
-                out = ops.gaussian_blur_masked(out, Pd, g.to(x.device), radius)
+        # ``out``: the LAST stage writes there (a caller's slice of a larger batch buffer: no concatenation afterwards)
+        res = ops.simclr_augment(x, Pd, contrast_first, self.r_c is not None, out=None if radius > 0 else out)
+        if radius > 0:
+            res = ops.gaussian_blur_masked(res, Pd, g.to(x.device), radius, out=out)
         if self.p_cutout is not None:
-            ops.cutout_masked_(out, Pd, self.cutout_length)
-        return out
+            ops.cutout_masked_(res, Pd, self.cutout_length)
+        return res
 
-    def forward(self, inputs):
+    def forward(self, inputs, out=None):
         if not inputs.is_cuda:
             raise RuntimeError('contrad_amd augmentation runs on the MI355X HIP path only (no CPU fallback)')
         B, _, d2, d3 = inputs.shape
         P, contrast_first, sigma = self.sample(B, d2, d3)
-        return self.apply(inputs, P, contrast_first, sigma)
+        return self.apply(inputs, P, contrast_first, sigma, out=out)
 
 
 def _kwargs_from_bindings():

@@ -437,6 +437,50 @@ __global__ __launch_bounds__(256) void modconv_tables_kernel(contrad_modconv_bat
   }
 }
 
+// Demodulation factors of all layers (contrad_modconv_demod): block = (layer, 256 output channels, 16 samples); the 16
+// squared style rows sit in LDS transposed ([c][16]: one broadcast ds_read_b128 x 4 per c), every thread owns one output
+// channel and streams its column of wsq (coalesced over the block), 16 accumulators.  Sum over c in ascending order.
+constexpr int DM_NB = 16, DM_MAXC = 512;
+__global__ __launch_bounds__(256) void modconv_demod_kernel(contrad_demod_batch b, ModconvMap map, float eps) {
+  __shared__ float4 s2[DM_MAXC][DM_NB / 4];
+  int l = 0;
+  while (l + 1 < b.n && (int)blockIdx.x >= map.start[l + 1]) ++l;
+  const contrad_demod_layer& L = b.layers[l];
+  const int blk = blockIdx.x - map.start[l];
+  const int kchunks = (L.K + 255) / 256;
+  const int k = (blk % kchunks) * 256 + threadIdx.x;
+  const int n0 = (blk / kchunks) * DM_NB;
+  float acc[DM_NB];
+#pragma unroll
+  for (int j = 0; j < DM_NB; ++j) acc[j] = 0.f;
+  for (int c0 = 0; c0 < L.Cin; c0 += DM_MAXC) {
+    const int cn = min(DM_MAXC, L.Cin - c0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < cn * DM_NB; e += 256) {
+      const int j = e / cn, c = e - j * cn;                       // consecutive threads: consecutive c of one sample
+      const float v = (n0 + j < b.B) ? L.style[(size_t)(n0 + j) * L.Cin + c0 + c] : 0.f;
+      reinterpret_cast<float*>(&s2[c][0])[j] = v * v;
+    }
+    __syncthreads();
+    if (k < L.K) {
+      for (int c = 0; c < cn; ++c) {
+        const float w = L.wsq[(size_t)(c0 + c) * L.K + k];
+#pragma unroll
+        for (int q = 0; q < DM_NB / 4; ++q) {
+          const float4 v = s2[c][q];
+          acc[4 * q] = fmaf(v.x, w, acc[4 * q]); acc[4 * q + 1] = fmaf(v.y, w, acc[4 * q + 1]);
+          acc[4 * q + 2] = fmaf(v.z, w, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(v.w, w, acc[4 * q + 3]);
+        }
+      }
+    }
+  }
+  if (k < L.K) {
+#pragma unroll
+    for (int j = 0; j < DM_NB; ++j)
+      if (n0 + j < b.B) L.out[(size_t)(n0 + j) * L.K + k] = rsqrtf(acc[j] + eps);
+  }
+}
+
 // PixelNorm: one wave per row
 __global__ void pixelnorm_kernel(const float* __restrict__ x, float* __restrict__ y, int M, int K) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -602,6 +646,19 @@ extern "C" int contrad_modconv_tables(const contrad_modconv_batch* b, contrad_st
     map.start[l + 1] = map.start[l] + cdiv(L.Cout, 32) * cdiv(L.Cin, 32);
   }
   hipLaunchKernelGGL(modconv_tables_kernel, dim3(map.start[b->n]), dim3(256), 0, (hipStream_t)stream, *b, map);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int contrad_modconv_demod(const contrad_demod_batch* b, float eps, contrad_stream_t stream) {
+  CONTRAD_ARG(b && b->n > 0 && b->n <= CONTRAD_MODCONV_MAX_LAYERS && b->B > 0);
+  ModconvMap map{};
+  for (int l = 0; l < b->n; ++l) {
+    const contrad_demod_layer& L = b->layers[l];
+    CONTRAD_ARG(L.style && L.wsq && L.out && L.Cin > 0 && L.K > 0);
+    map.start[l + 1] = map.start[l] + cdiv(L.K, 256) * cdiv(b->B, DM_NB);
+  }
+  hipLaunchKernelGGL(modconv_demod_kernel, dim3(map.start[b->n]), dim3(256), 0, (hipStream_t)stream, *b, map, eps);
   CONTRAD_CHECK_LAUNCH();
   return 0;
 }

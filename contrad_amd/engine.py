@@ -192,24 +192,37 @@ def d_step_stylegan2(P, G, D, opt_D, options, images, step, reducer=None, style_
     return d_loss, aux
 
 
+_MERGED_CALLS = __import__('os').environ.get('CONTRAD_DEV_MERGED', '1') != '0'       # (same-box A/B runs of bench.py)
+
+
 def loss_D_fn_separate(P, D, options, images, gen_images):
     """ContraD discriminator loss with the call structure of train_stylegan2_contraD.py (G_D.forward :138-164 and
     _loss_D_fn :95-109): the fakes (N) and the two real views (2N) are augmented SEPARATELY and go through D in two
     calls; the losses act on the concatenated embeddings.  Same return contract as contrad.loss_D_fn."""
     from .training.gan.contrad import _ContraDContrastive, _GanDLoss
     N = images.size(0)
-    aug_f = P.augment_fn(gen_images.detach())                       # (same RNG draw order as the two reference calls)
-    aug_r = P.augment_fn(torch.cat([images, images], dim=0))
-    if hasattr(D, 'call_batches'):
-        # the two calls as one pass over 3N images: only the minibatch-stddev statistics see the call boundary
-        (d_gen, aux_g), (d_real2, aux_r) = D.call_batches([aug_f, aug_r], sg_linear=True, projection=True,
-                                                          projection2=True)
+    if _MERGED_CALLS and hasattr(D, 'call_merged') and getattr(P.augment_fn, 'supports_out', False):
+        # the two calls as ONE pass over 3N images (only the minibatch-stddev statistics see the call boundary), laid out
+        # [real views 2N | fakes N] -- the order the losses want -- by letting each augmentation write its slice of one
+        # buffer: no concatenation of the batches, no split + re-concatenation of the outputs (forward and backward).
+        # Draw order as in the reference: the fakes' augmentation parameters first, then the real views'.
+        both = torch.empty((3 * N,) + tuple(images.shape[1:]), device=images.device, dtype=torch.float32)
+        P.augment_fn(gen_images.detach(), out=both[2 * N:])
+        P.augment_fn(torch.cat([images, images], dim=0), out=both[:2 * N])
+        d_all, aux = D.call_merged(both, [2 * N, N], sg_linear=True, projection=True, projection2=True)
+        proj, proj2 = aux['projection'], aux['projection2']
     else:
-        d_gen, aux_g = D(aug_f, sg_linear=True, projection=True, projection2=True)
-        d_real2, aux_r = D(aug_r, sg_linear=True, projection=True, projection2=True)
-    proj = torch.cat([aux_r['projection'], aux_g['projection']], dim=0)
-    proj2 = torch.cat([aux_r['projection2'], aux_g['projection2']], dim=0)
-    d_all = torch.cat([d_real2, d_gen], dim=0)
+        aug_f = P.augment_fn(gen_images.detach())                   # (same RNG draw order as the two reference calls)
+        aug_r = P.augment_fn(torch.cat([images, images], dim=0))
+        if hasattr(D, 'call_batches'):
+            (d_gen, aux_g), (d_real2, aux_r) = D.call_batches([aug_f, aug_r], sg_linear=True, projection=True,
+                                                              projection2=True)
+        else:
+            d_gen, aux_g = D(aug_f, sg_linear=True, projection=True, projection2=True)
+            d_real2, aux_r = D(aug_r, sg_linear=True, projection=True, projection2=True)
+        proj = torch.cat([aux_r['projection'], aux_g['projection']], dim=0)
+        proj2 = torch.cat([aux_r['projection2'], aux_g['projection2']], dim=0)
+        d_all = torch.cat([d_real2, d_gen], dim=0)
     simclr, sup = _ContraDContrastive.apply(proj, proj2, N, P.temp, bool(P.distributed))
     gan, d_real_m, d_gen_m = _GanDLoss.apply(d_all, N, options['loss'])
     return simclr + P.lbd_a * sup, {'penalty': gan, 'd_real': d_real_m, 'd_gen': d_gen_m}
@@ -382,22 +395,27 @@ class _StaticAugment(object):
                 _r, g = self.aug.blur_kernel(self.H, sigma)
                 self.taps[i].copy_(upload(g.view(1, -1), self.dev).view(-1))
 
-    def __call__(self, x):
+    supports_out = True          # (``out=``: the last stage writes into the caller's buffer, see SimCLRAugment.apply)
+
+    def __call__(self, x, out=None):
         from . import ops
         i, self.k = self.k, self.k + 1
         if x.shape[0] != self.sizes[i]:
             raise RuntimeError('captured step: augmentation call %d saw %d images, planned %d' % (i, x.shape[0], self.sizes[i]))
         if x.requires_grad and torch.is_grad_enabled():      # generator step: gradient flows through the augmentation
             from .augment import _SimCLRFn
+            if out is not None:
+                raise RuntimeError('augmentation: out= is a forward-only option')
             return _SimCLRFn.apply(x.contiguous().float(), self.blocks[i], -1, self.aug.r_c is not None,
                                    (self.radius, self.taps[i]) if self.taps is not None else None,
                                    self.aug.cutout_length if self.aug.p_cutout is not None else None)
-        out = ops.simclr_augment(x.detach().contiguous().float(), self.blocks[i], -1, self.aug.r_c is not None)
+        res = ops.simclr_augment(x.detach().contiguous().float(), self.blocks[i], -1, self.aug.r_c is not None,
+                                 out=None if self.taps is not None else out)
         if self.taps is not None:
-            out = ops.gaussian_blur_masked(out, self.blocks[i], self.taps[i], self.radius)
+            res = ops.gaussian_blur_masked(res, self.blocks[i], self.taps[i], self.radius, out=out)
         if self.aug.p_cutout is not None:
-            ops.cutout_masked_(out, self.blocks[i], self.aug.cutout_length)
-        return out
+            ops.cutout_masked_(res, self.blocks[i], self.aug.cutout_length)
+        return res
 
 
 class _StaticSG2Inputs(object):

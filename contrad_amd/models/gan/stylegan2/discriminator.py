@@ -398,6 +398,18 @@ class ResidualDiscriminatorP(BaseDiscriminator):
             return [(parts[i], auxs[i]) for i in range(len(sizes))]
         return list(torch.split(out, sizes, dim=0))
 
+    def call_merged(self, x, sizes, **flags):
+        """``call_batches`` for calls whose inputs already sit one after the other in ``x`` (sum(sizes) rows): returns the
+        MERGED result -- logits / embeddings of all calls in the row order of ``x`` -- so that a caller that wants them
+        concatenated anyway (train_stylegan2_contraD.py:95-109 concatenates real views and fakes before the losses) needs
+        neither the per-call split nor the concatenation, forward or backward."""
+        self._batch_splits = [int(n) for n in sizes]
+        try:
+            assert sum(self._batch_splits) == x.shape[0]
+            return self(x, **flags)
+        finally:
+            self._batch_splits = None
+
     # ---- weight packing plan -------------------------------------------------------------------------
     def _pack(self, fused=True):
         """``fused`` (both graph constructions use it): the skip weights carry the residual merge's 1/sqrt2 -- together

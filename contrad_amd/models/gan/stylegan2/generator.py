@@ -346,9 +346,8 @@ class Generator(nn.Module):
         """Forward-only path: ({modconv: (B, C_in) style}, {modconv: (B, C_out) demodulation factor}).  One GEMM over the
         B * n_latent latent rows gives every layer's style; ONE gather (a cached flat index) lays the row block of each
         layer's latent index out contiguously, layer after layer (was: one strided-slice copy per layer); the
-        demodulation factors rsqrt(sum_c s^2 Wsq + 1e-8) (generator.py:62-64) of all layers then take one squaring pass,
-        one small GEMM per layer into ONE buffer and one add + rsqrt over that buffer (was: 3 elementwise launches per
-        layer)."""
+        demodulation factors rsqrt(sum_c s^2 Wsq + 1e-8) (generator.py:62-64) of all layers come from ONE launch
+        (contrad_modconv_demod; rounds 2 - 4: a squaring pass, a split-K GEMM + reduce per layer, one add + rsqrt)."""
         B, L, D = latents.shape
         wp = c['packed'][c['mod_all']]
         cols = wp.shape[1]
@@ -377,21 +376,30 @@ class Generator(nn.Module):
         for mc, (o, n) in order:
             styles[mc] = flat[off:off + B * n].view(B, n)
             off += B * n
-        sq = flat * flat
         dem = [mc for mc, _ in order if mc.demodulate]
         dbuf = torch.empty(B * sum(mc.out_channel for mc in dem), device=out.device, dtype=torch.float32)
-        demods, doff, off = {}, 0, 0
-        offs = {}
-        for mc, (o, n) in order:
-            offs[mc] = off
-            off += B * n
+        demods, doff = {}, 0
+        if LEGACY_PREP:       # (dev A/B: squaring pass + one split-K GEMM and reduce per layer + add + rsqrt)
+            sq = flat * flat
+            offs, off = {}, 0
+            for mc, (o, n) in order:
+                offs[mc] = off
+                off += B * n
+        jobs = []
         for mc in dem:
             n_in, K = c['mod_cols'][mc][1], mc.out_channel
-            d = dbuf[doff:doff + B * K].view(B, 1, 1, K)
-            ops.conv2d_fwd(sq[offs[mc]:offs[mc] + B * n_in].view(B, 1, 1, n_in), c['wsq'][mc], None, K, 1, 1, 1, 0, out=d)
-            demods[mc] = d.view(B, K)
+            d = dbuf[doff:doff + B * K].view(B, K)
+            if LEGACY_PREP:
+                ops.conv2d_fwd(sq[offs[mc]:offs[mc] + B * n_in].view(B, 1, 1, n_in), c['wsq'][mc], None, K, 1, 1, 1, 0,
+                               out=d.view(B, 1, 1, K))
+            else:
+                jobs.append((styles[mc], c['wsq'][mc], d))
+            demods[mc] = d
             doff += B * K
-        torch.rsqrt_(dbuf.add_(1e-8))
+        if LEGACY_PREP:
+            torch.rsqrt_(dbuf.add_(1e-8))
+        else:
+            ops.modconv_demod(jobs, 1e-8)       # every layer's rsqrt(s^2 @ Wsq + 1e-8) in one launch
         return styles, demods
 
     # ---- pieces ----------------------------------------------------------------------------------------------

@@ -671,6 +671,25 @@ def modconv_tables(layers):
         lib().call('contrad_modconv_tables', ctypes.byref(b), _stream())
 
 
+def modconv_demod(layers, eps=1e-8):
+    """``layers``: list of (style [B][Cin] with contiguous rows, wsq [Cin][K], out [B][K]); one launch writes every
+    out = rsqrt(style^2 @ wsq + eps)."""
+    from ._lib import DemodBatch, MODCONV_MAX_LAYERS
+    for start in range(0, len(layers), MODCONV_MAX_LAYERS):
+        chunk = layers[start:start + MODCONV_MAX_LAYERS]
+        b = DemodBatch()
+        b.n, b.B = len(chunk), chunk[0][0].shape[0]
+        for j, (st, wsq, out) in enumerate(chunk):
+            _chk(st, 'style'); _chk(wsq, 'wsq'); _chk(out, 'out')
+            if (st.shape[0] != b.B or not st.is_contiguous() or not wsq.is_contiguous() or not out.is_contiguous()
+                    or st.shape[1] != wsq.shape[0] or tuple(out.shape) != (b.B, wsq.shape[1])):
+                raise RuntimeError('contrad_hip: modconv_demod needs contiguous [B][Cin] / [Cin][K] / [B][K] tensors')
+            L = b.layers[j]
+            L.style, L.wsq, L.out = st.data_ptr(), wsq.data_ptr(), out.data_ptr()
+            L.Cin, L.K = wsq.shape[0], wsq.shape[1]
+        lib().call('contrad_modconv_demod', ctypes.byref(b), float(eps), _stream())
+
+
 def modconv_epilogue_(x, demod, noise, noise_w, bias, out=None, post_scale=None):
     """sqrt2 * lrelu_0.2(x * demod + noise_w * noise + bias) [* post_scale[n,k]] on x (N,H,W,K); in place unless ``out``
     is given.  ``post_scale``: the consuming layer's style vector (its nhwc_scale pass folded into this store)."""

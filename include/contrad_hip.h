@@ -370,6 +370,20 @@ typedef struct {
   contrad_modconv_layer layers[CONTRAD_MODCONV_MAX_LAYERS];
 } contrad_modconv_batch;
 int contrad_modconv_tables(const contrad_modconv_batch* b, contrad_stream_t stream);
+/* Demodulation factors of ALL demodulated layers of one generator forward in one launch (generator.py:62-64):
+ * out_l[n][k] = rsqrt( sum_c style_l[n][c]^2 * wsq_l[c][k] + eps ), style_l [B][Cin] (rows contiguous), wsq_l [Cin][K]
+ * from contrad_modconv_tables, out_l [B][K].  (Was per layer: a squaring pass, a split-K GEMM + its reduce, add, rsqrt.) */
+typedef struct {
+  const float* style;
+  const float* wsq;
+  float* out;
+  int Cin, K;
+} contrad_demod_layer;
+typedef struct {
+  int n, B;
+  contrad_demod_layer layers[CONTRAD_MODCONV_MAX_LAYERS];
+} contrad_demod_batch;
+int contrad_modconv_demod(const contrad_demod_batch* b, float eps, contrad_stream_t stream);
 /* PixelNorm (stylegan2/layers.py:14-19): y = x * rsqrt(mean_c(x^2) + 1e-8) over rows of [M][K]. */
 int contrad_pixelnorm(const float* x, float* y, int M, int K, contrad_stream_t stream);
 /* y[n,h,w,c] = x[n,h,w,c] * s[n,c]: weight modulation moved onto the input channels of the shared-weight conv

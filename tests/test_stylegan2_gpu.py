@@ -310,6 +310,23 @@ def test_modconv_tables_against_torch():
             assert rel(wsq, ref_wsq) < 1e-6
 
 
+@pytest.mark.parametrize('B', [5, 16, 70])
+def test_modconv_demod_against_torch(B):
+    """contrad_modconv_demod: rsqrt(style^2 @ wsq + 1e-8) of several layers (ragged channel counts, Cin above one LDS
+    chunk) from one launch."""
+    g = torch.Generator().manual_seed(9)
+    jobs, refs = [], []
+    for cin, k in [(512, 512), (32, 64), (100, 36), (1024, 300), (64, 3)]:
+        st = torch.randn(B, cin, generator=g)
+        wsq = torch.rand(cin, k, generator=g) / cin
+        out = torch.full((B, k), float('nan'), device=DEV)
+        jobs.append((st.to(DEV), wsq.to(DEV), out))
+        refs.append(torch.rsqrt((st.double() ** 2) @ wsq.double() + 1e-8).float())
+    ops.modconv_demod(jobs, 1e-8)
+    for (st, wsq, out), ref in zip(jobs, refs):
+        assert rel(out, ref) < 1e-5
+
+
 def _upfirdn_ref(x, k, up, down, pad):
     """Plain-torch upfirdn2d on NHWC (B,H,W,C) with pad = (x0, x1, y0, y1): zero insertion, (possibly negative) padding,
     correlation with the flipped kernel, decimation -- the contract of op/upfirdn2d_kernel.cu:209-243."""
