@@ -8,6 +8,9 @@ TAG=${1:-r05}
 O=$R/gpurun_out/${TAG}p
 rm -rf $O; mkdir -p $O
 cd $R
+if [ -z "$SKIP_TESTS" ]; then     # the whole GPU suite first, every tolerance with the error actually observed (tests/conftest.py: margin)
+  (cd $R; rm -f $O/margins.txt; CONTRAD_MARGINS=$O/margins.txt timeout 1200 python -m pytest tests -q -m gpu > $O/pytest.log 2>&1; tail -3 $O/pytest.log)
+fi
 cd /tmp && export TMPDIR=/tmp
 for c in ${KT_CONFIGS-c10_b512 sg2_32 sg2_512}; do
   case $c in c10_b512) S="--steps 5 --warmup 3";; sg2_32) S="--steps 5 --warmup 3";; sg2_512) S="--steps 16 --warmup 2";; esac
@@ -50,6 +53,8 @@ for c in ${KT_CONFIGS-c10_b512 sg2_32 sg2_512}; do
   cp $O/${c}_under_rocprof.json $O/profiles/${TAG}_${c}_n1_under_rocprof.json
 done
 [ -f $O/bench_n1.json ] && tail -1 $O/bench_n1.json > $O/profiles/${TAG}_bench_n1.json
+[ -f $O/margins.txt ] && cp $O/margins.txt $O/profiles/${TAG}_test_margins.txt
+[ -f $O/pytest.log ] && tail -3 $O/pytest.log > $O/profiles/${TAG}_pytest_tail.txt
 cp profiles/${TAG}_*_pmc.* $O/profiles/ 2>/dev/null
 for B in ${RANK_BATCHES-256 128 64}; do
   cp $O/b${B}_rows.txt $O/profiles/${TAG}_c10_b${B}_rank_rows.txt; cp $O/b${B}_kernel_trace.txt $O/profiles/${TAG}_c10_b${B}_rank_kernel_trace.txt; cp $O/b${B}_shapes.json $O/profiles/${TAG}_c10_b${B}_rank_shapes.json
