@@ -308,6 +308,43 @@ __global__ __launch_bounds__(256) void upfirdn4_u1d2_kernel(UpfirdnArgs a) {
 // out[oy][ox] = sum_{ky,kx} k[ky][kx] z[oy + ky - pad_y0][ox + kx - pad_x0],  z[2i][2j] = in[i][j], zero elsewhere.
 // Each output sees a 2 x 2 subset of the taps; a thread produces the 2 x 2 output quad at (2 qy .. +1, 2 qx .. +1) from
 // the <= 3 x 3 input pixels it can touch (9 loads for 4 outputs instead of 16 tap tests each).
+// Which tap an (input pixel, output) pair uses depends only on the PARITY of the padding: with py_lo = 2 qy - pad_y0 and
+// iy_lo = ceil(py_lo / 2), the tap row of input row iy_lo + dy for output row 2 qy + r is  ky = PY + 2 dy - r,  PY =
+// pad_y0 & 1 -- the same for every thread of the launch.  PY / PX are template parameters, so every weight index is a
+// compile-time constant and the 16 weights stay in scalar registers.  (Rounds 2 - 4 computed ky / kx per thread: a
+// dynamically indexed private array, which the compiler promotes to LDS -- 16 KB per block, 36 ds_read_b32 per thread with
+// an LDS bank-conflict fraction of 0.937 in every PMC summary.)
+template <int PY, int PX>
+__device__ __forceinline__ void upfirdn4_u2d1_body(const UpfirdnArgs& a, const Fir4& f, const float* base, int iy_lo,
+                                                   int ix_lo, float4 (&acc)[2][2]) {
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int iy = iy_lo + dy;
+    const bool vy = (unsigned)iy < (unsigned)a.in_h;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ix = ix_lo + dx;
+      // (pixels that reach no output of the quad -- both tap indices out of range -- are not loaded at all)
+      const bool used_y = (PY + 2 * dy >= 0 && PY + 2 * dy <= 3) || (PY + 2 * dy - 1 >= 0 && PY + 2 * dy - 1 <= 3);
+      const bool used_x = (PX + 2 * dx >= 0 && PX + 2 * dx <= 3) || (PX + 2 * dx - 1 >= 0 && PX + 2 * dx - 1 <= 3);
+      if (!(used_y && used_x)) continue;
+      if (!(vy && (unsigned)ix < (unsigned)a.in_w)) continue;
+      const float4 v = *reinterpret_cast<const float4*>(base + ((size_t)iy * a.in_w + ix) * a.minor);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int ky = PY + 2 * dy - r;
+        if (ky < 0 || ky > 3) continue;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int kx = PX + 2 * dx - q;
+          if (kx < 0 || kx > 3) continue;
+          fma4(acc[r][q], f.w[ky * 4 + kx], v);
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void upfirdn4_u2d1_kernel(UpfirdnArgs a) {
   const Fir4 f = load_fir4(a.kernel);
   const int mv = a.minor >> 2;
@@ -329,6 +366,26 @@ __global__ __launch_bounds__(256) void upfirdn4_u2d1_kernel(UpfirdnArgs a) {
 #pragma unroll
   for (int r = 0; r < 2; ++r) { acc[r][0] = make_float4(0.f, 0.f, 0.f, 0.f); acc[r][1] = acc[r][0]; }
   const float* base = a.in + (size_t)m * a.in_h * a.in_w * a.minor + c;
+  // oy0 / ox0 are even: the parities are those of the paddings, uniform over the launch (a scalar branch)
+  const int par = ((a.pad_y0 & 1) << 1) | (a.pad_x0 & 1);
+  if (par == 0) upfirdn4_u2d1_body<0, 0>(a, f, base, iy_lo, ix_lo, acc);
+  else if (par == 1) upfirdn4_u2d1_body<0, 1>(a, f, base, iy_lo, ix_lo, acc);
+  else if (par == 2) upfirdn4_u2d1_body<1, 0>(a, f, base, iy_lo, ix_lo, acc);
+  else upfirdn4_u2d1_body<1, 1>(a, f, base, iy_lo, ix_lo, acc);
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (oy0 + r < a.out_h && ox0 + q < a.out_w)
+        uf_store4(a, (((size_t)m * a.out_h + oy0 + r) * a.out_w + ox0 + q) * a.minor + c, acc[r][q]);
+}
+
+// The same op on single-channel planes (minor == 1: the generator's RGB skip is upsampled as B * 3 planes, generator.py:
+// 121-143): one thread per 2 x 2 output quad, consecutive threads along x.  (Was the generic kernel: 16 tap tests with a
+// division each per output, 7 launches of 35 us per StyleGAN2_512 step for 50 MB.)
+template <int PY, int PX>
+__device__ __forceinline__ void upfirdn4_u2d1_plane_body(const UpfirdnArgs& a, const Fir4& f, const float* base, int iy_lo,
+                                                         int ix_lo, float (&acc)[2][2]) {
 #pragma unroll
   for (int dy = 0; dy < 3; ++dy) {
     const int iy = iy_lo + dy;
@@ -336,27 +393,53 @@ __global__ __launch_bounds__(256) void upfirdn4_u2d1_kernel(UpfirdnArgs a) {
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
       const int ix = ix_lo + dx;
+      const bool used_y = (PY + 2 * dy <= 3) || (PY + 2 * dy - 1 >= 0 && PY + 2 * dy - 1 <= 3);
+      const bool used_x = (PX + 2 * dx <= 3) || (PX + 2 * dx - 1 >= 0 && PX + 2 * dx - 1 <= 3);
+      if (!(used_y && used_x)) continue;
       if (!(vy && (unsigned)ix < (unsigned)a.in_w)) continue;
-      const float4 v = *reinterpret_cast<const float4*>(base + ((size_t)iy * a.in_w + ix) * a.minor);
+      const float v = base[(size_t)iy * a.in_w + ix];
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        const int ky = 2 * iy - (oy0 + r - a.pad_y0);
+        const int ky = PY + 2 * dy - r;
         if (ky < 0 || ky > 3) continue;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          const int kx = 2 * ix - (ox0 + q - a.pad_x0);
+          const int kx = PX + 2 * dx - q;
           if (kx < 0 || kx > 3) continue;
-          fma4(acc[r][q], f.w[ky * 4 + kx], v);
+          acc[r][q] = fmaf(f.w[ky * 4 + kx], v, acc[r][q]);
         }
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void upfirdn4_u2d1_planes_kernel(UpfirdnArgs a) {
+  const Fir4 f = load_fir4(a.kernel);
+  const int sx = (a.out_w + 1) >> 1, sy = (a.out_h + 1) >> 1;
+  const long long total = (long long)a.major * sy * sx;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int ox0 = (int)(e % sx) * 2;
+  const long long t = e / sx;
+  const int oy0 = (int)(t % sy) * 2;
+  const int m = (int)(t / sy);
+  const int py_lo = oy0 - a.pad_y0, px_lo = ox0 - a.pad_x0;
+  const int iy_lo = (py_lo + 1) >> 1, ix_lo = (px_lo + 1) >> 1;
+  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  const float* base = a.in + (size_t)m * a.in_h * a.in_w;
+  const int par = ((a.pad_y0 & 1) << 1) | (a.pad_x0 & 1);
+  if (par == 0) upfirdn4_u2d1_plane_body<0, 0>(a, f, base, iy_lo, ix_lo, acc);
+  else if (par == 1) upfirdn4_u2d1_plane_body<0, 1>(a, f, base, iy_lo, ix_lo, acc);
+  else if (par == 2) upfirdn4_u2d1_plane_body<1, 0>(a, f, base, iy_lo, ix_lo, acc);
+  else upfirdn4_u2d1_plane_body<1, 1>(a, f, base, iy_lo, ix_lo, acc);
 #pragma unroll
   for (int r = 0; r < 2; ++r)
 #pragma unroll
     for (int q = 0; q < 2; ++q)
-      if (oy0 + r < a.out_h && ox0 + q < a.out_w)
-        uf_store4(a, (((size_t)m * a.out_h + oy0 + r) * a.out_w + ox0 + q) * a.minor + c, acc[r][q]);
+      if (oy0 + r < a.out_h && ox0 + q < a.out_w) {
+        float v1[1] = {acc[r][q]};
+        uf_store<1>(a, ((size_t)m * a.out_h + oy0 + r) * a.out_w + ox0 + q, v1);
+      }
 }
 
 // y = act(x + b[(i / step_b) % size_b]) * scale  (grad 0) | x * act'(ref) * scale (grad 1) | 0 (grad 2)
@@ -437,19 +520,24 @@ __global__ __launch_bounds__(256) void modconv_tables_kernel(contrad_modconv_bat
   }
 }
 
-// Demodulation factors of all layers (contrad_modconv_demod): block = (layer, 256 output channels, 16 samples); the 16
-// squared style rows sit in LDS transposed ([c][16]: one broadcast ds_read_b128 x 4 per c), every thread owns one output
-// channel and streams its column of wsq (coalesced over the block), 16 accumulators.  Sum over c in ascending order.
-constexpr int DM_NB = 16, DM_MAXC = 512;
+// Demodulation factors of all layers (contrad_modconv_demod): block = (layer, 64 output channels, 16 samples); the 16
+// squared style rows sit in LDS transposed ([c][16]: broadcast ds_read_b128 x 4 per c); lane = output channel, the four
+// waves of a block split the Cin range and each streams its columns of wsq with 16 independent loads in flight (a
+// dependent load per c made the first version latency-bound: 120 us for 10 MB), 16 accumulators per thread; the four
+// partial sums are added in wave order through LDS.
+constexpr int DM_NB = 16, DM_MAXC = 512, DM_KB = 64;
 __global__ __launch_bounds__(256) void modconv_demod_kernel(contrad_demod_batch b, ModconvMap map, float eps) {
   __shared__ float4 s2[DM_MAXC][DM_NB / 4];
+  __shared__ float part[3][DM_NB][DM_KB];
   int l = 0;
   while (l + 1 < b.n && (int)blockIdx.x >= map.start[l + 1]) ++l;
   const contrad_demod_layer& L = b.layers[l];
   const int blk = blockIdx.x - map.start[l];
-  const int kchunks = (L.K + 255) / 256;
-  const int k = (blk % kchunks) * 256 + threadIdx.x;
+  const int kchunks = (L.K + DM_KB - 1) / DM_KB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = (blk % kchunks) * DM_KB + lane;
   const int n0 = (blk / kchunks) * DM_NB;
+  const bool kok = k < L.K;
   float acc[DM_NB];
 #pragma unroll
   for (int j = 0; j < DM_NB; ++j) acc[j] = 0.f;
@@ -462,22 +550,36 @@ __global__ __launch_bounds__(256) void modconv_demod_kernel(contrad_demod_batch 
       reinterpret_cast<float*>(&s2[c][0])[j] = v * v;
     }
     __syncthreads();
-    if (k < L.K) {
-      for (int c = 0; c < cn; ++c) {
-        const float w = L.wsq[(size_t)(c0 + c) * L.K + k];
+    const int per = (cn + 3) / 4, cb = wave * per, ce = min(cn, cb + per);      // this wave's slice of the channels
+    const float* wcol = L.wsq + (size_t)c0 * L.K + (kok ? k : 0);
+    for (int c = cb; c < ce; c += 16) {
+      float w[16];
 #pragma unroll
-        for (int q = 0; q < DM_NB / 4; ++q) {
-          const float4 v = s2[c][q];
-          acc[4 * q] = fmaf(v.x, w, acc[4 * q]); acc[4 * q + 1] = fmaf(v.y, w, acc[4 * q + 1]);
-          acc[4 * q + 2] = fmaf(v.z, w, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(v.w, w, acc[4 * q + 3]);
+      for (int u = 0; u < 16; ++u) w[u] = (c + u < ce) ? wcol[(size_t)(c + u) * L.K] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        if (c + u < ce) {
+#pragma unroll
+          for (int q = 0; q < DM_NB / 4; ++q) {
+            const float4 v = s2[c + u][q];
+            acc[4 * q] = fmaf(v.x, w[u], acc[4 * q]); acc[4 * q + 1] = fmaf(v.y, w[u], acc[4 * q + 1]);
+            acc[4 * q + 2] = fmaf(v.z, w[u], acc[4 * q + 2]); acc[4 * q + 3] = fmaf(v.w, w[u], acc[4 * q + 3]);
+          }
         }
       }
     }
   }
-  if (k < L.K) {
+  if (wave > 0) {
 #pragma unroll
-    for (int j = 0; j < DM_NB; ++j)
-      if (n0 + j < b.B) L.out[(size_t)(n0 + j) * L.K + k] = rsqrtf(acc[j] + eps);
+    for (int j = 0; j < DM_NB; ++j) part[wave - 1][j][lane] = acc[j];
+  }
+  __syncthreads();
+  if (wave == 0 && kok) {
+#pragma unroll
+    for (int j = 0; j < DM_NB; ++j) {
+      const float t = ((acc[j] + part[0][j][lane]) + part[1][j][lane]) + part[2][j][lane];
+      if (n0 + j < b.B) L.out[(size_t)(n0 + j) * L.K + k] = rsqrtf(t + eps);
+    }
   }
 }
 
@@ -656,7 +758,7 @@ extern "C" int contrad_modconv_demod(const contrad_demod_batch* b, float eps, co
   for (int l = 0; l < b->n; ++l) {
     const contrad_demod_layer& L = b->layers[l];
     CONTRAD_ARG(L.style && L.wsq && L.out && L.Cin > 0 && L.K > 0);
-    map.start[l + 1] = map.start[l] + cdiv(L.K, 256) * cdiv(b->B, DM_NB);
+    map.start[l + 1] = map.start[l] + cdiv(L.K, DM_KB) * cdiv(b->B, DM_NB);
   }
   hipLaunchKernelGGL(modconv_demod_kernel, dim3(map.start[b->n]), dim3(256), 0, (hipStream_t)stream, *b, map, eps);
   CONTRAD_CHECK_LAUNCH();
@@ -709,6 +811,12 @@ static int upfirdn2d_launch(const float* input, const float* kernel, float* out,
     const long long tot = (long long)major * ((a.out_h + 1) / 2) * ((a.out_w + 1) / 2) * (minor / 4);
     if (down_x == 2) hipLaunchKernelGGL(upfirdn4_u1d2_kernel, dim3((unsigned)cdivll(tot, 256)), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(upfirdn4_u2d1_kernel, dim3((unsigned)cdivll(tot, 256)), dim3(256), 0, s, a);
+    CONTRAD_CHECK_LAUNCH();
+    return 0;
+  }
+  if (minor == 1 && kh == 4 && kw == 4 && up_x == 2 && up_y == 2 && down_x == 1 && down_y == 1) {
+    const long long tot = (long long)major * ((a.out_h + 1) / 2) * ((a.out_w + 1) / 2);
+    hipLaunchKernelGGL(upfirdn4_u2d1_planes_kernel, dim3((unsigned)cdivll(tot, 256)), dim3(256), 0, s, a);
     CONTRAD_CHECK_LAUNCH();
     return 0;
   }

@@ -346,7 +346,7 @@ def _upfirdn_ref(x, k, up, down, pad):
 @pytest.mark.parametrize('cfg', [(1, 1, (2, 2, 2, 2)), (1, 1, (1, 1, 1, 1)), (1, 1, (1, 2, 2, 1)), (1, 1, (-1, 2, 0, 1)),
                                  (1, 2, (1, 1, 1, 1)), (1, 2, (2, 2, 2, 2)), (1, 2, (0, 1, 1, 0)),
                                  (2, 1, (2, 1, 2, 1)), (2, 1, (1, 2, 1, 2)), (2, 1, (0, 3, 3, 0)), (2, 1, (2, 2, 1, 1))])
-@pytest.mark.parametrize('shape', [(2, 9, 11, 4), (3, 16, 16, 32), (1, 33, 7, 8), (2, 4, 5, 64)])
+@pytest.mark.parametrize('shape', [(2, 9, 11, 4), (3, 16, 16, 32), (1, 33, 7, 8), (2, 4, 5, 64), (6, 9, 11, 1), (3, 16, 17, 1)])
 def test_fir4_specialisations_against_plain_torch(cfg, shape):
     """The 4x4-FIR kernels (up1/down1 tile 4x2, down 2 tile 2x2, up 2 quad) incl. odd sizes, asymmetric and negative pads."""
     up, down, pad = cfg
