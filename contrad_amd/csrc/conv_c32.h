@@ -32,6 +32,7 @@ struct ConvC32Args {
   int N, H, W, ldw;
   int tiles_x, tiles_y;
   long long ntiles;
+  int st_nt;             // non-temporal output stores (igemm.hip, st_nt_for())
 };
 
 template <int MODE>   // MODE_FWD or MODE_DGRAD
@@ -138,7 +139,8 @@ __global__ __launch_bounds__(256, 2) void conv_c32_kernel(const ConvC32Args a) {
       } else {
         if (ro) v *= (ro[off] > 0.f) ? g1 : g0;                    // (no act_ref: raw sums, like the engine's own epilogue)
       }
-      yo[off] = v;
+      if (a.st_nt) __builtin_nontemporal_store(v, yo + off);      // (launch-uniform)
+      else yo[off] = v;
     }
   }
 }
@@ -158,8 +160,10 @@ inline int conv_c32_blocks(const contrad_conv_desc* d) {
 
 template <int MODE>
 inline int launch_conv_c32(const contrad_conv_desc* d, const float* in, const float* wp, float* out, const float* bias,
-                           const float* addend, const float* act_ref, float slope, float gain, hipStream_t stream) {
+                           const float* addend, const float* act_ref, float slope, float gain, int st_nt,
+                           hipStream_t stream) {
   ConvC32Args a{};
+  a.st_nt = st_nt;
   a.x = in; a.wp = wp; a.y = out; a.bias = bias; a.addend = addend; a.act_ref = act_ref;
   a.slope = slope; a.gain = gain;
   a.N = d->N; a.H = d->H; a.W = d->W; a.ldw = d->ldw;

@@ -73,7 +73,24 @@ struct IgemmArgs {
   unsigned char px_order[256];   // pixel-major FWD / DGRAD: the pixel the k-th tile of an image block works on (balance, see pixel_order())
   int pixmajor;          // lean FWD / DGRAD: M-tiles are BM images at one output pixel (tiles_m = image blocks x Ho*Wo), padding taps skipped
   int px_full;           // px_order holds the order of ALL tiles of the launch (image block * pixels + pixel), pixel_order_full()
+  int st_nt;             // lean FWD / DGRAD: non-temporal activation stores (outputs beyond the caches, st_nt_for())
 };
+
+// Non-temporal epilogue stores for activations the L2 cannot hold until their consumer runs (>= NT_STORE_BYTES = the 32 MB
+// of L2 on the chip; the memory-side Infinity Cache sees the lines either way).  Plain stores keep the written lines in the
+// XCD's L2, where they evict operand lines the blocks are about to re-read (im2col taps, halo rows of the 32-channel
+// kernels).  Round 5, StyleGAN2_512 (activations of 0.1 - 1.6 GB), five same-box alternations (profiles/r05_ab_stnt.txt):
+// plain 62.81 ms per step (62.35 ... 63.42, bimodal), non-temporal from 256 MB 62.54, every activation store non-temporal
+// 62.25 (62.15 ... 62.38); the headline (outputs of 50 - 201 MB) 15.76 vs 15.81 and StyleGAN2-32 15.20 vs 15.21: inside
+// the run-to-run spread.  (The cache-policy operand of a buffer store is an immediate: the epilogue holds both forms
+// behind a launch-uniform branch; split-K slabs stay plain -- the reduce reads them back at once.)
+constexpr long long NT_STORE_BYTES = 32ll << 20;
+inline int st_nt_for(long long rows, int ld) {
+#if defined(LEAN_ST_NT)          // (dev builds: -DLEAN_ST_NT=0 / 1 forces plain / non-temporal everywhere)
+  if (LEAN_ST_NT >= 0) return LEAN_ST_NT;
+#endif
+  return rows * (long long)ld * (long long)sizeof(float) >= NT_STORE_BYTES ? 1 : 0;
+}
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -1542,9 +1559,10 @@ extern "C" int contrad_conv2d_fwd_add(const contrad_conv_desc* d, const float* x
   const long long M = (long long)d->N * d->Ho * d->Wo;
   CONTRAD_ARG(M < (1ll << 31));
   a.M = (int)M; a.Ncol = d->K; a.Kg = d->KH * d->KW * d->C;
+  a.st_nt = st_nt_for(M, d->ldy);
   if (conv_c32_ok(d))   // weight-stationary kernel (conv_c32.h); (alignment is an argument error above, so the dispatch is
                         // exactly what contrad_conv2d_path / _grid_blocks report)
-    return launch_conv_c32<MODE_FWD>(d, x, wp, y, bias, addend, nullptr, slope, gain, (hipStream_t)stream);
+    return launch_conv_c32<MODE_FWD>(d, x, wp, y, bias, addend, nullptr, slope, gain, a.st_nt, (hipStream_t)stream);
   if (fwd_k1_ok(d)) {
     hipLaunchKernelGGL(fwd_k1_kernel, dim3((unsigned)cdivll(M, 4)), dim3(256), 0, (hipStream_t)stream, x, wp, M, d->C,
                        d->ldx, d->ldw, bias, slope, gain, y, d->ldy, addend);
@@ -1610,11 +1628,13 @@ extern "C" int contrad_conv2d_dgrad_ws(const contrad_conv_desc* d, const float* 
   CONTRAD_ARG(gy && wp && dx);
   if (vec_ok(d, MODE_DGRAD)) CONTRAD_ARG(aligned16(gy, wp, dx) && aligned16(act_ref, nullptr, nullptr));
   if (conv_c32_ok(d))   // stride-1 pad-1 3x3: the same weight-stationary kernel with the filter mirrored (conv_c32.h)
-    return launch_conv_c32<MODE_DGRAD>(d, gy, wp, dx, nullptr, nullptr, act_ref, slope, gain, (hipStream_t)stream);
+    return launch_conv_c32<MODE_DGRAD>(d, gy, wp, dx, nullptr, nullptr, act_ref, slope, gain,
+                                       st_nt_for((long long)d->N * d->H * d->W, d->ldx), (hipStream_t)stream);
   // every input pixel must be covered by at least one tap of its parity class, otherwise the class
   // (whose gradient is exactly zero) still writes zeros: handled by Kg == 0 -> T == 0 -> acc = 0.
   IgemmArgs a{};
   a.A = gy; a.B = wp; a.C = dx; a.act_ref = act_ref; a.d = *d; a.slope = slope; a.gain = gain;
+  a.st_nt = st_nt_for((long long)d->N * d->H * d->W, d->ldx);
   const int s = d->stride;
   const long long Mc = (long long)d->N * cdiv(d->H, s) * cdiv(d->W, s);  // largest class
   CONTRAD_ARG(Mc < (1ll << 31));

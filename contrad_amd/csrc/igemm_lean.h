@@ -26,6 +26,12 @@
 // parity tests compare each against the fp32 oracle with the stated tolerance.
 #pragma once
 
+#ifndef LEAN_LD_NT
+#define LEAN_LD_NT 0     // dev knob: the epilogue's second operand (act_ref / addend, read once) loaded non-temporally too
+#endif
+#ifndef LEAN_ST_NT
+#define LEAN_ST_NT -1    // dev knob: 0 / 1 forces plain / non-temporal activation stores in every launch (-1: by output size)
+#endif
 #ifndef LEAN_QPAD
 #define LEAN_QPAD 8      // dwords between the four k-quad planes of a quad-layout LDS tile beyond 4 * rows (see lean_tile)
 #endif
@@ -665,6 +671,8 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
   // M and columns past Ncol fall outside num_records and are dropped by the hardware -- one v_add per store instead of
   // a 64-bit address, two compares and a branch (the 64 stores of a wave were ~2000 instructions; blocks of the
   // shallow-K StyleGAN2 layers spent more time here than in their 18 K-tiles).
+  // activation stores of outputs no cache will hold until the consumer runs: non-temporal (aux = 2), igemm.hip st_nt_for()
+  const bool st_nt = (LEAN_ST_NT >= 0) ? (LEAN_ST_NT != 0) : (MODE != MODE_WGRAD && p.st_nt != 0);
   constexpr unsigned COL_OOB = 0x40000000u;    // > every valid block-relative offset, and 2 * COL_OOB does not wrap
   unsigned colpart[TN];
 #pragma unroll
@@ -740,7 +748,9 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
           for (int q = 0; q < EPI_G; ++q)
 #pragma unroll
             for (int jj = 0; jj < TN; ++jj)
-              rv[q][jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)(offs[q] + colpart[jj]), 0, 0));
+              rv[q][jj] = (LEAN_LD_NT && st_nt)
+                              ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)(offs[q] + colpart[jj]), 0, 2))
+                              : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)(offs[q] + colpart[jj]), 0, 0));
         }
 #pragma unroll
         for (int q = 0; q < EPI_G; ++q) {
@@ -756,7 +766,8 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
               v *= p.gain;
               if (ref) v += rv[q][jj];
             }
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)vo, 0, 0);
+            if (st_nt) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)vo, 0, 2);
+            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)vo, 0, 0);
           }
         }
       }
@@ -802,7 +813,9 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
             for (int q = 0; q < EPI_F; ++q)
 #pragma unroll
               for (int j = 0; j < TN; ++j)
-                rv[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, (int)(lanepart[j] + rowpart[q]), 0, 0));
+                rv[q][j] = (LEAN_LD_NT && st_nt)
+                               ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, (int)(lanepart[j] + rowpart[q]), 0, 2))
+                               : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, (int)(lanepart[j] + rowpart[q]), 0, 0));
           }
 #pragma unroll
           for (int q = 0; q < EPI_F; ++q)
@@ -814,7 +827,10 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
                 v *= (v > 0.f) ? g1 : g0;
                 if (has_add) v += rv[q][j];
               }
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)(lanepart[j] + rowpart[q]), 0, 0);
+              if (st_nt && !slab)      // (the cache-policy operand must be an immediate: two store instructions)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)(lanepart[j] + rowpart[q]), 0, 2);
+              else
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)(lanepart[j] + rowpart[q]), 0, 0);
             }
         }
     } else {

@@ -14,6 +14,30 @@
 
 namespace {
 
+// Streaming accesses of the FIR kernels: activations of hundreds of MB read once and written once.  UF_NT (dev build
+// knob: bit 0 loads, bit 1 stores) marks them non-temporal; default: plain.  Round 5 (profiles/r05_hbm_nt.txt): in
+// ISOLATION non-temporal stores lift the blur at 48 x 512^2 x 32 from 4.12 to 5.04 TB/s (plain stores keep the written
+// lines in the XCD's L2, where they evict the input rows the neighbouring threads re-read) -- but inside a step the
+// consumer then finds nothing of the output in the caches and the step is no faster (62.07 vs 62.16 ms always-nt, 62.18
+// from 32 MB, 63.0 from 128 MB; profiles/r05_ab_nt.txt).  Non-temporal LOADS lose everywhere (the taps' re-reads miss).
+typedef float uf_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 uf_ld4(const float* p) {
+#if defined(UF_NT) && (UF_NT & 1)
+  const uf_v4f v = __builtin_nontemporal_load(reinterpret_cast<const uf_v4f*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ void uf_st4(float* p, float4 v) {
+#if defined(UF_NT) && (UF_NT & 2)
+  uf_v4f w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+  __builtin_nontemporal_store(w, reinterpret_cast<uf_v4f*>(p));
+#else
+  *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
 struct UpfirdnArgs {
   const float* in;
   const float* kernel;
@@ -39,19 +63,29 @@ struct UpfirdnArgs {
 template <int VW>
 __device__ __forceinline__ void uf_store(const UpfirdnArgs& a, size_t off, float* v) {
   if (a.addend) {
-#pragma unroll
-    for (int i = 0; i < VW; ++i) v[i] += a.addend[off + i];
+    if (VW == 4) {
+      const float4 t = uf_ld4(a.addend + off);
+      v[0] += t.x; v[1 % VW] += t.y; v[2 % VW] += t.z; v[3 % VW] += t.w;
+    } else {
+      v[0] += a.addend[off];
+    }
   }
   if (a.out) {
-    if (VW == 4) *reinterpret_cast<float4*>(a.out + off) = make_float4(v[0], v[1 % VW], v[2 % VW], v[3 % VW]);
+    if (VW == 4) uf_st4(a.out + off, make_float4(v[0], v[1 % VW], v[2 % VW], v[3 % VW]));
     else a.out[off] = v[0];
   }
   if (a.out2) {
     const float neg = a.slope * a.gain;
-    float w[VW];
+    float w[VW], rf[VW];
+    if (VW == 4) {
+      const float4 t = uf_ld4(a.act_ref + off);
+      rf[0] = t.x; rf[1 % VW] = t.y; rf[2 % VW] = t.z; rf[3 % VW] = t.w;
+    } else {
+      rf[0] = a.act_ref[off];
+    }
 #pragma unroll
-    for (int i = 0; i < VW; ++i) w[i] = v[i] * (a.act_ref[off + i] > 0.f ? a.gain : neg);
-    if (VW == 4) *reinterpret_cast<float4*>(a.out2 + off) = make_float4(w[0], w[1 % VW], w[2 % VW], w[3 % VW]);
+    for (int i = 0; i < VW; ++i) w[i] = v[i] * (rf[i] > 0.f ? a.gain : neg);
+    if (VW == 4) uf_st4(a.out2 + off, make_float4(w[0], w[1 % VW], w[2 % VW], w[3 % VW]));
     else a.out2[off] = w[0];
   }
 }
@@ -76,7 +110,7 @@ __device__ __forceinline__ void mc_store4(const UpfirdnArgs& a, int m, size_t pi
     const float4 q = *reinterpret_cast<const float4*>(a.mc_post + (size_t)m * a.minor + c);
     v.x *= q.x; v.y *= q.y; v.z *= q.z; v.w *= q.w;
   }
-  *reinterpret_cast<float4*>(a.out + pix * a.minor + c) = v;
+  uf_st4(a.out + pix * a.minor + c, v);
 }
 
 constexpr int MAX_FIR = 8;
@@ -220,7 +254,7 @@ __global__ __launch_bounds__(256) void upfirdn4_u1d1_kernel(UpfirdnArgs a) {
     for (int dx = 0; dx < 5; ++dx) {
       const int ix = ix0 + dx;
       v[dx] = (vy && (unsigned)ix < (unsigned)a.in_w)
-                  ? *reinterpret_cast<const float4*>(base + ((size_t)iy * a.in_w + ix) * a.minor)
+                  ? uf_ld4(base + ((size_t)iy * a.in_w + ix) * a.minor)
                   : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
@@ -281,7 +315,7 @@ __global__ __launch_bounds__(256) void upfirdn4_u1d2_kernel(UpfirdnArgs a) {
     for (int dx = 0; dx < 6; ++dx) {
       const int ix = ix0 + dx;
       v[dx] = (vy && (unsigned)ix < (unsigned)a.in_w)
-                  ? *reinterpret_cast<const float4*>(base + ((size_t)iy * a.in_w + ix) * a.minor)
+                  ? uf_ld4(base + ((size_t)iy * a.in_w + ix) * a.minor)
                   : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
@@ -329,7 +363,7 @@ __device__ __forceinline__ void upfirdn4_u2d1_body(const UpfirdnArgs& a, const F
       const bool used_x = (PX + 2 * dx >= 0 && PX + 2 * dx <= 3) || (PX + 2 * dx - 1 >= 0 && PX + 2 * dx - 1 <= 3);
       if (!(used_y && used_x)) continue;
       if (!(vy && (unsigned)ix < (unsigned)a.in_w)) continue;
-      const float4 v = *reinterpret_cast<const float4*>(base + ((size_t)iy * a.in_w + ix) * a.minor);
+      const float4 v = uf_ld4(base + ((size_t)iy * a.in_w + ix) * a.minor);
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int ky = PY + 2 * dy - r;
