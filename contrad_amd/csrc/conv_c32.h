@@ -14,6 +14,10 @@
 // bias + LeakyReLU.  The k order of the contraction is (tap, channel pair).
 #pragma once
 
+#ifndef C32_YFAST
+#define C32_YFAST 0     // tile walk of the 32-channel kernels (conv_c32.h, wgrad_c32.h): 0 = along rows, 1 = down columns
+#endif
+
 constexpr int CC_TH = 4, CC_TW = 32, CC_C = 32;
 constexpr int CC_PIX = (CC_TH + 2) * (CC_TW + 2);              // pixels of the halo tile
 constexpr int CC_CS = CC_PIX + 1;                              // channel stride in LDS: odd, so that the transposing
@@ -61,8 +65,13 @@ __global__ __launch_bounds__(256, 2) void conv_c32_kernel(const ConvC32Args a) {
   auto origin = [&](long long t, int& n, int& ty, int& tx) {
     n = (int)(t / tpi);
     const int r = (int)(t - (long long)n * tpi);
+#if C32_YFAST        // a block walks DOWN a column of tiles: the next tile's two upper halo rows are the rows just read
+    tx = r / a.tiles_y;
+    ty = r - tx * a.tiles_y;
+#else
     ty = r / a.tiles_x;
     tx = r - ty * a.tiles_x;
+#endif
   };
   auto fetch = [&](long long t) {      // the next tile's global loads, issued before the current tile's MFMAs
     int n, ty, tx;

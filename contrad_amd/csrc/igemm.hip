@@ -76,15 +76,15 @@ struct IgemmArgs {
   int st_nt;             // lean FWD / DGRAD: non-temporal activation stores (outputs beyond the caches, st_nt_for())
 };
 
-// Non-temporal epilogue stores for activations the L2 cannot hold until their consumer runs (>= NT_STORE_BYTES = the 32 MB
-// of L2 on the chip; the memory-side Infinity Cache sees the lines either way).  Plain stores keep the written lines in the
-// XCD's L2, where they evict operand lines the blocks are about to re-read (im2col taps, halo rows of the 32-channel
-// kernels).  Round 5, StyleGAN2_512 (activations of 0.1 - 1.6 GB), five same-box alternations (profiles/r05_ab_stnt.txt):
-// plain 62.81 ms per step (62.35 ... 63.42, bimodal), non-temporal from 256 MB 62.54, every activation store non-temporal
-// 62.25 (62.15 ... 62.38); the headline (outputs of 50 - 201 MB) 15.76 vs 15.81 and StyleGAN2-32 15.20 vs 15.21: inside
-// the run-to-run spread.  (The cache-policy operand of a buffer store is an immediate: the epilogue holds both forms
-// behind a launch-uniform branch; split-K slabs stay plain -- the reduce reads them back at once.)
-constexpr long long NT_STORE_BYTES = 32ll << 20;
+// Non-temporal epilogue stores for activations that no cache will hold until their consumer runs (>= NT_STORE_BYTES = the
+// 256 MB Infinity Cache).  Plain stores keep the written lines in the XCD's L2, where they evict operand lines the blocks
+// are about to re-read (im2col taps, halo rows of the 32-channel kernels).  Round 5, same-box alternations
+// (profiles/r05_ab_stnt.txt): StyleGAN2_512 (activations of 0.1 - 1.6 GB), five alternations: plain 62.81 ms per step
+// (62.35 ... 63.42), non-temporal from 256 MB 62.54, every activation store non-temporal 62.25; but the headline (outputs of
+// 50 - 201 MB, which the NEXT layer finds in the Infinity Cache) loses with it: 15.681 -> 15.747 ms (5 / 5 alternations),
+// StyleGAN2-32 15.215 -> 15.272 -- hence the threshold.  (The cache-policy operand of a buffer store is an immediate: the
+// epilogue holds both forms behind a launch-uniform branch; split-K slabs stay plain -- the reduce reads them back at once.)
+constexpr long long NT_STORE_BYTES = 256ll << 20;
 inline int st_nt_for(long long rows, int ld) {
 #if defined(LEAN_ST_NT)          // (dev builds: -DLEAN_ST_NT=0 / 1 forces plain / non-temporal everywhere)
   if (LEAN_ST_NT >= 0) return LEAN_ST_NT;

@@ -15,11 +15,12 @@
 namespace {
 
 // Streaming accesses of the FIR kernels: activations of hundreds of MB read once and written once.  UF_NT (dev build
-// knob: bit 0 loads, bit 1 stores) marks them non-temporal; default: plain.  Round 5 (profiles/r05_hbm_nt.txt): in
-// ISOLATION non-temporal stores lift the blur at 48 x 512^2 x 32 from 4.12 to 5.04 TB/s (plain stores keep the written
-// lines in the XCD's L2, where they evict the input rows the neighbouring threads re-read) -- but inside a step the
-// consumer then finds nothing of the output in the caches and the step is no faster (62.07 vs 62.16 ms always-nt, 62.18
-// from 32 MB, 63.0 from 128 MB; profiles/r05_ab_nt.txt).  Non-temporal LOADS lose everywhere (the taps' re-reads miss).
+// knob: bit 0 loads, bit 1 stores) forces them non-temporal.  Round 5 (profiles/r05_hbm_nt.txt): non-temporal STORES lift
+// the blur at 48 x 512^2 x 32 from 4.12 to 5.04 TB/s and its transpose with the act' epilogue from 4.17 to 5.24 (plain
+// stores keep the written lines in the XCD's L2, where they evict the input rows the neighbouring threads re-read); in
+// the StyleGAN2_512 step that is 62.79 -> 62.04 ms (five same-box alternations, profiles/r05_ab_stnt.txt) -- used for
+// outputs of >= 256 MB (UpfirdnArgs.nt_store); smaller outputs are found in the caches by their consumer and stay plain.
+// Non-temporal LOADS lose everywhere (the taps' re-reads miss): 4.12 -> 3.22 TB/s.
 typedef float uf_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 uf_ld4(const float* p) {
 #if defined(UF_NT) && (UF_NT & 1)
@@ -29,13 +30,16 @@ __device__ __forceinline__ float4 uf_ld4(const float* p) {
   return *reinterpret_cast<const float4*>(p);
 #endif
 }
-__device__ __forceinline__ void uf_st4(float* p, float4 v) {
+__device__ __forceinline__ void uf_st4(float* p, float4 v, bool nt) {
 #if defined(UF_NT) && (UF_NT & 2)
-  uf_v4f w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
-  __builtin_nontemporal_store(w, reinterpret_cast<uf_v4f*>(p));
-#else
-  *reinterpret_cast<float4*>(p) = v;
+  nt = true;
 #endif
+  if (nt) {           // (uniform over the launch)
+    uf_v4f w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+    __builtin_nontemporal_store(w, reinterpret_cast<uf_v4f*>(p));
+  } else {
+    *reinterpret_cast<float4*>(p) = v;
+  }
 }
 
 struct UpfirdnArgs {
@@ -57,6 +61,7 @@ struct UpfirdnArgs {
   const float* mc_noise_w;
   const float* mc_bias;
   const float* mc_post;
+  int nt_store;      // output beyond the caches (>= 256 MB): non-temporal stores, see upfirdn2d_launch
 };
 
 // epilogue store of VW consecutive channels at flat element offset `off` of the output
@@ -71,7 +76,7 @@ __device__ __forceinline__ void uf_store(const UpfirdnArgs& a, size_t off, float
     }
   }
   if (a.out) {
-    if (VW == 4) uf_st4(a.out + off, make_float4(v[0], v[1 % VW], v[2 % VW], v[3 % VW]));
+    if (VW == 4) uf_st4(a.out + off, make_float4(v[0], v[1 % VW], v[2 % VW], v[3 % VW]), a.nt_store != 0);
     else a.out[off] = v[0];
   }
   if (a.out2) {
@@ -85,7 +90,7 @@ __device__ __forceinline__ void uf_store(const UpfirdnArgs& a, size_t off, float
     }
 #pragma unroll
     for (int i = 0; i < VW; ++i) w[i] = v[i] * (rf[i] > 0.f ? a.gain : neg);
-    if (VW == 4) uf_st4(a.out2 + off, make_float4(w[0], w[1 % VW], w[2 % VW], w[3 % VW]));
+    if (VW == 4) uf_st4(a.out2 + off, make_float4(w[0], w[1 % VW], w[2 % VW], w[3 % VW]), a.nt_store != 0);
     else a.out2[off] = w[0];
   }
 }
@@ -110,7 +115,7 @@ __device__ __forceinline__ void mc_store4(const UpfirdnArgs& a, int m, size_t pi
     const float4 q = *reinterpret_cast<const float4*>(a.mc_post + (size_t)m * a.minor + c);
     v.x *= q.x; v.y *= q.y; v.z *= q.z; v.w *= q.w;
   }
-  uf_st4(a.out + pix * a.minor + c, v);
+  uf_st4(a.out + pix * a.minor + c, v, a.nt_store != 0);
 }
 
 constexpr int MAX_FIR = 8;
@@ -831,6 +836,9 @@ static int upfirdn2d_launch(const float* input, const float* kernel, float* out,
   a.addend = addend; a.act_ref = act_ref; a.out2 = out2; a.slope = slope; a.gain = gain;
   if (mc) { a.mc_demod = mc->demod; a.mc_noise = mc->noise; a.mc_noise_w = mc->noise_w; a.mc_bias = mc->bias; a.mc_post = mc->post; }
   CONTRAD_ARG(a.out_h > 0 && a.out_w > 0);
+  // non-temporal stores once the output cannot stay in the 256 MB Infinity Cache for its consumer (the same rule as the conv
+  // engine's epilogues, igemm.hip NT_STORE_BYTES): StyleGAN2_512, five same-box alternations: 62.79 -> 62.04 ms per step
+  a.nt_store = ((long long)major * a.out_h * a.out_w * minor * (long long)sizeof(float) >= (256ll << 20)) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = (minor & 3) == 0;
   const bool fir4 = vec && kh == 4 && kw == 4 && up_x == up_y && down_x == down_y;

@@ -77,7 +77,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_c32_kernel(const WgradC32Args a)
   auto fetch = [&](long long t) {
     const int n = (int)(t / tpi);
     const int r = (int)(t - (long long)n * tpi);
+#if C32_YFAST
+    const int tx = r / a.tiles_y, ty = r - tx * a.tiles_y;
+#else
     const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+#endif
     const size_t org = ((size_t)n * a.H * a.W + (size_t)(ty * WC_TH) * a.W + tx * WC_TW) * WC_C;
     const unsigned edge = (ty == 0 ? 1u : 0u) | (ty == a.tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) |
                           (tx == a.tiles_x - 1 ? 8u : 0u) | 16u;                      // wave-uniform
