@@ -14,6 +14,10 @@
 // column sums) that the engine's wgrad_reduce_kernel sums over blocks in fixed order.
 #pragma once
 
+#ifndef C32_YFAST
+#define C32_YFAST 0     // tile walk: 0 = along rows, 1 = down columns (see conv_c32.h)
+#endif
+
 constexpr int WC_TH = 4, WC_TW = 32, WC_C = 32;
 constexpr int WC_XS = (WC_TH + 2) * (WC_TW + 2) * WC_C;      // floats of the x halo tile
 constexpr int WC_GS = WC_TH * WC_TW * WC_C;                  // floats of the gy tile
