@@ -14,8 +14,14 @@
 // bias + LeakyReLU.  The k order of the contraction is (tap, channel pair).
 #pragma once
 
+// Tile walk of the 32-channel kernels (conv_c32.h, wgrad_c32.h): 1 = a block walks DOWN a column of tiles, so the two upper
+// halo rows of the next tile are the rows it has just read (0 = along rows: the vertical halo, half of a 4-row tile again,
+// came back 16 tiles later and missed the L2).  Round 5 (profiles/r05_pmc_c32_walk.txt): FETCH_SIZE per launch 710 -> 522
+// (FWD), 918 -> 663 (DGRAD), 1 589 -> 1 383 MiB (WGRAD), L2 hit rate 0.30 -> 0.41 / 0.51 -> 0.58; durations and the step
+// are unchanged (61.87 vs 61.85 ms, five alternations) -- these kernels are not bound by their fabric traffic -- so the
+// order is kept for the bytes it saves, not for time.
 #ifndef C32_YFAST
-#define C32_YFAST 0     // tile walk of the 32-channel kernels (conv_c32.h, wgrad_c32.h): 0 = along rows, 1 = down columns
+#define C32_YFAST 1
 #endif
 
 constexpr int CC_TH = 4, CC_TW = 32, CC_C = 32;

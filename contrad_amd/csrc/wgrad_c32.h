@@ -15,7 +15,7 @@
 #pragma once
 
 #ifndef C32_YFAST
-#define C32_YFAST 0     // tile walk: 0 = along rows, 1 = down columns (see conv_c32.h)
+#define C32_YFAST 1     // tile walk: 0 = along rows, 1 = down columns (see conv_c32.h)
 #endif
 
 constexpr int WC_TH = 4, WC_TW = 32, WC_C = 32;
