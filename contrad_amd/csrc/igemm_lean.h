@@ -26,6 +26,9 @@
 // parity tests compare each against the fp32 oracle with the stated tolerance.
 #pragma once
 
+#ifndef LEAN_DEEP
+#define LEAN_DEEP 0      // dev knob: 1 = the narrow WGRAD instances (<= 128 x 64) keep TWO K-tiles of global loads in flight
+#endif                   //           3 = also the narrow FWD / DGRAD instances (see lean_tile, "DEEP")
 #ifndef LEAN_LD_NT
 #define LEAN_LD_NT 0     // dev knob: the epilogue's second operand (act_ref / addend, read once) loaded non-temporally too
 #endif
@@ -49,6 +52,10 @@ __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t lean_rsrc(const float* base, bool on) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, on ? (int)LEAN_RANGE : 0, 0x00020000);
 }
+
+// compile-time value of the K loop's buffer parity (std::integral_constant when the loop is unrolled by two, else 0)
+template <class P> struct lean_par_value { static constexpr int v = 0; };
+template <int V> struct lean_par_value<std::integral_constant<int, V>> { static constexpr int v = V; };
 
 // x = q * d + r with a wave-uniform divisor: power-of-two extents (every level of the image pyramids here except the
 // blur-padded 2^k + 1 ones) take a shift and a mask instead of the ~35-instruction runtime division -- the prologue is
@@ -392,7 +399,13 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
   }
 
   // ---------------- per-tile (wave-uniform) state and loaders ----------------
-  float4 ra[PA], rb[PB];
+  // DEEP: two register sets -- the loads of tile t + 2 are issued while tile t is multiplied and land in LDS during tile
+  // t + 1.  One K-tile of a narrow instance is 1 - 2 us of matrix-pipe time for the waves of a SIMD together, the order of a
+  // load that misses the L2 (SQ_WAIT_ANY 0.37 of the wave cycles of the 128 x 64 WGRAD instance vs 0.10 of 128 x 128).
+  constexpr bool DEEP = ((LEAN_DEEP & 1) && MODE == MODE_WGRAD && BM * BN <= 128 * 64) ||
+                        ((LEAN_DEEP & 2) && MODE != MODE_WGRAD && BM * BN <= 128 * 64);
+  constexpr int NSET = DEEP ? 2 : 1;
+  float4 ra[NSET][PA], rb[NSET][PB];
   unsigned soffA = 0, soffB = 0;
   unsigned edge = 0;   // WGRAD: which borders of the output grid the next patch touches (bits as in inv)
   // ... and the same word for the walk's current position.  The four flags are 2 / 4 / 8 / 16, not 1 / 2 / 4 / 8: the
@@ -482,16 +495,16 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
       } while (wskip & pos_edge);
     }
   };
-  auto load_a_piece = [&](int i) {
+  auto load_a_piece = [&](int set, int i) {
     unsigned v;
     if constexpr (MODE == MODE_WGRAD) {
       v = (inv[i] & edge) ? LEAN_OOB : va[i];
     } else {
       v = va[i] | ((inv[i] >> u_tap) << 31);
     }
-    ra[i] = bload4(rsA, v, soffA);
+    ra[set][i] = bload4(rsA, v, soffA);
   };
-  auto load_b_piece = [&](int i) { rb[i] = bload4(rsB, vb[i], soffB); };
+  auto load_b_piece = [&](int set, int i) { rb[set][i] = bload4(rsB, vb[i], soffB); };
 
   // ---------------- LDS addressing (dword indices relative to the current buffer) ----------------
   int wrA, wrB, rdA[TM], rdB[TN];
@@ -518,18 +531,18 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
   float4 colacc = zero4();
   const bool do_bias = (MODE == MODE_WGRAD) && p.bias_ws != nullptr && tile_m == 0;   // uniform per block
 
-  auto store_a_piece = [&](int bufoff, int i) {
+  auto store_a_piece = [&](int bufoff, int set, int i) {
     float* dst = smem + bufoff + wrA + (A_Q ? i * 256 : i * A_RPP * BM);
-    *reinterpret_cast<float4*>(dst) = ra[i];
+    *reinterpret_cast<float4*>(dst) = ra[set][i];
   };
   const bool b_owner = !B_HALF || (B_Q ? qrow < BN : b_r < BK);   // does this thread own a piece of the B tile?
-  auto store_b_piece = [&](int bufoff, int i) {
+  auto store_b_piece = [&](int bufoff, int set, int i) {
     float* dst = smem + bufoff + wrB + (B_Q ? i * 256 : i * B_RPP * LDB);
-    if (b_owner) *reinterpret_cast<float4*>(dst) = rb[i];
+    if (b_owner) *reinterpret_cast<float4*>(dst) = rb[set][i];
     if constexpr (MODE == MODE_WGRAD) {
       if (do_bias) {   // the empty asm keeps this a real uniform branch: if-converted it costs 8 VALU + 4 selects per
         asm volatile("" ::: "memory");   // tile in EVERY block, and only 1 block in tiles_m needs it
-        colacc.x += rb[i].x; colacc.y += rb[i].y; colacc.z += rb[i].z; colacc.w += rb[i].w;
+        colacc.x += rb[set][i].x; colacc.y += rb[set][i].y; colacc.z += rb[set][i].z; colacc.w += rb[set][i].w;
       }
     }
   };
@@ -545,14 +558,22 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
   if (T > 0) {
     begin_tile();
 #pragma unroll
-    for (int i = 0; i < PA; ++i) load_a_piece(i);
+    for (int i = 0; i < PA; ++i) load_a_piece(0, i);
 #pragma unroll
-    for (int i = 0; i < PB; ++i) load_b_piece(i);
+    for (int i = 0; i < PB; ++i) load_b_piece(0, i);
     end_tile();
+    if constexpr (DEEP) {      // tile 1 goes into flight before tile 0 is waited for (set 1: stored during K-tile 0)
+      begin_tile();
 #pragma unroll
-    for (int i = 0; i < PA; ++i) store_a_piece(0, i);
+      for (int i = 0; i < PA; ++i) load_a_piece(1, i);
 #pragma unroll
-    for (int i = 0; i < PB; ++i) store_b_piece(0, i);
+      for (int i = 0; i < PB; ++i) load_b_piece(1, i);
+      end_tile();
+    }
+#pragma unroll
+    for (int i = 0; i < PA; ++i) store_a_piece(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) store_b_piece(0, 0, i);
   }
   __syncthreads();
 
@@ -577,6 +598,7 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
   // (The 128 x 128 FWD / DGRAD instances sit at the 128-VGPR limit and spill 25 ... 215 registers in every unrolled shape
   // tried -- break in the middle, or an even tile count with a zero-filled last tile: they keep the run-time buffer select.)
   constexpr bool UNROLL2 = !(BM * BN > 128 * 64 && MODE != MODE_WGRAD);
+  static_assert(!DEEP || UNROLL2, "the two-deep prefetch needs the buffer parity at compile time");
   auto k_tile = [&](auto par, auto with_mfma, const int t) {
     const int cur = (int)par * BUF, nxt = BUF - cur;   // (par: std::integral_constant when unrolled -> folds to immediates)
     (void)t;
@@ -621,9 +643,12 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
     for (int ks = 0; ks < KS; ++ks) {
       const int h = ks >> 2, j = ks & 3;
 #if !defined(LEAN_ABLATE_LOADS)     // (ablation builds give WRONG results: timing only, tools/build_variant.sh)
+      // (DEEP: K-tile t loads tile t + 2 into set t & 1 -- its previous content, tile t, is in LDS -- and stores set
+      // (t + 1) & 1; the K loop is unrolled by two for every DEEP instance, so `par` = t & 1 at compile time)
+      constexpr int LSET = DEEP ? lean_par_value<decltype(par)>::v : 0, SSET = DEEP ? 1 - lean_par_value<decltype(par)>::v : 0;
       if (ks == A_LD0) begin_tile();
-      if (ks >= A_LD0 && ks < A_LD0 + PA) load_a_piece(ks - A_LD0);
-      if (ks >= B_LD0 && ks < B_LD0 + PB) load_b_piece(ks - B_LD0);
+      if (ks >= A_LD0 && ks < A_LD0 + PA) load_a_piece(LSET, ks - A_LD0);
+      if (ks >= B_LD0 && ks < B_LD0 + PB) load_b_piece(LSET, ks - B_LD0);
       if (ks == B_LD0 + PB - 1) end_tile();
 #endif
       __builtin_amdgcn_sched_barrier(0);
@@ -638,8 +663,8 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
       }
       __builtin_amdgcn_sched_barrier(0);
 #if !defined(LEAN_ABLATE_STORES)
-      if (ks >= A_ST0 && ks < A_ST0 + PA) store_a_piece(nxt, ks - A_ST0);
-      if (ks >= B_ST0 && ks < B_ST0 + PB) store_b_piece(nxt, ks - B_ST0);
+      if (ks >= A_ST0 && ks < A_ST0 + PA) store_a_piece(nxt, SSET, ks - A_ST0);
+      if (ks >= B_ST0 && ks < B_ST0 + PB) store_b_piece(nxt, SSET, ks - B_ST0);
 #endif
     }
 #if !defined(LEAN_ABLATE_BARRIER)
