@@ -42,7 +42,6 @@ struct ConvC32Args {
   int N, H, W, ldw;
   int tiles_x, tiles_y;
   long long ntiles;
-  int st_nt;             // non-temporal output stores (igemm.hip, st_nt_for())
 };
 
 template <int MODE>   // MODE_FWD or MODE_DGRAD
@@ -142,6 +141,8 @@ __global__ __launch_bounds__(256, 2) void conv_c32_kernel(const ConvC32Args a) {
     const size_t row0 = (((size_t)n * a.H + ty * CC_TH + wave) * a.W + tx * CC_TW + 4 * hi) * CC_C + l31;
     float* yo = a.y + row0;
     const float* ro = (MODE == MODE_FWD) ? (a.addend ? a.addend + row0 : nullptr) : (a.act_ref ? a.act_ref + row0 : nullptr);
+    // (plain stores: a non-temporal form -- buffer stores with the nt policy, round 5 -- took this kernel from 241 to 255
+    // VGPRs and doubled its branches; not worth the risk for outputs the 256 MB Infinity Cache cannot hold anyway)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int off = ((r & 3) + 8 * (r >> 2)) * CC_C;             // compile-time: an immediate offset of the access
@@ -154,8 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv_c32_kernel(const ConvC32Args a) {
       } else {
         if (ro) v *= (ro[off] > 0.f) ? g1 : g0;                    // (no act_ref: raw sums, like the engine's own epilogue)
       }
-      if (a.st_nt) __builtin_nontemporal_store(v, yo + off);      // (launch-uniform)
-      else yo[off] = v;
+      yo[off] = v;
     }
   }
 }
@@ -175,10 +175,8 @@ inline int conv_c32_blocks(const contrad_conv_desc* d) {
 
 template <int MODE>
 inline int launch_conv_c32(const contrad_conv_desc* d, const float* in, const float* wp, float* out, const float* bias,
-                           const float* addend, const float* act_ref, float slope, float gain, int st_nt,
-                           hipStream_t stream) {
+                           const float* addend, const float* act_ref, float slope, float gain, hipStream_t stream) {
   ConvC32Args a{};
-  a.st_nt = st_nt;
   a.x = in; a.wp = wp; a.y = out; a.bias = bias; a.addend = addend; a.act_ref = act_ref;
   a.slope = slope; a.gain = gain;
   a.N = d->N; a.H = d->H; a.W = d->W; a.ldw = d->ldw;

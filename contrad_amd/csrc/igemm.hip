@@ -77,13 +77,15 @@ struct IgemmArgs {
 };
 
 // Non-temporal epilogue stores for activations that no cache will hold until their consumer runs (>= NT_STORE_BYTES = the
-// 256 MB Infinity Cache).  Plain stores keep the written lines in the XCD's L2, where they evict operand lines the blocks
-// are about to re-read (im2col taps, halo rows of the 32-channel kernels).  Round 5, same-box alternations
-// (profiles/r05_ab_stnt.txt): StyleGAN2_512 (activations of 0.1 - 1.6 GB), five alternations: plain 62.81 ms per step
-// (62.35 ... 63.42), non-temporal from 256 MB 62.54, every activation store non-temporal 62.25; but the headline (outputs of
-// 50 - 201 MB, which the NEXT layer finds in the Infinity Cache) loses with it: 15.681 -> 15.747 ms (5 / 5 alternations),
-// StyleGAN2-32 15.215 -> 15.272 -- hence the threshold.  (The cache-policy operand of a buffer store is an immediate: the
-// epilogue holds both forms behind a launch-uniform branch; split-K slabs stay plain -- the reduce reads them back at once.)
+// 256 MB Infinity Cache), in the narrow lean instances (igemm_lean.h NT_CAP: the 128 x 128 FWD / DGRAD instances -- the
+// headline's kernels, at the 128-VGPR limit -- spill with the second store loop; conv_c32 keeps plain stores).  Plain
+// stores keep the written lines in the XCD's L2, where they evict operand lines the blocks are about to re-read.  Round 5,
+// same-box alternations (profiles/r05_ab_stnt.txt): StyleGAN2_512 (activations of 0.1 - 1.6 GB): plain 62.81 ms per step
+// (62.35 ... 63.42), non-temporal from 256 MB 62.54, every activation store non-temporal 62.25; in the final form (narrow
+// instances only) 61.96 -> 61.76; the headline (outputs of 50 - 201 MB, which the NEXT layer finds in the Infinity Cache)
+// LOSES with non-temporal stores: 15.681 -> 15.747 ms (5 / 5 alternations), StyleGAN2-32 15.215 -> 15.272 -- hence the
+// threshold.  (The cache-policy operand of a buffer store is an immediate: the epilogue holds both store loops behind ONE
+// launch-uniform branch; split-K slabs stay plain -- the reduce reads them back at once.)
 constexpr long long NT_STORE_BYTES = 256ll << 20;
 inline int st_nt_for(long long rows, int ld) {
 #if defined(LEAN_ST_NT)          // (dev builds: -DLEAN_ST_NT=0 / 1 forces plain / non-temporal everywhere)
@@ -1562,7 +1564,7 @@ extern "C" int contrad_conv2d_fwd_add(const contrad_conv_desc* d, const float* x
   a.st_nt = st_nt_for(M, d->ldy);
   if (conv_c32_ok(d))   // weight-stationary kernel (conv_c32.h); (alignment is an argument error above, so the dispatch is
                         // exactly what contrad_conv2d_path / _grid_blocks report)
-    return launch_conv_c32<MODE_FWD>(d, x, wp, y, bias, addend, nullptr, slope, gain, a.st_nt, (hipStream_t)stream);
+    return launch_conv_c32<MODE_FWD>(d, x, wp, y, bias, addend, nullptr, slope, gain, (hipStream_t)stream);
   if (fwd_k1_ok(d)) {
     hipLaunchKernelGGL(fwd_k1_kernel, dim3((unsigned)cdivll(M, 4)), dim3(256), 0, (hipStream_t)stream, x, wp, M, d->C,
                        d->ldx, d->ldw, bias, slope, gain, y, d->ldy, addend);
@@ -1628,8 +1630,7 @@ extern "C" int contrad_conv2d_dgrad_ws(const contrad_conv_desc* d, const float* 
   CONTRAD_ARG(gy && wp && dx);
   if (vec_ok(d, MODE_DGRAD)) CONTRAD_ARG(aligned16(gy, wp, dx) && aligned16(act_ref, nullptr, nullptr));
   if (conv_c32_ok(d))   // stride-1 pad-1 3x3: the same weight-stationary kernel with the filter mirrored (conv_c32.h)
-    return launch_conv_c32<MODE_DGRAD>(d, gy, wp, dx, nullptr, nullptr, act_ref, slope, gain,
-                                       st_nt_for((long long)d->N * d->H * d->W, d->ldx), (hipStream_t)stream);
+    return launch_conv_c32<MODE_DGRAD>(d, gy, wp, dx, nullptr, nullptr, act_ref, slope, gain, (hipStream_t)stream);
   // every input pixel must be covered by at least one tap of its parity class, otherwise the class
   // (whose gradient is exactly zero) still writes zeros: handled by Kg == 0 -> T == 0 -> acc = 0.
   IgemmArgs a{};

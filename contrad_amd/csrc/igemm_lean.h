@@ -697,7 +697,11 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
   // a 64-bit address, two compares and a branch (the 64 stores of a wave were ~2000 instructions; blocks of the
   // shallow-K StyleGAN2 layers spent more time here than in their 18 K-tiles).
   // activation stores of outputs no cache will hold until the consumer runs: non-temporal (aux = 2), igemm.hip st_nt_for()
-  const bool st_nt = (LEAN_ST_NT >= 0) ? (LEAN_ST_NT != 0) : (MODE != MODE_WGRAD && p.st_nt != 0);
+  // (The 128 x 128 FWD / DGRAD instances -- the headline's kernels, at the 128-VGPR limit -- do not carry the second form:
+  // with it they spill 52 - 56 bytes; the layers they serve in StyleGAN2_512 have outputs of 0.4 GB, the smallest that
+  // would qualify.)
+  constexpr bool NT_CAP = (MODE != MODE_WGRAD) && !(BM * BN > 128 * 64);
+  const bool st_nt = NT_CAP && ((LEAN_ST_NT >= 0) ? (LEAN_ST_NT != 0) : (p.st_nt != 0));
   constexpr unsigned COL_OOB = 0x40000000u;    // > every valid block-relative offset, and 2 * COL_OOB does not wrap
   unsigned colpart[TN];
 #pragma unroll
@@ -757,6 +761,11 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
     // move a buffer load across a buffer store -- and waited vmcnt(0) 64 times per thread, i.e. paid the full memory latency
     // of a load AND of the preceding store per element: a block's epilogue lasted as long as ~30 K-tiles.  A whole 32-row
     // group in flight spills the 128 x 128 instances: 8 rows keep them inside 128 VGPRs.)
+    // (The store loop exists twice, plain and non-temporal -- the cache-policy operand of a buffer store is an immediate
+    // -- behind ONE launch-uniform branch: written as a test per store the compiler kept 243 branches in the epilogue.)
+    auto store_rows = [&](auto nt_c) {
+    constexpr int ST_AUX = decltype(nt_c)::value ? 2 : 0;
+    constexpr int LD_AUX = (LEAN_LD_NT && decltype(nt_c)::value) ? 2 : 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -773,9 +782,7 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
           for (int q = 0; q < EPI_G; ++q)
 #pragma unroll
             for (int jj = 0; jj < TN; ++jj)
-              rv[q][jj] = (LEAN_LD_NT && st_nt)
-                              ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)(offs[q] + colpart[jj]), 0, 2))
-                              : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)(offs[q] + colpart[jj]), 0, 0));
+              rv[q][jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)(offs[q] + colpart[jj]), 0, LD_AUX));
         }
 #pragma unroll
         for (int q = 0; q < EPI_G; ++q) {
@@ -791,11 +798,12 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
               v *= p.gain;
               if (ref) v += rv[q][jj];
             }
-            if (st_nt) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)vo, 0, 2);
-            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)vo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)vo, 0, ST_AUX);
           }
         }
       }
+    };
+    if (st_nt) store_rows(std::true_type{}); else store_rows(std::false_type{});
   } else {
     const bool slab = (MODE == MODE_WGRAD) || p.ny > 1;              // split-K partial slab [split][M][Ncol]
     const bool pxm = (MODE == MODE_FWD) && pl_pixmajor;               // rows = images at one pixel: pitch = one image of y
@@ -822,6 +830,9 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
       // (residual addend fetched EPI_F rows at a time before that group's stores: see the row-table branch above; the
       // 128 x 128 instance has registers for 4 rows)
       constexpr int EPI_F = (BM * BN > 128 * 64) ? 4 : EPI_G;
+      auto store_fwd = [&](auto nt_c) {
+      constexpr int ST_AUX = decltype(nt_c)::value ? 2 : 0;
+      constexpr int LD_AUX = (LEAN_LD_NT && decltype(nt_c)::value) ? 2 : 0;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -838,9 +849,7 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
             for (int q = 0; q < EPI_F; ++q)
 #pragma unroll
               for (int j = 0; j < TN; ++j)
-                rv[q][j] = (LEAN_LD_NT && st_nt)
-                               ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, (int)(lanepart[j] + rowpart[q]), 0, 2))
-                               : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, (int)(lanepart[j] + rowpart[q]), 0, 0));
+                rv[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, (int)(lanepart[j] + rowpart[q]), 0, LD_AUX));
           }
 #pragma unroll
           for (int q = 0; q < EPI_F; ++q)
@@ -852,12 +861,11 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
                 v *= (v > 0.f) ? g1 : g0;
                 if (has_add) v += rv[q][j];
               }
-              if (st_nt && !slab)      // (the cache-policy operand must be an immediate: two store instructions)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)(lanepart[j] + rowpart[q]), 0, 2);
-              else
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)(lanepart[j] + rowpart[q]), 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)(lanepart[j] + rowpart[q]), 0, ST_AUX);
             }
         }
+      };
+      if (st_nt && !slab) store_fwd(std::true_type{}); else store_fwd(std::false_type{});      // (split-K slabs stay plain)
     } else {
 #pragma unroll
       for (int i = 0; i < TM; ++i)

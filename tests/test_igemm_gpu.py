@@ -327,3 +327,34 @@ def test_dgrad_split_k_equals_the_unsplit_kernel_with_fused_epilogue_and_sliced_
         again = ops.conv2d_dgrad(gy, wp, (N, H, W, C), k, k, s, p, act_ref=a_ref[..., :C], slope=0.2, gain=1.5,
                                  out=torch.zeros(N, H, W, ldx, device=dev)[..., :C])
         assert torch.equal(again, dx)                                        # fixed summation order
+
+
+def test_nontemporal_store_path_equals_the_plain_one():
+    """Outputs of >= 256 MB take non-temporal epilogue stores (igemm.hip NT_STORE_BYTES; conv_c32 kernels too): the same
+    layer on a batch whose output is 268 MB and on its two halves (134 MB each: plain stores) -- equal results (1e-6: the
+    plan may change with the batch), forward with bias / activation / addend, data gradient with the act' epilogue, for a
+    lean-engine shape and for the 32-channel weight-stationary kernel; spot-checked against PyTorch CPU."""
+    dev = torch.device('cuda')
+    g = torch.Generator(device='cuda').manual_seed(4)
+    for (N, H, C, K) in ((16, 256, 64, 64), (32, 256, 32, 32)):          # 16 * 256^2 * 64 * 4 B = 268 MB; conv_c32 shape
+        x = torch.randn(N, H, H, C, device=dev, generator=g)
+        w = torch.randn(K, C, 3, 3, device=dev, generator=g) * 0.05
+        b = torch.randn(K, device=dev, generator=g)
+        wp = ops.pack_weight(w)
+        add = torch.randn(N, H, H, K, device=dev, generator=g)
+        assert add.numel() * 4 >= 256 << 20 and add.numel() * 2 < 256 << 20
+        y = ops.conv2d_fwd(x, wp, b, K, 3, 3, 1, 1, 0.2, 1.4, addend=add)
+        h = N // 2
+        for sl in (slice(0, h), slice(h, N)):
+            yh = ops.conv2d_fwd(x[sl].contiguous(), wp, b, K, 3, 3, 1, 1, 0.2, 1.4, addend=add[sl].contiguous())
+            assert rel(y[sl], yh) < 1e-6
+        ref = F.leaky_relu(F.conv2d(x[:1].cpu().permute(0, 3, 1, 2), w.cpu(), b.cpu(), padding=1), 0.2) * 1.4
+        assert rel(y[:1].cpu(), ref.permute(0, 2, 3, 1) + add[:1].cpu()) < TOL
+        gy = torch.randn(N, H, H, K, device=dev, generator=g)
+        act = torch.randn(N, H, H, C, device=dev, generator=g)
+        dx = ops.conv2d_dgrad(gy, wp, tuple(x.shape), 3, 3, 1, 1, act_ref=act, slope=0.2, gain=1.4)
+        for sl in (slice(0, h), slice(h, N)):
+            dh = ops.conv2d_dgrad(gy[sl].contiguous(), wp, (sl.stop - sl.start, H, H, C), 3, 3, 1, 1,
+                                  act_ref=act[sl].contiguous(), slope=0.2, gain=1.4)
+            assert rel(dx[sl], dh) < 1e-6
+        del x, add, y, gy, act, dx

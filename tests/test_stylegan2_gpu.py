@@ -487,3 +487,27 @@ def test_fused_r1_trunk_equals_the_node_family(size, small32, N):
             # (biases of r1 alone flow through the stddev curvature only: tiny, fp32-conditioned -- tests/test_r1_gradient_gpu.py)
             tol = 2e-3 if (tag == 'a' and k.endswith('bias')) else 1e-4
             assert l2(gf, gn) < tol, (tag, k, l2(gf, gn))
+
+
+def test_fir_nontemporal_store_path_equals_the_plain_one():
+    """FIR outputs of >= 256 MB are stored non-temporally (stylegan2_ops.hip, UpfirdnArgs.nt_store): the blur and the
+    upsampling FIR with the fused epilogue on a 268 MB output equal the same calls on the two halves of the batch (plain
+    stores) bit for bit -- the arithmetic per output does not depend on the batch."""
+    g = torch.Generator(device=DEV).manual_seed(6)
+    k1 = torch.tensor([1., 3., 3., 1.]); k = (k1[:, None] * k1[None, :] / 64).to(DEV)
+    N, H, C = 16, 256, 64
+    x = torch.randn(N, H, H, C, device=DEV, generator=g)
+    ref = torch.randn(N, H, H, C, device=DEV, generator=g)
+    _, o = ops.upfirdn2d_fused(x, k, 1, 1, (2, 1, 2, 1), act_ref=ref, slope=0.2, gain=1.4, want_out=False, want_out2=True)
+    assert o.numel() * 4 >= 256 << 20
+    h = N // 2
+    for sl in (slice(0, h), slice(h, N)):
+        _, oh = ops.upfirdn2d_fused(x[sl].contiguous(), k, 1, 1, (2, 1, 2, 1), act_ref=ref[sl].contiguous(), slope=0.2,
+                                    gain=1.4, want_out=False, want_out2=True)
+        assert torch.equal(o[sl], oh)
+    xs = x[:, ::2, ::2].contiguous()
+    up = ops.upfirdn2d(xs, k, 2, 1, (2, 1, 2, 1))
+    assert up.numel() * 4 >= 256 << 20
+    for sl in (slice(0, h), slice(h, N)):
+        assert torch.equal(up[sl], ops.upfirdn2d(xs[sl].contiguous(), k, 2, 1, (2, 1, 2, 1)))
+    assert rel(up[:1], _upfirdn_ref(xs[:1].cpu(), k.cpu(), 2, 1, (2, 1, 2, 1))) < 1e-5
