@@ -83,3 +83,22 @@ def test_rows_are_attributed_by_launch_order(tmp_path):
         if len(f) >= 11 and l.startswith(('igemm', 'wgrad_c32', 'conv_c32', 'fwd_k1')) and f[9] != 'ambig':
             assert float(f[9]) <= 1.0, l
     assert any(l.startswith('wgrad_c32_kernel') and abs(float(l.split()[5]) - 100.0) < 1e-6 for l in plain_part.splitlines())
+
+
+def test_isa_loop_stats_finds_the_main_loops_and_they_are_not_issue_bound():
+    """tools/isa_loop_stats.py (profiles/r05_isa_loop_stats.txt): every 128x128 lean instance's main loop is found in
+    the built library's gfx950 code object and carries far fewer than the ~16 issue slots a 64-cycle
+    v_mfma_f32_32x32x2_f32 leaves its wave."""
+    import subprocess
+    import pytest
+    lib = os.path.join(ROOT, 'contrad_amd', 'csrc', 'libcontrad_hip.so')
+    if not (os.path.exists(lib) and os.path.exists('/opt/rocm/lib/llvm/bin/llvm-objdump')):
+        pytest.skip('needs the built library and llvm-objdump')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'isa_loop_stats.py'), lib], capture_output=True,
+                         text=True, check=True).stdout
+    rows = {l[:40].strip(): l[40:].split() for l in out.splitlines() if l and not l.startswith(('#', 'kernel'))}
+    for mode, mfma in ((0, 32), (1, 32), (2, 64)):
+        r = rows['igemm_lean_kernel<%d, 128, 128, false>' % mode]
+        assert int(r[1]) == mfma, r                  # K-tile of 32 MFMAs per wave (WGRAD: two K-tiles per trip)
+        assert float(r[14]) < 4.0, r                 # non-MFMA instructions per MFMA
+    assert int(rows['wgrad_c32_kernel'][1]) == 36 and float(rows['wgrad_c32_kernel'][14]) < 2.0
