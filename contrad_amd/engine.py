@@ -7,6 +7,8 @@ SUM all-reduce of the parameter gradients whose 1/world_size is folded into the 
 The discriminator's backward hands autograd views of two flat buffers (all weight gradients, all bias gradients),
 so the exchange is two large collectives over xGMI instead of DDP's 25 MB buckets.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -192,7 +194,9 @@ def d_step_stylegan2(P, G, D, opt_D, options, images, step, reducer=None, style_
     return d_loss, aux
 
 
-_MERGED_CALLS = __import__('os').environ.get('CONTRAD_DEV_MERGED', '1') != '0'       # (same-box A/B runs of bench.py)
+# One discriminator call over [two real views | fakes] with the minibatch-stddev groups kept inside each segment (True, the
+# product path: D.call_merged) or the reference's two calls; the switch serves the same-box A/B runs of bench.py (tools/dev/r5d.sh, profiles/r05_ab_merged_demod.txt).
+_MERGED_CALLS = os.environ.get('CONTRAD_DEV_MERGED', '1') != '0'
 
 
 def loss_D_fn_separate(P, D, options, images, gen_images):

@@ -8,6 +8,7 @@ penalty (train_stylegan2.py:106-113) -- works as it does in the reference.  Acti
 EqualConv2d scale 1/sqrt(fan_in) is folded into the packed weights, state-dict names match the reference.
 """
 import math
+import weakref
 
 import torch
 import torch.nn as nn
@@ -20,7 +21,7 @@ from ..base import BaseDiscriminator, PlainParams, TinyHead, _Act, make_projecti
 _SLOPE, _GAIN = 0.2, math.sqrt(2.0)
 # per-discriminator pack of the current step (ResidualDiscriminatorP._pack); outside the module so that deepcopy / pickling
 # of a discriminator never meets autograd-graph tensors
-_PACK_CACHE = __import__('weakref').WeakKeyDictionary()
+_PACK_CACHE = weakref.WeakKeyDictionary()
 _HEAD_SLOPE = 0.1
 
 
@@ -462,7 +463,7 @@ class ResidualDiscriminatorP(BaseDiscriminator):
         idx['q2'] = add(self.projection2[2].weight, dp, dh, 1, 1.0)
         meta = A.PackMeta(entries, groups)
         meta.comm = comm            # PackWeightsFn.backward then exchanges the packed gradients (data parallel)
-        owner = __import__('weakref').ref(self)
+        owner = weakref.ref(self)
         # once its backward has run the pack must not be referenced any more: a graph kept alive across a hipGraph capture
         # (its AccumulateGrad nodes are tied to the stream it ran on) crashes hipStreamEndCapture
         meta.on_backward = lambda: (_PACK_CACHE.pop(owner(), None) if owner() is not None else None)

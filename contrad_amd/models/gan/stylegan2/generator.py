@@ -17,6 +17,7 @@ Packed weights / Wsq tables are cached and rebuilt only when a parameter's versi
 the D-step).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -26,10 +27,13 @@ from .... import autograd_ops as A
 from ....hostio import upload
 
 
-# dev / test switch: the forward-only path with the upsampling StyledConv's blur + epilogue in one launch and the next
-# layer's modulation folded into the producer's store (True), or as separate passes (False; bitwise the same images)
-LEGACY_PREP = __import__('os').environ.get('CONTRAD_DEV_G_PREP', '') == 'legacy'       # (same-box A/B runs of bench.py)
-FUSE_TAIL = __import__('os').environ.get('CONTRAD_DEV_G_FUSE', '1') != '0'      # (same-box A/B runs of bench.py)
+# Switches for the same-box A/B runs of bench.py (tools/dev/r5b.sh … r5d.sh, profiles/r05_ab_g*.txt) and for the test that
+# the two forms give the same bits; the defaults are the product path.
+# FUSE_TAIL: the forward-only path with the upsampling StyledConv's blur + epilogue in one launch and the next layer's
+#   modulation folded into the producer's store (True), or as separate passes (False; bitwise the same images).
+# LEGACY_PREP: the round-4 per-layer preparation of the demodulation tables instead of the batched launches.
+LEGACY_PREP = os.environ.get('CONTRAD_DEV_G_PREP', '') == 'legacy'
+FUSE_TAIL = os.environ.get('CONTRAD_DEV_G_FUSE', '1') != '0'
 
 
 class _EqualLinearParams(nn.Module):

@@ -54,7 +54,7 @@ for c in ${KT_CONFIGS-c10_b512 sg2_32 sg2_512}; do
 done
 [ -f $O/bench_n1.json ] && tail -1 $O/bench_n1.json > $O/profiles/${TAG}_bench_n1.json
 [ -f $O/margins.txt ] && cp $O/margins.txt $O/profiles/${TAG}_test_margins.txt
-[ -f $O/pytest.log ] && tail -3 $O/pytest.log > $O/profiles/${TAG}_pytest_tail.txt
+[ -f $O/pytest.log ] && grep -E " passed| failed| error" $O/pytest.log | tail -3 > $O/profiles/${TAG}_pytest_tail.txt
 cp profiles/${TAG}_*_pmc.* $O/profiles/ 2>/dev/null
 for B in ${RANK_BATCHES-256 128 64}; do
   cp $O/b${B}_rows.txt $O/profiles/${TAG}_c10_b${B}_rank_rows.txt; cp $O/b${B}_kernel_trace.txt $O/profiles/${TAG}_c10_b${B}_rank_kernel_trace.txt; cp $O/b${B}_shapes.json $O/profiles/${TAG}_c10_b${B}_rank_shapes.json
