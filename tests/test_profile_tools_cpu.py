@@ -92,8 +92,9 @@ def test_isa_loop_stats_finds_the_main_loops_and_they_are_not_issue_bound():
     import subprocess
     import pytest
     lib = os.path.join(ROOT, 'contrad_amd', 'csrc', 'libcontrad_hip.so')
-    if not (os.path.exists(lib) and os.path.exists('/opt/rocm/lib/llvm/bin/llvm-objdump')):
-        pytest.skip('needs the built library and llvm-objdump')
+    import shutil
+    if not (os.path.exists(lib) and os.path.exists('/opt/rocm/lib/llvm/bin/llvm-objdump') and shutil.which('c++filt')):
+        pytest.skip('needs the built library, llvm-objdump and c++filt')
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'isa_loop_stats.py'), lib], capture_output=True,
                          text=True, check=True).stdout
     rows = {l[:40].strip(): l[40:].split() for l in out.splitlines() if l and not l.startswith(('#', 'kernel'))}
