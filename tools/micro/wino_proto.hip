@@ -1,0 +1,311 @@
+// Prototype (round 6): Winograd F(2x2, 3x3) in exact fp32 on v_mfma_f32_32x32x2_f32 for the 3x3 stride-1
+// pad-1 layers, input and output transforms in registers / LDS (nothing transformed ever reaches HBM).
+//
+//   y = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A        16 independent GEMMs  M_xi[tile][k] = sum_c V_xi[tile][c] U_xi[c][k]
+//
+// Block = 64 tiles (8 x 8 tiles = a 16 x 16 output patch of one image) x 64 output channels x all 16 xi, 4 waves, ONE
+// wave per SIMD: wave (wm, wn) owns tiles wm*32.. x couts wn*32.. for all 16 xi = 16 accumulator tiles = 256 registers,
+// so the output transform is per-lane register arithmetic.  The contraction runs in 8-channel chunks; per chunk a wave
+// issues 64 MFMAs (4096 matrix-pipe cycles) and, between them, its share of the NEXT chunk's staging: 8 buffer loads of x
+// + 8 of U, 64 VALU of input transform (column stage in registers, row stage with one DPP exchange between the two
+// lanes that share a tile), 16 ds_write_b128, and the 32 ds_read_b128 of its own fragments.
+//
+// standalone: hipcc --offload-arch=gfx950 -O3 -o wino_proto wino_proto.hip && ./wino_proto
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifndef WINO_KQS
+#define WINO_KQS 260      // dwords per k-quad plane: 64 rows x 4 + pad
+#endif
+#ifndef WINO_PL
+#define WINO_PL 528       // dwords per xi plane (2 k-quads); = 16 (mod 32): the two lanes of a tile write planes an odd
+#endif                    // number apart in one ds_write_b128 -> their 8-lane group covers all 32 banks once
+constexpr int KQS = WINO_KQS, PL = WINO_PL;
+constexpr int V_SZ = 16 * PL;          // V (transformed input) then U (transformed filter)
+constexpr int BUF = 2 * V_SZ;          // one stage: 67 584 B; two stages 135 168 B
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const float* base, bool on) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, on ? (int)0x80000000u : 0, 0x00020000);
+}
+__device__ __forceinline__ float dpp_swap1(float v) {   // value of the neighbouring lane (lane ^ 1): quad_perm [1,0,3,2]
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
+struct WinoArgs {
+  const float* x;    // [N][H][W][C]
+  const float* U;    // [16][C/8][2][K][4]   (xi, chunk, k-quad, cout, 4 channels); xi = (a, 3) planes negated
+  float* y;          // [N][H][W][K]
+  int N, H, W, C, K;
+  int PH, PW;        // 16 x 16 output patches per image
+};
+
+__global__ __launch_bounds__(256, 1) void wino_fwd(const WinoArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // block -> (patch, cout block): the cout blocks of a patch are neighbours on one XCD (they read the same x)
+  const int NKB = p.K / 64;
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int kb = jb % NKB, patch = (jb / NKB) * 8 + xcd;
+  const int ppi = p.PH * p.PW;
+  const int n = patch / ppi, pr = patch - n * ppi;
+  const int ph = pr / p.PW, pw = pr - ph * p.PW;
+  const int n0 = kb * 64;
+  const int NCH = p.C / 8;
+
+  // ---- staging roles ----
+  // x: (half, tile, kq): the lane pair of a tile splits its 4 columns; register A = the column the partner needs
+  const int half = tid & 1, tile = (tid >> 1) & 63, kq = tid >> 7;
+  const int ty = tile >> 3, tx = tile & 7;
+  const int h0 = ph * 16 + ty * 2 - 1, w0 = pw * 16 + tx * 2 - 1;
+  const int colA = w0 + (half ? 2 : 1), colB = w0 + (half ? 3 : 0);
+  unsigned vxA[4], vxB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int hh = h0 + i;
+    const bool rok = (unsigned)hh < (unsigned)p.H;
+    vxA[i] = (rok && (unsigned)colA < (unsigned)p.W) ? (unsigned)(((hh * p.W + colA) * p.C + kq * 4) * 4) : OOB;
+    vxB[i] = (rok && (unsigned)colB < (unsigned)p.W) ? (unsigned)(((hh * p.W + colB) * p.C + kq * 4) * 4) : OOB;
+  }
+  const float sgn = half ? -1.f : 1.f;
+  const float* xbase = p.x + (size_t)n * p.H * p.W * p.C;
+  // V planes this lane writes for tile row i: out0 -> (i, half ? 3 : 0), out1 -> (i, half ? 2 : 1)
+  const int wrV0 = (half ? 3 : 0) * PL + kq * KQS + tile * 4;
+  const int wrV1 = (half ? 2 : 1) * PL + kq * KQS + tile * 4;
+  // U: (cout, kq, xi group): 8 planes per thread
+  const int ucout = tid & 63, ukq = (tid >> 6) & 1, uxg = tid >> 7;
+  unsigned vu[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int xi = uxg * 8 + i;
+    vu[i] = (unsigned)(((((size_t)xi * NCH) * 2 + ukq) * p.K + n0 + ucout) * 16);
+  }
+  const unsigned u_step = (unsigned)(2 * p.K * 16);     // bytes per chunk in U
+  const int wrU = V_SZ + (uxg * 8) * PL + ukq * KQS + ucout * 4;
+
+  // fragment reads
+  const int rdA = lhi * KQS + (wm * 32 + l31) * 4;
+  const int rdB = V_SZ + lhi * KQS + (wn * 32 + l31) * 4;
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  float4 rxA[4], rxB[4], ru[8];
+  float tA[4][4], tB[4][4];     // column-stage results [row i][channel]
+
+  auto load_x = [&](int t, int i) {   // i = 0..7
+#ifdef ABL_NOXLOAD
+    return;
+#endif
+    const __amdgpu_buffer_rsrc_t rs = rsrc(xbase, t < NCH);
+    const unsigned so = (unsigned)t * 32u;
+    if (i < 4) rxA[i] = bload4(rs, vxA[i], so); else rxB[i - 4] = bload4(rs, vxB[i - 4], so);
+  };
+  auto load_u = [&](int t, int i) {
+#ifdef ABL_NOULOAD
+    return;
+#endif
+    const __amdgpu_buffer_rsrc_t rs = rsrc(p.U, t < NCH);
+    ru[i] = bload4(rs, vu[i], (unsigned)t * u_step);
+  };
+  auto col_stage = [&](int c) {   // channel component c of the lane's two columns: t = B^T d
+    const float a0 = ((const float*)&rxA[0])[c], a1 = ((const float*)&rxA[1])[c], a2 = ((const float*)&rxA[2])[c], a3 = ((const float*)&rxA[3])[c];
+    const float b0 = ((const float*)&rxB[0])[c], b1 = ((const float*)&rxB[1])[c], b2 = ((const float*)&rxB[2])[c], b3 = ((const float*)&rxB[3])[c];
+    tA[0][c] = a0 - a2; tA[1][c] = a1 + a2; tA[2][c] = a2 - a1; tA[3][c] = a1 - a3;
+    tB[0][c] = b0 - b2; tB[1][c] = b1 + b2; tB[2][c] = b2 - b1; tB[3][c] = b1 - b3;
+  };
+  auto row_stage_store = [&](int bufoff, int i) {   // tile row i: (.) B across the lane pair, two planes out
+    float4 o0, o1;
+    float* q0 = (float*)&o0; float* q1 = (float*)&o1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float r = dpp_swap1(tA[i][c]);
+      q0[c] = tB[i][c] - r;                 // half 0: V[i][0];  half 1: -V[i][3]  (U's (., 3) planes are negated)
+      q1[c] = __builtin_fmaf(sgn, r, tA[i][c]);   // half 0: V[i][1];  half 1: V[i][2]   ... see below
+    }
+    *reinterpret_cast<float4*>(smem + bufoff + wrV0 + i * 4 * PL) = o0;
+    *reinterpret_cast<float4*>(smem + bufoff + wrV1 + i * 4 * PL) = o1;
+  };
+  auto store_u = [&](int bufoff, int i) {
+    *reinterpret_cast<float4*>(smem + bufoff + wrU + i * PL) = ru[i];
+  };
+
+  // ---- prologue: chunk 0 into stage 0, chunk 1 into flight ----
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { load_x(0, i); load_u(0, i); }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) col_stage(c);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) store_u(0, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) row_stage_store(0, i);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { load_x(1, i); load_u(1, i); }
+  __syncthreads();
+
+  auto chunk = [&](auto par, const int t) {
+    constexpr int cur = decltype(par)::value * BUF, nxt = BUF - cur;
+    float4 fa[2], fb[2];
+    fa[0] = *reinterpret_cast<const float4*>(smem + cur + rdA);
+    fb[0] = *reinterpret_cast<const float4*>(smem + cur + rdB);
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) {
+      if (xi + 1 < 16) {
+        fa[(xi + 1) & 1] = *reinterpret_cast<const float4*>(smem + cur + rdA + (xi + 1) * PL);
+        fb[(xi + 1) & 1] = *reinterpret_cast<const float4*>(smem + cur + rdB + (xi + 1) * PL);
+      }
+      // staging of chunk t + 1 (registers -> transform -> stage nxt), then chunk t + 2 into flight
+#ifndef ABL_NOSTAGE
+      if (xi < 4) { col_stage(xi); store_u(nxt, 2 * xi); store_u(nxt, 2 * xi + 1); }
+#endif
+      if (xi >= 4 && xi < 8) {
+#ifndef ABL_NOSTAGE
+        row_stage_store(nxt, xi - 4);
+#endif
+        load_x(t + 2, 2 * (xi - 4)); load_x(t + 2, 2 * (xi - 4) + 1);
+        load_u(t + 2, 2 * (xi - 4)); load_u(t + 2, 2 * (xi - 4) + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const float* a = (const float*)&fa[xi & 1];
+      const float* b = (const float*)&fb[xi & 1];
+#pragma unroll
+#ifndef ABL_NOMFMA
+      for (int j = 0; j < 4; ++j) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[xi], 0, 0, 0);
+#else
+      for (int j = 0; j < 4; ++j) acc[xi][j] += a[j] * b[j];
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#ifndef ABL_NOBARRIER
+    __syncthreads();
+#endif
+  };
+  for (int t = 0; t < NCH; t += 2) {
+    chunk(std::integral_constant<int, 0>{}, t);
+    chunk(std::integral_constant<int, 1>{}, t + 1);     // (C % 16 == 0)
+  }
+
+  // ---- output transform (per lane) and store ----
+  const int cout = n0 + wn * 32 + l31;
+  float* ybase = p.y + (size_t)n * p.H * p.W * p.K + cout;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int tl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+    const int oy = ph * 16 + (tl >> 3) * 2, ox = pw * 16 + (tl & 7) * 2;
+    float s0[4], s1[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float m0 = acc[a * 4 + 0][r], m1 = acc[a * 4 + 1][r], m2 = acc[a * 4 + 2][r], m3 = acc[a * 4 + 3][r];
+      s0[a] = m0 + m1 + m2;
+      s1[a] = m1 - m2 - m3;
+    }
+    const float y00 = s0[0] + s0[1] + s0[2], y01 = s1[0] + s1[1] + s1[2];
+    const float y10 = s0[1] - s0[2] - s0[3], y11 = s1[1] - s1[2] - s1[3];
+    float* q = ybase + ((size_t)oy * p.W + ox) * p.K;
+    q[0] = y00; q[p.K] = y01;
+    q[(size_t)p.W * p.K] = y10; q[(size_t)p.W * p.K + p.K] = y11;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+static void make_U(const std::vector<float>& w, int C, int K, std::vector<float>& U) {   // w: [K][C][3][3]
+  const float G[4][3] = {{1, 0, 0}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0, 0, 1}};
+  const int NCH = C / 8;
+  U.assign((size_t)16 * C * K, 0.f);
+  for (int k = 0; k < K; ++k)
+    for (int c = 0; c < C; ++c) {
+      const float* g = &w[((size_t)k * C + c) * 9];
+      float t[4][3], u[4][4];
+      for (int a = 0; a < 4; ++a) for (int j = 0; j < 3; ++j) t[a][j] = G[a][0] * g[0 * 3 + j] + G[a][1] * g[1 * 3 + j] + G[a][2] * g[2 * 3 + j];
+      for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) u[a][b] = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
+      for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) {
+        const int xi = a * 4 + b, ch = c / 8, kq = (c % 8) / 4, j = c % 4;
+        U[((((size_t)xi * NCH + ch) * 2 + kq) * K + k) * 4 + j] = (b == 3) ? -u[a][b] : u[a][b];
+      }
+    }
+}
+
+static double run_case(int N, int H, int C, int K, int reps) {
+  const int W = H;
+  const size_t nx = (size_t)N * H * W * C, ny = (size_t)N * H * W * K;
+  std::vector<float> hx(nx), hw((size_t)K * C * 9), hU;
+  unsigned s = 12345u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xFFFF) / 65536.f - 0.5f; };
+  for (auto& v : hx) v = rnd();
+  for (auto& v : hw) v = rnd() * 0.1f;
+  make_U(hw, C, K, hU);
+  float *dx, *dU, *dy;
+  (void)hipMalloc(&dx, nx * 4); (void)hipMalloc(&dU, hU.size() * 4); (void)hipMalloc(&dy, ny * 4);
+  (void)hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(dU, hU.data(), hU.size() * 4, hipMemcpyHostToDevice);
+  (void)hipMemset(dy, 0xFF, ny * 4);
+  WinoArgs a{dx, dU, dy, N, H, W, C, K, H / 16, W / 16};
+  const int patches = N * a.PH * a.PW, blocks = patches * (K / 64);
+  const size_t lds = 2 * BUF * 4;
+  (void)hipFuncSetAttribute((const void*)wino_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(wino_fwd, dim3(blocks), dim3(256), lds, 0, a);
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(e)); return -1; }
+  std::vector<float> hy(ny);
+  (void)hipMemcpy(hy.data(), dy, ny * 4, hipMemcpyDeviceToHost);
+  // sampled check against a double-precision direct correlation
+  double maxerr = 0, maxref = 0, sse = 0, ssr = 0;
+  for (int it = 0; it < 4096; ++it) {
+    s = s * 1664525u + 1013904223u; const int nn = (s >> 8) % N;
+    s = s * 1664525u + 1013904223u; int hh = (s >> 8) % H;
+    s = s * 1664525u + 1013904223u; int ww = (s >> 8) % W;
+    s = s * 1664525u + 1013904223u; const int kk = (s >> 8) % K;
+    if (it < 64) { hh = (it & 1) ? H - 1 : 0; ww = (it & 2) ? W - 1 : 0; }   // corners
+    double ref = 0;
+    for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw) {
+      const int ih = hh - 1 + kh, iw = ww - 1 + kw;
+      if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
+      const float* xp = &hx[(((size_t)nn * H + ih) * W + iw) * C];
+      for (int c = 0; c < C; ++c) ref += (double)xp[c] * hw[((size_t)kk * C + c) * 9 + kh * 3 + kw];
+    }
+    const double got = hy[(((size_t)nn * H + hh) * W + ww) * K + kk];
+    maxerr = fmax(maxerr, fabs(got - ref)); maxref = fmax(maxref, fabs(ref));
+    sse += (got - ref) * (got - ref); ssr += ref * ref;
+  }
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(wino_fwd, dim3(blocks), dim3(256), lds, 0, a);
+  (void)hipEventRecord(e0);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(wino_fwd, dim3(blocks), dim3(256), lds, 0, a);
+  (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+  const double dense = 2.0 * N * H * W * (double)K * C * 9, issued = dense / 2.25;
+  printf("N%-5d H%-4d C%-4d K%-4d  blocks %6d  %8.1f us  nominal %6.1f TF/s  issued %6.1f TF/s (%.3f of 157.3)  max|err| %.3g (max|ref| %.3g)  rel-L2 %.3g\n",
+         N, H, C, K, blocks, ms * 1e3, dense / ms / 1e9, issued / ms / 1e9, issued / ms / 1e9 / 157.3, maxerr, maxref, sqrt(sse / ssr));
+  (void)hipFree(dx); (void)hipFree(dU); (void)hipFree(dy);
+  return ms;
+}
+
+int main(int argc, char** argv) {
+  const int reps = argc > 1 ? atoi(argv[1]) : 20;
+#ifdef ABL_ANY
+  run_case(1536, 16, 128, 128, reps); run_case(48, 128, 128, 128, reps); return 0;
+#endif
+  run_case(8, 16, 128, 128, 2);            // small: correctness first
+  run_case(1536, 16, 128, 128, reps);      // headline layer (today FWD 863 us in the step, ~800 alone)
+  run_case(48, 128, 128, 128, reps);       // StyleGAN2_512 conv1 at 128^2 (1863 in the step, 1620 alone)
+  run_case(1536, 16, 128, 128, reps);
+  run_case(48, 128, 128, 128, reps);
+  run_case(48, 64, 256, 256, reps);
+  run_case(48, 32, 512, 512, reps);
+  return 0;
+}
