@@ -21,7 +21,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifndef WINO_KQS
-#define WINO_KQS 260      // dwords per k-quad plane: 64 rows x 4 + pad
+#define WINO_KQS 264      // dwords per k-quad plane: 64 rows x 4 + pad; = 8 (mod 32)
 #endif
 #ifndef WINO_PL
 #define WINO_PL 528       // dwords per xi plane (2 k-quads); = 16 (mod 32): the two lanes of a tile write planes an odd
@@ -29,6 +29,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int KQS = WINO_KQS, PL = WINO_PL;
 constexpr int V_SZ = 16 * PL;          // V (transformed input) then U (transformed filter)
 constexpr int BUF = 2 * V_SZ;          // one stage: 67 584 B; two stages 135 168 B
+constexpr int RAW_SZ = 18 * 18 * 8;   // raw input patch of one chunk: [pixel][8 channels]
+constexpr int RAW0 = 2 * BUF;
+constexpr int LDS_DWORDS = 2 * BUF + 2 * RAW_SZ;   // 155 904 B
 constexpr unsigned OOB = 0x80000000u;
 
 __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -65,22 +68,27 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const WinoArgs p) {
   const int n0 = kb * 64;
   const int NCH = p.C / 8;
 
-  // ---- staging roles ----
-  // x: (half, tile, kq): the lane pair of a tile splits its 4 columns; register A = the column the partner needs
-  const int half = tid & 1, tile = (tid >> 1) & 63, kq = tid >> 7;
-  const int ty = tile >> 3, tx = tile & 7;
-  const int h0 = ph * 16 + ty * 2 - 1, w0 = pw * 16 + tx * 2 - 1;
-  const int colA = w0 + (half ? 2 : 1), colB = w0 + (half ? 3 : 0);
-  unsigned vxA[4], vxB[4];
+  // ---- raw patch: 18 x 18 pixels x 8 channels, every pixel fetched ONCE per block (v1 fetched it per tile: 3.2x) ----
+  // item = pixel * 2 + kq; thread: items tid, tid + 256, tid + 512 (< 648)
+  unsigned vraw[3];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int hh = h0 + i;
-    const bool rok = (unsigned)hh < (unsigned)p.H;
-    vxA[i] = (rok && (unsigned)colA < (unsigned)p.W) ? (unsigned)(((hh * p.W + colA) * p.C + kq * 4) * 4) : OOB;
-    vxB[i] = (rok && (unsigned)colB < (unsigned)p.W) ? (unsigned)(((hh * p.W + colB) * p.C + kq * 4) * 4) : OOB;
+  for (int i = 0; i < 3; ++i) {
+    const int item = tid + 256 * i, px = item >> 1, q = item & 1;
+    const int r = px / 18, c = px - r * 18;
+    const int hh = ph * 16 - 1 + r, ww = pw * 16 - 1 + c;
+    vraw[i] = (item < 648 && (unsigned)hh < (unsigned)p.H && (unsigned)ww < (unsigned)p.W)
+                  ? (unsigned)(((hh * p.W + ww) * p.C + q * 4) * 4) : OOB;
   }
-  const float sgn = half ? -1.f : 1.f;
+  const bool raw3 = tid + 512 < 648;
   const float* xbase = p.x + (size_t)n * p.H * p.W * p.C;
+
+  // ---- transform roles: (half, kq, tile): the lane pair of a tile splits its 4 columns; register A = the column the
+  // partner needs ----
+  const int half = tid & 1, kq = (tid >> 1) & 1, tile = tid >> 2;
+  const int ty = tile >> 3, tx = tile & 7;
+  const int rdRawA = ((2 * ty) * 18 + 2 * tx + (half ? 2 : 1)) * 8 + kq * 4;
+  const int rdRawB = ((2 * ty) * 18 + 2 * tx + (half ? 3 : 0)) * 8 + kq * 4;
+  const float sgn = half ? -1.f : 1.f;
   // V planes this lane writes for tile row i: out0 -> (i, half ? 3 : 0), out1 -> (i, half ? 2 : 1)
   const int wrV0 = (half ? 3 : 0) * PL + kq * KQS + tile * 4;
   const int wrV1 = (half ? 2 : 1) * PL + kq * KQS + tile * 4;
@@ -105,16 +113,26 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const WinoArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  float4 rxA[4], rxB[4], ru[8];
+  float4 rraw[3], ru[8];
+  float4 rxA[4], rxB[4];
   float tA[4][4], tB[4][4];     // column-stage results [row i][channel]
 
-  auto load_x = [&](int t, int i) {   // i = 0..7
+  auto load_raw = [&](int t, int i) {
 #ifdef ABL_NOXLOAD
     return;
 #endif
     const __amdgpu_buffer_rsrc_t rs = rsrc(xbase, t < NCH);
-    const unsigned so = (unsigned)t * 32u;
-    if (i < 4) rxA[i] = bload4(rs, vxA[i], so); else rxB[i - 4] = bload4(rs, vxB[i - 4], so);
+    rraw[i] = bload4(rs, vraw[i], (unsigned)t * 32u);
+  };
+  auto store_raw = [&](int stage, int i) {
+    if (i < 2 || raw3) *reinterpret_cast<float4*>(smem + RAW0 + stage * RAW_SZ + (tid + 256 * i) * 4) = rraw[i];
+  };
+  auto read_raw = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      rxA[i] = *reinterpret_cast<const float4*>(smem + RAW0 + stage * RAW_SZ + rdRawA + i * 18 * 8);
+      rxB[i] = *reinterpret_cast<const float4*>(smem + RAW0 + stage * RAW_SZ + rdRawB + i * 18 * 8);
+    }
   };
   auto load_u = [&](int t, int i) {
 #ifdef ABL_NOULOAD
@@ -135,8 +153,8 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const WinoArgs p) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float r = dpp_swap1(tA[i][c]);
-      q0[c] = tB[i][c] - r;                 // half 0: V[i][0];  half 1: -V[i][3]  (U's (., 3) planes are negated)
-      q1[c] = __builtin_fmaf(sgn, r, tA[i][c]);   // half 0: V[i][1];  half 1: V[i][2]   ... see below
+      q0[c] = tB[i][c] - r;                       // half 0: V[i][0];  half 1: -V[i][3]  (U's (., 3) planes are negated)
+      q1[c] = __builtin_fmaf(sgn, r, tA[i][c]);   // half 0: V[i][1];  half 1: V[i][2]
     }
     *reinterpret_cast<float4*>(smem + bufoff + wrV0 + i * 4 * PL) = o0;
     *reinterpret_cast<float4*>(smem + bufoff + wrV1 + i * 4 * PL) = o1;
@@ -145,21 +163,37 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const WinoArgs p) {
     *reinterpret_cast<float4*>(smem + bufoff + wrU + i * PL) = ru[i];
   };
 
-  // ---- prologue: chunk 0 into stage 0, chunk 1 into flight ----
+  // ---- prologue: chunk 0 transformed into stage 0, raw chunk 1 in LDS, raw chunk 2 and U chunk 1 in flight ----
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { load_x(0, i); load_u(0, i); }
+  for (int i = 0; i < 3; ++i) load_raw(0, i);
 #pragma unroll
-  for (int c = 0; c < 4; ++c) col_stage(c);
+  for (int i = 0; i < 8; ++i) load_u(0, i);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) store_raw(0, i);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) load_raw(1, i);
 #pragma unroll
   for (int i = 0; i < 8; ++i) store_u(0, i);
 #pragma unroll
+  for (int i = 0; i < 8; ++i) load_u(1, i);
+  __syncthreads();
+  read_raw(0);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) col_stage(c);
+#pragma unroll
   for (int i = 0; i < 4; ++i) row_stage_store(0, i);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { load_x(1, i); load_u(1, i); }
+  for (int i = 0; i < 3; ++i) store_raw(1, i);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) load_raw(2, i);
   __syncthreads();
 
+  // iteration t: MFMAs on stage t & 1;  raw (t + 1) [LDS stage (t+1)&1] -> transform -> V stage (t+1)&1;
+  //              raw (t + 2) registers -> LDS raw stage t & 1;  raw (t + 3) into flight;
+  //              U (t + 1) registers -> U stage (t+1)&1;  U (t + 2) into flight
   auto chunk = [&](auto par, const int t) {
-    constexpr int cur = decltype(par)::value * BUF, nxt = BUF - cur;
+    constexpr int P = decltype(par)::value;
+    constexpr int cur = P * BUF, nxt = BUF - cur;
     float4 fa[2], fb[2];
     fa[0] = *reinterpret_cast<const float4*>(smem + cur + rdA);
     fb[0] = *reinterpret_cast<const float4*>(smem + cur + rdB);
@@ -169,17 +203,16 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const WinoArgs p) {
         fa[(xi + 1) & 1] = *reinterpret_cast<const float4*>(smem + cur + rdA + (xi + 1) * PL);
         fb[(xi + 1) & 1] = *reinterpret_cast<const float4*>(smem + cur + rdB + (xi + 1) * PL);
       }
-      // staging of chunk t + 1 (registers -> transform -> stage nxt), then chunk t + 2 into flight
 #ifndef ABL_NOSTAGE
-      if (xi < 4) { col_stage(xi); store_u(nxt, 2 * xi); store_u(nxt, 2 * xi + 1); }
-#endif
-      if (xi >= 4 && xi < 8) {
-#ifndef ABL_NOSTAGE
-        row_stage_store(nxt, xi - 4);
-#endif
-        load_x(t + 2, 2 * (xi - 4)); load_x(t + 2, 2 * (xi - 4) + 1);
-        load_u(t + 2, 2 * (xi - 4)); load_u(t + 2, 2 * (xi - 4) + 1);
+      if (xi == 0) read_raw(1 - P);
+      if (xi == 1) { store_raw(P, 0); store_raw(P, 1); store_raw(P, 2); }
+      if (xi == 2) { load_raw(t + 3, 0); load_raw(t + 3, 1); load_raw(t + 3, 2); }
+      if (xi >= 2 && xi < 6) { col_stage(xi - 2); store_u(nxt, 2 * (xi - 2)); store_u(nxt, 2 * (xi - 2) + 1); }
+      if (xi >= 6 && xi < 10) {
+        row_stage_store(nxt, xi - 6);
+        load_u(t + 2, 2 * (xi - 6)); load_u(t + 2, 2 * (xi - 6) + 1);
       }
+#endif
       __builtin_amdgcn_sched_barrier(0);
       const float* a = (const float*)&fa[xi & 1];
       const float* b = (const float*)&fb[xi & 1];
@@ -256,7 +289,7 @@ static double run_case(int N, int H, int C, int K, int reps) {
   (void)hipMemset(dy, 0xFF, ny * 4);
   WinoArgs a{dx, dU, dy, N, H, W, C, K, H / 16, W / 16};
   const int patches = N * a.PH * a.PW, blocks = patches * (K / 64);
-  const size_t lds = 2 * BUF * 4;
+  const size_t lds = (size_t)LDS_DWORDS * 4;
   (void)hipFuncSetAttribute((const void*)wino_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(wino_fwd, dim3(blocks), dim3(256), lds, 0, a);
   hipError_t e = hipDeviceSynchronize();
@@ -297,6 +330,7 @@ static double run_case(int N, int H, int C, int K, int reps) {
 
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 20;
+  if (argc > 2) { run_case(48, 128, 128, 128, reps); return 0; }   // one shape (counter runs)
 #ifdef ABL_ANY
   run_case(1536, 16, 128, 128, reps); run_case(48, 128, 128, 128, reps); return 0;
 #endif
