@@ -814,6 +814,85 @@ int launch(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
 #include "igemm_lean.h"
 #include "wgrad_c32.h"
 #include "conv_c32.h"
+#include "wino.h"
+
+// ---------------- Winograd F(2x2, 3x3) path (wino.h): 3x3 stride-1 pad-1 layers, forward and data gradient ----------------
+// Can the shape run on wino_kernel<mode> at all?  (input channels % 16, output channels % 64, power-of-two maps >= 4)
+bool wino_ok(const contrad_conv_desc* d, int mode) {
+  if (mode != MODE_FWD && mode != MODE_DGRAD) return false;
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1) return false;
+  if (d->H < 4 || d->W < 4 || (d->H & (d->H - 1)) || (d->W & (d->W - 1))) return false;
+  const int cin = mode == MODE_FWD ? d->C : d->K, cout = mode == MODE_FWD ? d->K : d->C;
+  const int ldi = mode == MODE_FWD ? d->ldx : d->ldy, ldo = mode == MODE_FWD ? d->ldy : d->ldx;
+  if ((cin & 15) || (cout & 63) || (ldi & 3) || (d->ldw & 3)) return false;
+  const int th = std::min(8, d->H / 2), tw = std::min(8, d->W / 2);
+  const long long nimg = 64 / (th * tw);
+  if (nimg > 16) return false;
+  const long long lim = 1ll << 31;
+  if (nimg * d->H * d->W * std::max(ldi, ldo) * 4 >= lim) return false;     // block-relative byte offsets
+  if (16ll * cin * cout * 4 >= lim) return false;
+  return true;
+}
+
+wino::Args wino_args(const contrad_conv_desc* d, int mode) {
+  wino::Args a{};
+  a.N = d->N; a.H = d->H; a.W = d->W;
+  a.Cin = mode == MODE_FWD ? d->C : d->K;
+  a.Cout = mode == MODE_FWD ? d->K : d->C;
+  a.ldi = mode == MODE_FWD ? d->ldx : d->ldy;
+  a.ldo = mode == MODE_FWD ? d->ldy : d->ldx;
+  a.TH = std::min(8, d->H / 2); a.TW = std::min(8, d->W / 2);
+  a.sh_tw = __builtin_ctz(a.TW); a.sh_thw = __builtin_ctz(a.TH * a.TW);
+  a.NIMG = 64 / (a.TH * a.TW);
+  a.PH = d->H / (2 * a.TH); a.PW = d->W / (2 * a.TW);
+  a.NP = cdiv(d->N, a.NIMG) * a.PH * a.PW;
+  a.NKB = a.Cout / 64;
+  // raw box: with the halo (pixels outside the image load as zeros) when the image has several patches along the axis,
+  // else the image itself (the halo reads the zero pixel)
+  a.BH = a.PH > 1 ? 2 * a.TH + 2 : d->H; a.r_org = a.PH > 1 ? -1 : 0;
+  a.BW = a.PW > 1 ? 2 * a.TW + 2 : d->W; a.c_org = a.PW > 1 ? -1 : 0;
+  return a;
+}
+
+long long wino_items(const contrad_conv_desc* d, int mode) {
+  const wino::Args a = wino_args(d, mode);
+  return (long long)a.NP * a.NKB;
+}
+
+constexpr int WINO_CUS = 256;      // one persistent block per CU of the MI355X
+
+// Does the plan send the layer there?  A block is a whole CU and an item (64 tiles x 64 couts x all channels) its unit of
+// work: the launch needs about a round of items, and the last round must not be mostly empty.
+bool wino_planned(const contrad_conv_desc* d, int mode) {
+  static const bool enabled = []() { const char* e = contrad_dev_env("CONTRAD_WINO"); return !(e && e[0] == '0'); }();
+  if (!enabled || !wino_ok(d, mode)) return false;
+  const long long items = wino_items(d, mode);
+  const long long rounds = cdivll(items, WINO_CUS);
+  return items >= 200 && rounds * WINO_CUS * 10 <= items * 14;
+}
+
+long long wino_workspace_bytes(const contrad_conv_desc* d) { return 16ll * d->C * d->K * (long long)sizeof(float); }
+
+int wino_grid(const wino::Args& a) {
+  const int l0 = cdiv(a.NP, 8) * a.NKB;           // items of the fullest XCD
+  return 8 * std::min(WINO_CUS / 8, l0);
+}
+
+template <int MODE>
+int launch_wino(const contrad_conv_desc* d, const float* in, const float* wp, const float* bias, const float* ref,
+                float* out, float slope, float gain, float* U, hipStream_t stream) {
+  static const hipError_t attr = hipFuncSetAttribute((const void*)wino::wino_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     wino::LDS_DWORDS * 4);
+  if (attr != hipSuccess) return (int)attr;
+  wino::Args a = wino_args(d, MODE);
+  a.x = in; a.U = U; a.y = out; a.bias = bias; a.ref = ref; a.slope = slope; a.gain = gain;
+  const int quads = (a.Cin / 4) * a.Cout;
+  hipLaunchKernelGGL(wino::wino_filter_kernel<MODE>, dim3(cdiv(quads, 256)), dim3(256), 0, stream, wp, U, d->C, d->K, d->ldw);
+  CONTRAD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(wino::wino_kernel<MODE>, dim3(wino_grid(a)), dim3(512), wino::LDS_DWORDS * 4, stream, a);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
 
 template <int MODE, int BM, int BN, bool BAL>
 int launch_lean_inst(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
@@ -1544,6 +1623,7 @@ extern "C" int contrad_abi_version(void) { return 2; }
 
 extern "C" long long contrad_conv2d_fwd_workspace_bytes(const contrad_conv_desc* d) {
   if (check_desc(d)) return -22;
+  if (wino_planned(d, MODE_FWD)) return wino_workspace_bytes(d);
   const FwdPlan p = fwd_plan(d);
   if (p.splits <= 1) return 0;
   return (long long)p.splits * d->N * d->Ho * d->Wo * d->K * (long long)sizeof(float);
@@ -1562,6 +1642,10 @@ extern "C" int contrad_conv2d_fwd_add(const contrad_conv_desc* d, const float* x
   CONTRAD_ARG(M < (1ll << 31));
   a.M = (int)M; a.Ncol = d->K; a.Kg = d->KH * d->KW * d->C;
   a.st_nt = st_nt_for(M, d->ldy);
+  if (wino_planned(d, MODE_FWD) && workspace && workspace_bytes >= wino_workspace_bytes(d)) {   // Winograd F(2x2, 3x3), wino.h
+    CONTRAD_ARG(aligned16(x, wp, workspace));
+    return launch_wino<MODE_FWD>(d, x, wp, bias, addend, y, slope, gain, workspace, (hipStream_t)stream);
+  }
   if (conv_c32_ok(d))   // weight-stationary kernel (conv_c32.h); (alignment is an argument error above, so the dispatch is
                         // exactly what contrad_conv2d_path / _grid_blocks report)
     return launch_conv_c32<MODE_FWD>(d, x, wp, y, bias, addend, nullptr, slope, gain, (hipStream_t)stream);
@@ -1617,6 +1701,7 @@ extern "C" int contrad_conv2d_fwd(const contrad_conv_desc* d, const float* x, co
 
 extern "C" long long contrad_conv2d_dgrad_workspace_bytes(const contrad_conv_desc* d) {
   if (check_desc(d)) return -22;
+  if (wino_planned(d, MODE_DGRAD)) return wino_workspace_bytes(d);
   const FwdPlan p = dgrad_plan(d, true);
   if (p.splits <= 1) return 0;
   return (long long)p.splits * d->N * d->H * d->W * d->ldx * (long long)sizeof(float);
@@ -1629,6 +1714,10 @@ extern "C" int contrad_conv2d_dgrad_ws(const contrad_conv_desc* d, const float* 
   if (rc) return rc;
   CONTRAD_ARG(gy && wp && dx);
   if (vec_ok(d, MODE_DGRAD)) CONTRAD_ARG(aligned16(gy, wp, dx) && aligned16(act_ref, nullptr, nullptr));
+  if (wino_planned(d, MODE_DGRAD) && workspace && workspace_bytes >= wino_workspace_bytes(d)) {   // wino.h: mirrored filter
+    CONTRAD_ARG(aligned16(gy, wp, workspace));
+    return launch_wino<MODE_DGRAD>(d, gy, wp, nullptr, act_ref, dx, slope, gain, workspace, (hipStream_t)stream);
+  }
   if (conv_c32_ok(d))   // stride-1 pad-1 3x3: the same weight-stationary kernel with the filter mirrored (conv_c32.h)
     return launch_conv_c32<MODE_DGRAD>(d, gy, wp, dx, nullptr, nullptr, act_ref, slope, gain, (hipStream_t)stream);
   // every input pixel must be covered by at least one tap of its parity class, otherwise the class
@@ -1720,6 +1809,29 @@ extern "C" int contrad_conv2d_dgrad(const contrad_conv_desc* d, const float* gy,
   return contrad_conv2d_dgrad_ws(d, gy, wp, dx, act_ref, slope, gain, nullptr, 0, stream);   // never splits K
 }
 
+extern "C" int contrad_conv2d_wino_ok(const contrad_conv_desc* d, int mode) {
+  if (check_desc(d)) return -22;
+  return wino_ok(d, mode) ? 1 : 0;
+}
+
+extern "C" long long contrad_conv2d_wino_workspace_bytes(const contrad_conv_desc* d) {
+  if (check_desc(d)) return -22;
+  return wino_workspace_bytes(d);
+}
+
+extern "C" int contrad_conv2d_wino(const contrad_conv_desc* d, int mode, const float* in, const float* wp,
+                                   const float* bias, const float* ref, float* out, float slope, float gain,
+                                   float* workspace, long long workspace_bytes, contrad_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  CONTRAD_ARG(in && wp && out && workspace && (mode == MODE_FWD || mode == MODE_DGRAD));
+  CONTRAD_ARG(wino_ok(d, mode) && workspace_bytes >= wino_workspace_bytes(d));
+  CONTRAD_ARG(aligned16(in, wp, workspace));
+  if (mode == MODE_FWD) return launch_wino<MODE_FWD>(d, in, wp, bias, ref, out, slope, gain, workspace, (hipStream_t)stream);
+  CONTRAD_ARG(bias == nullptr);
+  return launch_wino<MODE_DGRAD>(d, in, wp, nullptr, ref, out, slope, gain, workspace, (hipStream_t)stream);
+}
+
 extern "C" int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm, int* bn) {
   int rc = check_desc(d);
   if (rc) return rc;
@@ -1740,6 +1852,7 @@ extern "C" int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm
 extern "C" int contrad_conv2d_path(const contrad_conv_desc* d, int mode) {
   if (check_desc(d) || mode < 0 || mode > 2) return -22;
   if (mode == MODE_FWD && fwd_k1_ok(d)) return 5;
+  if (mode != MODE_WGRAD && wino_planned(d, mode)) return 7;
   if (mode != MODE_WGRAD && conv_c32_ok(d)) return 6;
   if (!vec_ok(d, mode)) return 0;
   if (mode == MODE_WGRAD && wgrad_c32_ok(d)) return 4;
@@ -1762,12 +1875,14 @@ extern "C" int contrad_conv2d_path(const contrad_conv_desc* d, int mode) {
 
 extern "C" double contrad_conv2d_executed_fraction(const contrad_conv_desc* d, int mode) {
   if (check_desc(d) || mode < 0 || mode > 2) return -22.0;
+  if (contrad_conv2d_path(d, mode) == 7) return 4.0 / 9.0;   // 16 transform-domain multiply-adds per 2x2 tile instead of 36
   if (contrad_conv2d_path(d, mode) != 3) return 1.0;
   return mode == MODE_DGRAD ? dgrad_valid_tap_fraction(d) : fwd_valid_tap_fraction(d);
 }
 
 extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int mode, int with_workspace) {
   if (check_desc(d) || mode < 0 || mode > 2) return -22;
+  if (mode != MODE_WGRAD && with_workspace && wino_planned(d, mode)) return wino_grid(wino_args(d, mode));   // (512 threads each)
   if (mode == MODE_FWD) {
     const FwdPlan p = fwd_plan(d);
     const long long M = (long long)d->N * d->Ho * d->Wo;

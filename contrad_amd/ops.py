@@ -86,6 +86,8 @@ def conv_kernel_name(mode, d):
         return 'fwd_k1_kernel'
     if path == 6:
         return 'conv_c32_kernel<%d>' % mode
+    if path == 7:
+        return 'wino_kernel<%d>' % mode
     if path in (2, 3):
         return 'igemm_lean_kernel<%d, %d, %d>' % (mode, bm.value, bn.value)
     return 'igemm_kernel<%d, %d, %d, %s>' % (mode, bm.value, bn.value, 'true' if path == 1 else 'false')
@@ -175,6 +177,28 @@ def conv2d_dgrad(gy, wp, x_shape, KH, KW, stride, pad, act_ref=None, slope=1.0, 
     ws = _workspace(nbytes, gy.device) if nbytes > 0 else None
     _conv_call(1, d, 'contrad_conv2d_dgrad_ws', ctypes.byref(d), _p(gy), _p(wp), _p(out), _p(act_ref),
                float(slope), float(gain), _p(ws), nbytes, _stream())
+    return out
+
+
+def conv2d_wino(mode, inp, wp, C, K, bias=None, ref=None, slope=1.0, gain=1.0, out=None):
+    """Winograd F(2x2, 3x3) on ANY shape ``contrad_conv2d_wino_ok`` accepts (conv2d_fwd / conv2d_dgrad pick it by themselves
+    for launches that fill the chip).  mode 0: inp = x (N,H,W,C) -> y (N,H,W,K); mode 1: inp = gy (N,H,W,K) -> dx (N,H,W,C)."""
+    _chk(inp, 'inp'); _chk(wp, 'wp'); _chk(bias, 'bias'); _chk(ref, 'ref')
+    N, H, W, _ = inp.shape
+    co = K if mode == 0 else C
+    if out is None:
+        out = torch.empty((N, H, W, co), device=inp.device, dtype=torch.float32)
+    _chk(out, 'out')
+    if ref is not None and (tuple(ref.shape) != tuple(out.shape) or _ld(ref) != _ld(out)):
+        raise RuntimeError('contrad_hip: ref must match the output in shape and leading dimension')
+    d = make_desc(N, H, W, C, K, 3, 3, 1, 1, _ld(inp) if mode == 0 else _ld(out), _ld(out) if mode == 0 else _ld(inp),
+                  wp.stride(0))
+    if lib().raw('contrad_conv2d_wino_ok')(ctypes.byref(d), mode) != 1:
+        raise RuntimeError('contrad_hip: shape not supported by the Winograd kernel')
+    nbytes = lib().raw('contrad_conv2d_wino_workspace_bytes')(ctypes.byref(d))
+    ws = _workspace(nbytes, inp.device)
+    lib().call('contrad_conv2d_wino', ctypes.byref(d), mode, _p(inp), _p(wp), _p(bias), _p(ref), _p(out),
+               float(slope), float(gain), _p(ws), ctypes.c_longlong(nbytes), _stream())
     return out
 
 

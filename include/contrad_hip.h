@@ -76,6 +76,21 @@ int contrad_conv2d_dgrad_ws(const contrad_conv_desc* d, const float* gy, const f
                             const float* act_ref, float slope, float gain, float* workspace,
                             long long workspace_bytes, contrad_stream_t stream);
 
+/* Winograd F(2x2, 3x3) in exact fp32 (csrc/wino.h) for 3x3 stride-1 pad-1 layers on power-of-two maps >= 4x4 whose input
+ * channels are a multiple of 16 and output channels a multiple of 64: 2.25x fewer multiply-adds than the direct kernels,
+ * fp32 round-off class results (rel-L2 3 - 6e-7 against fp64; F.conv2d of the reference reaches cuDNN's Winograd-class
+ * kernels the same way: models/gan/sndcgan.py:91-109, models/gan/stylegan2/layers.py:115-121).  contrad_conv2d_fwd_add /
+ * contrad_conv2d_dgrad_ws choose it by themselves for launches of about one item (64 tiles x 64 output channels) per CU or
+ * more -- their *_workspace_bytes then cover the transformed filter (16 * C * K floats, rewritten by every call) --;
+ * contrad_conv2d_wino runs it on ANY shape contrad_conv2d_wino_ok accepts (parity tests, integrators with their own plan).
+ * mode 0: in = x, out = y = gain * lrelu(conv + bias) [+ ref], bias / ref may be NULL;
+ * mode 1: in = gy, out = dx [* act'(ref)], bias must be NULL (semantics of contrad_conv2d_fwd_add / _dgrad_ws). */
+int contrad_conv2d_wino_ok(const contrad_conv_desc* d, int mode);
+long long contrad_conv2d_wino_workspace_bytes(const contrad_conv_desc* d);
+int contrad_conv2d_wino(const contrad_conv_desc* d, int mode, const float* in, const float* wp, const float* bias,
+                        const float* ref, float* out, float slope, float gain, float* workspace,
+                        long long workspace_bytes, contrad_stream_t stream);
+
 /* dwp[(kh,kw,c),k] = sum_{n,ho,wo} x[n,ho*s-p+kh,wo*s-p+kw,c] * gy[n,ho,wo,k]      (split over the
  * n*ho*wo axis into deterministic partial slabs in `workspace`, then reduced in fixed order).
  * dbias (may be NULL; needs C, K, ldx, ldy multiples of 4): dbias[k] = sum_{n,ho,wo} gy[n,ho,wo,k], the bias
@@ -90,11 +105,13 @@ int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm, int* bn);
  * a rectangle of pixels that share their non-padding taps), 4 = the accumulator-stationary weight-gradient kernel of
  * the 32 -> 32 channel 3x3 layers (wgrad_c32_kernel, mode 2 only), 5 = the single-output 1x1 layer (fwd_k1_kernel, mode 0
  * only: the 512 -> 1 logit of the heads), 6 = the weight-stationary kernel of the 32 -> 32 channel 3x3 stride-1 layers
- * (conv_c32_kernel<mode>, modes 0 and 1); negative = bad descriptor.  Profiling aid. */
+ * (conv_c32_kernel<mode>, modes 0 and 1), 7 = Winograd F(2x2, 3x3) (wino_kernel<mode>, modes 0 and 1; with a workspace);
+ * negative = bad descriptor.  Profiling aid. */
 int contrad_conv2d_path(const contrad_conv_desc* d, int mode);
 /* Share of the layer's nominal multiply-adds (2*N*Ho*Wo*K*C*KH*KW, the count every roofline here is quoted on, padding
  * taps included as in the reference's dense layer) that the kernel actually issues: 1 except on pixel-major tiles (path
- * 3), which skip the tap-positions that read padding (0.69 for a 3x3 pad-1 layer on a 4x4 map).  (A weight-gradient tile
+ * 3), which skip the tap-positions that read padding (0.69 for a 3x3 pad-1 layer on a 4x4 map), and on the Winograd path
+ * (7): 4/9, the transform-domain multiply-adds.  (A weight-gradient tile
  * that also sums the bias gradient visits everything: not reflected.)  Profiling aid. */
 double contrad_conv2d_executed_fraction(const contrad_conv_desc* d, int mode);
 /* Workgroups (256 threads each) of the main igemm launch this geometry gets for `mode` (with_workspace != 0: the plan the

@@ -65,16 +65,28 @@ def test_launch_plans_are_host_logic(built):
             # the 4x4 stride-2 layer onto the 8 x 8 dx map (0.77 of its tap-positions valid: pixel-major inside the parity
             # classes, slot-balanced class-major order, round 4) -- the larger maps stay image-major; the weight gradient
             # where at most 0.85 of the tap-positions are valid
+            # Round 6: forward and data gradient of the 3x3 stride-1 layers run on the Winograd kernel (path 7, csrc/wino.h; one
+            # persistent 512-thread block per CU; the workspace holds the transformed filter)
             Ho = (H + 2 * p - k) // s + 1
             if mode == 2:
                 want = 3 if (Ho == 4 or (Ho == 8 and k == 3)) else 2
+            elif k == 3:
+                want = 7
             else:
                 want = 3 if (mode == 0 or s == 1 or H == 8) else 2
             assert path(ctypes.byref(d), mode) == want, (H, C, K, mode)
+            if want == 7:
+                assert built.raw('contrad_conv2d_grid_blocks')(ctypes.byref(d), mode, 1) == 256
+                assert abs(built.raw('contrad_conv2d_executed_fraction')(ctypes.byref(d), mode) - 4.0 / 9.0) < 1e-12
+                assert built.raw('contrad_conv2d_wino_ok')(ctypes.byref(d), mode) == 1
+                continue
             assert tile(ctypes.byref(d), mode, ctypes.byref(bm), ctypes.byref(bn)) == 0
             want_bn = 64 if (mode == 1 and C == 64) else 128        # dgrad's columns are the input channels
             assert (bm.value, bn.value) == (128, want_bn), (H, C, K, mode, bm.value, bn.value)
-        assert built.raw('contrad_conv2d_fwd_workspace_bytes')(ctypes.byref(d)) == 0
+        want_ws = 16 * C * K * 4 if k == 3 else 0
+        assert built.raw('contrad_conv2d_fwd_workspace_bytes')(ctypes.byref(d)) == want_ws
+        assert built.raw('contrad_conv2d_dgrad_workspace_bytes')(ctypes.byref(d)) == want_ws
+        assert built.raw('contrad_conv2d_wino_workspace_bytes')(ctypes.byref(d)) == 16 * C * K * 4
     # Cin = 3 / Cout = 1 / 513 channels: general kernel, scalar or float4 gathers
     assert path(ctypes.byref(_desc(8, 32, 3, 64, 3, 1, 1)), 0) == 0
     d1 = _desc(8, 1, 512, 1, 1, 1, 0)                      # the 512 -> 1 logit: its own one-wave-per-row kernel forward,
@@ -93,7 +105,16 @@ def test_launch_plans_are_host_logic(built):
     d = _desc(192, 4, 512, 512, 3, 1, 1)
     nbytes = built.raw('contrad_conv2d_dgrad_workspace_bytes')(ctypes.byref(d))
     assert nbytes > 0 and nbytes % (192 * 16 * 512 * 4) == 0 and 2 <= nbytes // (192 * 16 * 512 * 4) <= 16
-    assert built.raw('contrad_conv2d_dgrad_workspace_bytes')(ctypes.byref(_desc(1536, 4, 512, 512, 3, 1, 1))) == 0
+    assert built.raw('contrad_conv2d_dgrad_workspace_bytes')(ctypes.byref(_desc(1536, 4, 516, 512, 3, 1, 1))) == 0   # (not Winograd: Cin)
+    # Winograd is planned only for launches of about an item (64 tiles x 64 output channels) per CU or more with a last round that
+    # is not mostly empty; it needs input channels % 16, output channels % 64 and power-of-two maps
+    wok = built.raw('contrad_conv2d_wino_ok')
+    assert path(ctypes.byref(_desc(192, 4, 512, 512, 3, 1, 1)), 0) != 7 and wok(ctypes.byref(_desc(192, 4, 512, 512, 3, 1, 1)), 0) == 1
+    assert path(ctypes.byref(_desc(192, 16, 128, 128, 3, 1, 1)), 0) == 7        # 384 items: two rounds, the second half full
+    assert path(ctypes.byref(_desc(160, 16, 128, 128, 3, 1, 1)), 0) != 7        # 320 items: the second round a quarter full
+    assert wok(ctypes.byref(_desc(8, 16, 24, 64, 3, 1, 1)), 0) == 0 and wok(ctypes.byref(_desc(8, 16, 32, 48, 3, 1, 1)), 0) == 0
+    assert wok(ctypes.byref(_desc(8, 16, 32, 48, 3, 1, 1)), 1) == 0 and wok(ctypes.byref(_desc(8, 16, 64, 48, 3, 1, 1)), 1) == 1
+    assert wok(ctypes.byref(_desc(8, 12, 32, 64, 3, 1, 1)), 0) == 0 and wok(ctypes.byref(_desc(8, 16, 32, 64, 3, 2, 1)), 0) == 0
     assert built.raw('contrad_conv2d_dgrad_workspace_bytes')(ctypes.byref(_desc(192, 8, 256, 512, 4, 2, 1))) == 0   # strided
     # contrastive column splits: ~256 blocks
     assert built.raw('contrad_contrast_workspace_bytes')(1024, 128) == 16 * 1024 * 128 * 4
@@ -120,7 +141,10 @@ def test_padding_skipping_tile_plans_without_gpu(built):
     bm, bn = ctypes.c_int(0), ctypes.c_int(0)
     N = 1536
     seen = set()
-    for (H, C, K, k, s, p) in _SNDCGAN:
+    # (the 3x3 stride-1 layers with channel counts the Winograd kernel does not take -- it needs output channels % 64 --: the
+    # direct kernels and their padding-skipping tiles serve them as they served 128 / 256 / 512 channels until round 5)
+    nowino = [(H, C - 32, K - 32, k, s, p) if k == 3 else (H, C, K, k, s, p) for (H, C, K, k, s, p) in _SNDCGAN]
+    for (H, C, K, k, s, p) in nowino:
         d = _desc(N, H, C, K, k, s, p)
         Ho = (H + 2 * p - k) // s + 1
         for mode in (0, 1):
@@ -153,7 +177,7 @@ def test_padding_skipping_tile_plans_without_gpu(built):
             assert blocks(ctypes.byref(d), mode, 1) == want, (H, k, mode, want)
     assert seen == {'pixel-major', 'border classes', 'strided pixel-major'}
     # too few images for a tile of the smallest class on every XCD: image-major tiles, everything issued
-    d = _desc(192, 8, 256, 256, 3, 1, 1)
+    d = _desc(192, 8, 256, 256, 3, 1, 1)        # (192 Winograd items: below the plan's threshold too)
     assert path(ctypes.byref(d), 0) == 2 and frac(ctypes.byref(d), 0) == 1.0
     assert path(ctypes.byref(d), 2) == 3 and abs(frac(ctypes.byref(d), 2) - 484.0 / 576.0) < 1e-12   # (WGRAD: pixel-major positions)
 

@@ -1,0 +1,140 @@
+"""GPU parity: Winograd F(2x2, 3x3) kernel (csrc/wino.h) through the C ABI vs PyTorch-CPU fp32 F.conv2d -- the reference's
+own arithmetic for these layers (models/gan/sndcgan.py:91-109, models/gan/stylegan2/layers.py:115-121).
+
+``contrad_conv2d_wino`` forces the kernel on every shape it supports (the automatic plan of conv2d_fwd / conv2d_dgrad only
+takes it for launches that fill the chip: checked at the BASELINE shapes below).  Tolerance 1e-3 relative to the tensor's max
+magnitude (north_star); observed 2e-7 ... 2e-6."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from contrad_amd import ops
+from contrad_amd._lib import lib
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+TIGHT = 2e-5        # what the kernel actually delivers (fp32 round-off class): a regression guard far below the contract
+
+# (N, H, W, C, K)
+CASES = [
+    (3, 16, 16, 32, 64),      # one 16 x 16 patch per image: the box is the image, the halo reads the zero pixel
+    (2, 32, 32, 16, 128),     # 2 x 2 patches per image: boxes with halo, borders load as zeros; two cout blocks
+    (5, 8, 8, 64, 64),        # 4 images per block, ragged last block
+    (18, 4, 4, 32, 64),       # 16 images per block, ragged
+    (2, 64, 32, 16, 64),      # non-square: 4 x 2 patches
+    (1, 4, 8, 16, 64),        # 8 images per block, one present
+    (3, 16, 32, 48, 192),     # one patch high, two wide (box 16 x 18); Cin = 48 (6 chunks), three cout blocks
+    (40, 16, 16, 16, 64),     # several items per block of the persistent grid (one chunk pair each)
+    (9, 8, 16, 128, 64),      # 2 images per block (4 x 8 tiles each)
+]
+
+
+def rel(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def _inputs(N, H, W, C, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, H, W, C, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.1
+    b = torch.randn(K, generator=g)
+    return x, w, b
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_wino_forward(case):
+    N, H, W, C, K = case
+    x, w, b = _inputs(N, H, W, C, K, 1)
+    add = torch.randn(N, H, W, K, generator=torch.Generator().manual_seed(2))
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1).permute(0, 2, 3, 1)
+    ref_act = F.leaky_relu(ref, 0.2) * 1.3
+    dev = torch.device('cuda')
+    wp = ops.pack_weight(w).to(dev)
+    y = ops.conv2d_wino(0, x.to(dev), wp, C, K, bias=b.to(dev), slope=0.2, gain=1.3)
+    assert rel(y.cpu(), ref_act) < TIGHT
+    y = ops.conv2d_wino(0, x.to(dev), wp, C, K, bias=None, ref=add.to(dev), slope=1.0, gain=1.0)
+    assert rel(y.cpu(), F.conv2d(x.permute(0, 3, 1, 2), w, None, padding=1).permute(0, 2, 3, 1) + add) < TIGHT
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_wino_data_gradient(case):
+    N, H, W, K, C = case          # (roles swapped: gy has K channels, dx has C; the kernel needs K % 16 == 0, C % 64 == 0)
+    g = torch.Generator().manual_seed(3)
+    gy = torch.randn(N, H, W, K, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.1
+    act = torch.randn(N, H, W, C, generator=g)
+    ref = F.conv_transpose2d(gy.permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1)
+    dev = torch.device('cuda')
+    wp = ops.pack_weight(w).to(dev)
+    dx = ops.conv2d_wino(1, gy.to(dev), wp, C, K)
+    assert rel(dx.cpu(), ref) < TIGHT
+    dx = ops.conv2d_wino(1, gy.to(dev), wp, C, K, ref=act.to(dev), slope=0.2, gain=1.5)
+    assert rel(dx.cpu(), ref * torch.where(act > 0, 1.5, 0.3)) < TIGHT
+
+
+def test_wino_channel_sliced_views():
+    """Input and output are channel slices of wider buffers (leading dimension != channels), as the engine's callers pass them."""
+    N, H, W, C, K = 3, 16, 16, 32, 64
+    x, w, b = _inputs(N, H, W, C, K, 5)
+    dev = torch.device('cuda')
+    xb = torch.full((N, H, W, C + 8), 7.0, device=dev)
+    xb[..., 4:4 + C] = x.to(dev)
+    yb = torch.full((N, H, W, K + 12), -3.0, device=dev)
+    ops.conv2d_wino(0, xb[..., 4:4 + C], ops.pack_weight(w).to(dev), C, K, bias=b.to(dev), slope=0.1, gain=1.0, out=yb[..., 8:8 + K])
+    ref = F.leaky_relu(F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1), 0.1).permute(0, 2, 3, 1)
+    assert rel(yb[..., 8:8 + K].cpu(), ref) < TIGHT
+    assert (yb[..., :8] == -3.0).all() and (yb[..., 8 + K:] == -3.0).all()      # nothing outside the slice is written
+
+
+def test_wino_is_deterministic_and_batch_independent():
+    N, H, W, C, K = 24, 8, 8, 32, 64
+    x, w, b = _inputs(N, H, W, C, K, 7)
+    dev = torch.device('cuda')
+    wp = ops.pack_weight(w).to(dev)
+    y1 = ops.conv2d_wino(0, x.to(dev), wp, C, K, bias=b.to(dev))
+    y2 = ops.conv2d_wino(0, x.to(dev), wp, C, K, bias=b.to(dev))
+    assert torch.equal(y1, y2)
+    y3 = ops.conv2d_wino(0, x[5:9].contiguous().to(dev), wp, C, K, bias=b.to(dev))
+    assert torch.equal(y1[5:9], y3)          # an image's result does not depend on its block or its neighbours
+
+
+def test_wino_rejects_what_it_cannot_run():
+    dev = torch.device('cuda')
+    for (N, H, W, C, K) in [(2, 16, 16, 24, 64), (2, 16, 16, 32, 48), (2, 12, 16, 32, 64), (2, 2, 2, 32, 64)]:
+        x = torch.zeros(N, H, W, C, device=dev)
+        wp = torch.zeros(9 * C, ops.round_up(K, 4), device=dev)
+        with pytest.raises(RuntimeError):
+            ops.conv2d_wino(0, x, wp, C, K)
+
+
+# the 3x3 stride-1 layers of the BASELINE workloads: (N, H, C) -- SNDCGAN at 3N = 1536, StyleGAN2_512 at 3N = 48
+PLANNED = [(1536, 16, 128), (1536, 8, 256), (48, 128, 128), (48, 64, 256), (48, 32, 512), (48, 256, 64)]
+
+
+@pytest.mark.parametrize('shape', PLANNED)
+def test_the_plan_takes_winograd_at_the_baseline_shapes_and_matches_torch(shape):
+    """conv2d_fwd / conv2d_dgrad (the calls the models make) at full size: the path query says Winograd, and the first and
+    last images match PyTorch-CPU."""
+    N, H, C = shape
+    K = C
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, H, H, C, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.05
+    b = torch.randn(K, generator=g)
+    wp = ops.pack_weight(w).to(dev)
+    d = ops.make_desc(N, H, H, C, K, 3, 3, 1, 1, C, K, wp.stride(0))
+    assert lib().raw('contrad_conv2d_path')(ctypes.byref(d), 0) == 7
+    assert lib().raw('contrad_conv2d_path')(ctypes.byref(d), 1) == 7
+    assert abs(lib().raw('contrad_conv2d_executed_fraction')(ctypes.byref(d), 0) - 4.0 / 9.0) < 1e-12
+    xd = x.to(dev)
+    y = ops.conv2d_fwd(xd, wp, b.to(dev), K, 3, 3, 1, 1, slope=0.1, gain=1.0)
+    sel = [0, 1, N - 2, N - 1] if H <= 64 else [0, N - 1]
+    xs = x[sel]
+    ref = F.leaky_relu(F.conv2d(xs.permute(0, 3, 1, 2), w, b, padding=1), 0.1).permute(0, 2, 3, 1)
+    assert rel(y[sel].cpu(), ref) < TIGHT
+    dx = ops.conv2d_dgrad(y, wp, (N, H, H, C), 3, 3, 1, 1, act_ref=xd, slope=0.1, gain=1.0)
+    refd = F.conv_transpose2d(y[sel].cpu().permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1) * torch.where(xs > 0, 1.0, 0.1)
+    assert rel(dx[sel].cpu(), refd) < TIGHT
