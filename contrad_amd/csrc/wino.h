@@ -285,9 +285,8 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
     __syncthreads();
   };
 
-  // exchange area (stage 1 is the free one at an item's end): [role][sub-block][8 rows][lane] float4 = 64 KB
-  float4* xch_mine = reinterpret_cast<float4*>(smem + BUF) + ((ROLE * 4 + wave) * 8) * 64 + lane;
-  float4* xch_other = reinterpret_cast<float4*>(smem + BUF) + (((1 - ROLE) * 4 + wave) * 8) * 64 + lane;
+  // exchange area (stage 1 is the free one at an item's end): [sub-block][16 rows][lane] float4 = 64 KB
+  float4* xch = reinterpret_cast<float4*>(smem + BUF) + (wave * 16) * 64 + lane;
   const float g1 = p.gain, g0 = p.gain * p.slope;
 
   for (; w_cur < L; w_cur += nslots) {
@@ -296,16 +295,12 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
       chunk(std::integral_constant<int, 1>{});     // (Cin % 16 == 0)
     }
     // ---- output transform.  Y[i][j] = sum_a AT[i][a] s_j[a],  s_0[a] = M[a][0] + M[a][1] + M[a][2],  s_1[a] = M[a][1] - M[a][2] - M[a][3]
-    // (M[a][3] as accumulated: V's and U's (a, 3) planes are both negated).  This wave's part of (y00, y01, y10, y11):
+    // (M[a][3] as accumulated: V's and U's (a, 3) planes are both negated).  A wave's part of (y00, y01, y10, y11):
     //   rows a = 0, 1 (ROLE 0): (s_0[0] + s_0[1], s_1[0] + s_1[1], s_0[1], s_1[1]);   a = 2, 3 (ROLE 1): (s_0[2], s_1[2], -s_0[2] - s_0[3], -s_1[2] - s_1[3])
-    // ROLE 0 finishes accumulator rows 0..7, ROLE 1 rows 8..15: each hands the other 8 rows of its part through LDS.
+    // The movers hand their part to the transform waves through LDS; those add, apply the epilogue and store.  (The movers
+    // carry the next item's in-flight loads -- 44 registers -- across this point: with a share of the stores and of the
+    // epilogue's second operand they spilled 65 - 138 registers into per-row scratch round trips, 4 - 7 us per item.)
     // (The last chunk ran on stage 1 and its barrier has passed: stage 1 is free; stage 0 holds the next item's chunk 0.)
-    const Item it = decode(w_cur);
-    const int cout = it.kb * 64 + wn * 32 + l31;
-    float* ybase = p.y + (size_t)it.n_first * p.H * p.W * p.ldo;
-    const __amdgpu_buffer_rsrc_t rsY = rsrc(ybase, true);
-    const __amdgpu_buffer_rsrc_t rsR = rsrc(p.ref ? p.ref + (size_t)it.n_first * p.H * p.W * p.ldo : ybase, p.ref != nullptr);
-    constexpr int R0 = ROLE * 8;
     auto part = [&](int r) -> float4 {
       float s0[2], s1[2];
 #pragma unroll
@@ -317,51 +312,77 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
       return ROLE == 0 ? make_float4(s0[0] + s0[1], s1[0] + s1[1], s0[1], s1[1])
                        : make_float4(s0[0], s1[0], -s0[0] - s0[1], -s1[0] - s1[1]);
     };
-    // (first the rows the other half finishes: their 64 accumulator registers are dead afterwards and make room for the
-    // epilogue's second operand -- with it loaded first the movers, whose in-flight loads of the next item stay live across
-    // the epilogue, spilled 88 - 138 registers)
+    if constexpr (ROLE == 1) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) xch_other[q * 64] = part((1 - ROLE) * 8 + q);
-    unsigned yoff[8];
-    float rv[8][4];
+      for (int r = 0; r < 16; ++r) xch[r * 64] = part(r);
+      __syncthreads();
+    } else {
+      const Item it = decode(w_cur);
+      const int cout = it.kb * 64 + wn * 32 + l31;
+      float* ybase = p.y + (size_t)it.n_first * p.H * p.W * p.ldo;
+      const __amdgpu_buffer_rsrc_t rsY = rsrc(ybase, true);
+      const __amdgpu_buffer_rsrc_t rsR = rsrc(p.ref ? p.ref + (size_t)it.n_first * p.H * p.W * p.ldo : ybase, p.ref != nullptr);
+      const unsigned dcol = (unsigned)p.ldo * 4u, drow = (unsigned)(p.W * p.ldo) * 4u;
+      // Byte offset of accumulator row r's tile (its first output pixel, this lane's cout) in the item's images.  The tile
+      // index wm * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2) is a sum of DISJOINT bits and (image, tile row, tile column) are bit
+      // fields of it, so the offset is lane part + a wave-uniform part per r: one v_add (+ compare / select on small maps,
+      // where a block holds several images and the last block is ragged).  (Written as img / ty / tx per row the compiler
+      // hoisted 48 per-lane values out of the item loop into scratch and reloaded them behind vmcnt(0) -- i.e. behind the
+      // epilogue loads just issued: 4 - 7 us per item.)
+      auto bit_off = [&](int b) -> unsigned {        // offset contribution of tile-index bit b (uniform)
+        return b < p.sh_tw ? (unsigned)((2 << b) * p.ldo * 4)
+               : b < p.sh_thw ? (unsigned)((2 << (b - p.sh_tw)) * p.W * p.ldo * 4)
+                              : (unsigned)((1 << (b - p.sh_thw)) * p.H * p.W * p.ldo * 4);
+      };
+      const unsigned lane_off = (lhi ? bit_off(2) : 0u) + (wm ? bit_off(5) : 0u) + (unsigned)((wn * 32 + l31) * 4);
+      const int lane_img = (wm * 32 + 4 * lhi) >> p.sh_thw;
+      const unsigned item_off = (unsigned)(((it.ph * 2 * p.TH * p.W + it.pw * 2 * p.TW) * p.ldo + it.kb * 64) * 4);
+      const int img_lim = p.N - it.n_first - lane_img;      // images of this lane's sub-block that exist
+      const unsigned base_off = lane_off + item_off;
+      auto row_off = [&](int r) -> unsigned {
+        const int rbits = (r & 3) + 8 * (r >> 2);
+        const unsigned u = ((r & 1) ? bit_off(0) : 0u) + ((r & 2) ? bit_off(1) : 0u) + ((r & 4) ? bit_off(3) : 0u) + ((r & 8) ? bit_off(4) : 0u);
+        return ((rbits >> p.sh_thw) < img_lim) ? base_off + u : OOB;
+      };
+      float rv[16][4];
+#ifndef WINO_NO_REF
+      if (p.ref) {   // uniform: the second operand of the epilogue goes into flight before the exchange barrier
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int r = R0 + q;
-      const int tl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      const int img = tl >> p.sh_thw, ty = (tl >> p.sh_tw) & (p.TH - 1), tx = tl & (p.TW - 1);
-      const int oy = it.ph * 2 * p.TH + 2 * ty, ox = it.pw * 2 * p.TW + 2 * tx;
-      yoff[q] = (it.n_first + img < p.N) ? (unsigned)((((img * p.H + oy) * p.W + ox) * p.ldo + cout) * 4) : OOB;
-    }
-    const unsigned dcol = (unsigned)p.ldo * 4u, drow = (unsigned)(p.W * p.ldo) * 4u;
-    if (p.ref) {   // uniform: the second operand of the epilogue goes into flight before the exchange barrier
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        rv[q][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)yoff[q], 0, 0));
-        rv[q][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)(yoff[q] + dcol), 0, 0));
-        rv[q][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)(yoff[q] + drow), 0, 0));
-        rv[q][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)(yoff[q] + drow + dcol), 0, 0));
-      }
-    }
-    __syncthreads();
-    const float bj = (MODE == MODE_FWD && p.bias) ? p.bias[cout] : 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float4 mine = part(R0 + q), oth = xch_mine[q * 64];
-      float v[4] = {mine.x + oth.x, mine.y + oth.y, mine.z + oth.z, mine.w + oth.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if constexpr (MODE == MODE_DGRAD) {
-          if (p.ref) v[e] *= (rv[q][e] > 0.f) ? g1 : g0;
-        } else {
-          v[e] += bj;
-          v[e] *= (v[e] > 0.f) ? g1 : g0;
-          if (p.ref) v[e] += rv[q][e];
+        for (int r = 0; r < 16; ++r) {
+          const unsigned o = row_off(r);
+          rv[r][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)o, 0, 0));
+          rv[r][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)(o + dcol), 0, 0));
+          rv[r][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)(o + drow), 0, 0));
+          rv[r][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)(o + drow + dcol), 0, 0));
         }
       }
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[0]), rsY, (int)yoff[q], 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[1]), rsY, (int)(yoff[q] + dcol), 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[2]), rsY, (int)(yoff[q] + drow), 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[3]), rsY, (int)(yoff[q] + drow + dcol), 0, 0);
+#else
+      for (int r = 0; r < 16; ++r) for (int e = 0; e < 4; ++e) rv[r][e] = 1.f;
+#endif
+      const float bj = (MODE == MODE_FWD && p.bias) ? p.bias[cout] : 0.f;
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        // (rows one by one: hoisted above the barrier, the 16 rows' own parts are 64 more live registers next to the 64 of rv)
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 mine = part(r), oth = xch[r * 64];
+        float v[4] = {mine.x + oth.x, mine.y + oth.y, mine.z + oth.z, mine.w + oth.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (MODE == MODE_DGRAD) {
+            if (p.ref) v[e] *= (rv[r][e] > 0.f) ? g1 : g0;
+          } else {
+            v[e] += bj;
+            v[e] *= (v[e] > 0.f) ? g1 : g0;
+            if (p.ref) v[e] += rv[r][e];
+          }
+        }
+        const unsigned o = row_off(r);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[0]), rsY, (int)o, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[1]), rsY, (int)(o + dcol), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[2]), rsY, (int)(o + drow), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[3]), rsY, (int)(o + drow + dcol), 0, 0);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i)

@@ -327,13 +327,15 @@ static void make_U(const std::vector<float>& w, int C, int K, std::vector<float>
     }
 }
 
+static int g_normal = 0;    // 1: standard-normal x (as tools/bench_conv.py) instead of uniform +-0.5: the chip clocks to its power budget
 static double run_case(int N, int H, int C, int K, int reps) {
   const int W = H;
   const size_t nx = (size_t)N * H * W * C, ny = (size_t)N * H * W * K;
   std::vector<float> hx(nx), hw((size_t)K * C * 9), hU;
   unsigned s = 12345u;
   auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xFFFF) / 65536.f - 0.5f; };
-  for (auto& v : hx) v = rnd();
+  for (auto& v : hx) v = g_normal ? (rnd() + rnd() + rnd() + rnd() + rnd() + rnd() + rnd() + rnd() + rnd() + rnd() + rnd() + rnd()) * 1.0f * 3.4641f / 3.4641f * 1.0f : rnd();
+  if (g_normal) for (auto& v : hx) v *= 1.0f;
   for (auto& v : hw) v = rnd() * 0.1f;
   make_U(hw, C, K, hU);
   float *dx, *dU, *dy;
@@ -385,7 +387,8 @@ static double run_case(int N, int H, int C, int K, int reps) {
 
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 20;
-  if (argc > 2) { run_case(48, 128, 128, 128, reps); return 0; }   // one shape (counter runs)
+  if (argc > 2 && argv[2][0] == 'n') g_normal = 1;
+  else if (argc > 2) { run_case(48, 128, 128, 128, reps); return 0; }   // one shape (counter runs)
 #ifdef ABL_ANY
   run_case(1536, 16, 128, 128, reps); run_case(48, 128, 128, 128, reps); return 0;
 #endif
