@@ -878,6 +878,49 @@ int wino_grid(const wino::Args& a) {
   return 8 * std::min(WINO_CUS / 8, l0);
 }
 
+// ---- weight gradient on the Winograd kernel (wino_wgrad_kernel): C % 64, K % 64 ----
+bool wino_wgrad_ok(const contrad_conv_desc* d) {
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1) return false;
+  if (d->H < 4 || d->W < 4 || (d->H & (d->H - 1)) || (d->W & (d->W - 1))) return false;
+  if ((d->C & 63) || (d->K & 63) || (d->ldx & 3) || (d->ldy & 3)) return false;
+  const long long lim = 1ll << 31;
+  if (2ll * d->H * d->W * std::max(d->ldx, d->ldy) * 4 >= lim) return false;     // chunk-relative byte offsets (<= 2 images)
+  return true;
+}
+
+wino::WArgs wino_wgrad_args(const contrad_conv_desc* d) {
+  wino::WArgs a{};
+  a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.ldx = d->ldx; a.ldy = d->ldy;
+  a.CTW = std::min(4, d->W / 2);
+  a.CTH = std::min(8 / a.CTW, d->H / 2);
+  a.CNIMG = 8 / (a.CTH * a.CTW);
+  a.sh_ctw = __builtin_ctz(a.CTW); a.sh_cthw = __builtin_ctz(a.CTH * a.CTW);
+  a.QH = d->H / (2 * a.CTH); a.QW = d->W / (2 * a.CTW);
+  a.Q = cdiv(d->N, a.CNIMG) * a.QH * a.QW;
+  a.CB = d->C / 64; a.KB = d->K / 64;
+  const int splits = std::max(1, std::min(a.Q, WINO_CUS / (a.CB * a.KB)));
+  a.qps = cdiv(a.Q, splits);
+  a.BH = a.QH > 1 ? 2 * a.CTH + 2 : d->H; a.r_org = a.QH > 1 ? -1 : 0;
+  a.BW = a.QW > 1 ? 2 * a.CTW + 2 : d->W; a.c_org = a.QW > 1 ? -1 : 0;
+  return a;
+}
+int wino_wgrad_splits(const wino::WArgs& a) { return cdiv(a.Q, a.qps); }
+
+// planned when every block gets a contraction long enough to pay for its prologue and its 4x4 -> 3x3 epilogue
+bool wino_wgrad_planned(const contrad_conv_desc* d) {
+  static const bool enabled = []() { const char* e = contrad_dev_env("CONTRAD_WINO_WGRAD"); return !(e && e[0] == '0'); }();
+  static const bool enabled2 = []() { const char* e = contrad_dev_env("CONTRAD_WINO"); return !(e && e[0] == '0'); }();
+  if (!enabled || !enabled2 || !wino_wgrad_ok(d)) return false;
+  const wino::WArgs a = wino_wgrad_args(d);
+  const long long blocks = (long long)a.CB * a.KB * wino_wgrad_splits(a);
+  return a.qps >= 48 && blocks * 10 >= WINO_CUS * 7 && blocks <= WINO_CUS;
+}
+
+long long wino_wgrad_workspace_bytes(const contrad_conv_desc* d) {
+  const wino::WArgs a = wino_wgrad_args(d);
+  return (long long)wino_wgrad_splits(a) * (9ll * d->C + 1) * d->K * (long long)sizeof(float);
+}
+
 template <int MODE>
 int launch_wino(const contrad_conv_desc* d, const float* in, const float* wp, const float* bias, const float* ref,
                 float* out, float slope, float gain, float* U, hipStream_t stream) {
@@ -1617,6 +1660,28 @@ __global__ void dgrad_reduce_kernel(const float* __restrict__ ws, int splits, lo
   }
 }
 
+int launch_wino_wgrad(const contrad_conv_desc* d, const float* x, const float* gy, float* dwp, float* dbias,
+                      float* workspace, hipStream_t stream) {
+  static const hipError_t attr = hipFuncSetAttribute((const void*)wino::wino_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     wino::W_LDS_DWORDS * 4);
+  if (attr != hipSuccess) return (int)attr;
+  wino::WArgs a = wino_wgrad_args(d);
+  const int splits = wino_wgrad_splits(a);
+  const long long total = 9ll * d->C * d->K;
+  a.x = x; a.gy = gy; a.ws = workspace;
+  a.bias_ws = dbias ? workspace + (size_t)splits * total : nullptr;
+  hipLaunchKernelGGL(wino::wino_wgrad_kernel, dim3(a.CB * a.KB * splits), dim3(512), wino::W_LDS_DWORDS * 4, stream, a);
+  CONTRAD_CHECK_LAUNCH();
+  int R = 1;
+  while (R < 64 && R * 2 <= splits && (total / 4) * R < 65536) R <<= 1;
+  long long rb = ((total / 4) * R + 255) / 256;
+  if (rb > 2048) rb = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)rb), dim3(256), 0, stream, workspace, dwp, 9 * d->C, d->K, d->ldw, splits,
+                     a.bias_ws, dbias, R);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int contrad_abi_version(void) { return 2; }
@@ -1811,12 +1876,24 @@ extern "C" int contrad_conv2d_dgrad(const contrad_conv_desc* d, const float* gy,
 
 extern "C" int contrad_conv2d_wino_ok(const contrad_conv_desc* d, int mode) {
   if (check_desc(d)) return -22;
+  if (mode == MODE_WGRAD) return wino_wgrad_ok(d) ? 1 : 0;
   return wino_ok(d, mode) ? 1 : 0;
 }
 
-extern "C" long long contrad_conv2d_wino_workspace_bytes(const contrad_conv_desc* d) {
-  if (check_desc(d)) return -22;
+extern "C" long long contrad_conv2d_wino_workspace_bytes(const contrad_conv_desc* d, int mode) {
+  if (check_desc(d) || mode < 0 || mode > 2) return -22;
+  if (mode == MODE_WGRAD) return wino_wgrad_ok(d) ? wino_wgrad_workspace_bytes(d) : -22;
   return wino_workspace_bytes(d);
+}
+
+extern "C" int contrad_conv2d_wino_wgrad(const contrad_conv_desc* d, const float* x, const float* gy, float* dwp,
+                                         float* dbias, float* workspace, long long workspace_bytes,
+                                         contrad_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  CONTRAD_ARG(x && gy && dwp && workspace && wino_wgrad_ok(d));
+  CONTRAD_ARG(aligned16(x, gy, workspace) && workspace_bytes >= wino_wgrad_workspace_bytes(d));
+  return launch_wino_wgrad(d, x, gy, dwp, dbias, workspace, (hipStream_t)stream);
 }
 
 extern "C" int contrad_conv2d_wino(const contrad_conv_desc* d, int mode, const float* in, const float* wp,
@@ -1853,6 +1930,7 @@ extern "C" int contrad_conv2d_path(const contrad_conv_desc* d, int mode) {
   if (check_desc(d) || mode < 0 || mode > 2) return -22;
   if (mode == MODE_FWD && fwd_k1_ok(d)) return 5;
   if (mode != MODE_WGRAD && wino_planned(d, mode)) return 7;
+  if (mode == MODE_WGRAD && wino_wgrad_planned(d)) return 7;
   if (mode != MODE_WGRAD && conv_c32_ok(d)) return 6;
   if (!vec_ok(d, mode)) return 0;
   if (mode == MODE_WGRAD && wgrad_c32_ok(d)) return 4;
@@ -1911,6 +1989,7 @@ extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int 
     const int tm_pad = cgroup > 0 ? cdiv(tiles_m, cgroup) * cgroup : tiles_m;
     return (long long)tm_pad * tiles_n * s * s;
   }
+  if (wino_wgrad_planned(d)) { const wino::WArgs a = wino_wgrad_args(d); return (long long)a.CB * a.KB * wino_wgrad_splits(a); }
   if (wgrad_c32_ok(d)) return wgrad_c32_blocks(d);
   int bm, bn, tm, tn, splits, pps;
   wgrad_plan(d, &bm, &bn, &tm, &tn, &splits, &pps);
@@ -1961,6 +2040,7 @@ extern "C" int contrad_conv2d_tile_order(const contrad_conv_desc* d, int mode, u
 
 extern "C" long long contrad_conv2d_wgrad_workspace_bytes(const contrad_conv_desc* d) {
   if (check_desc(d)) return -22;
+  if (wino_wgrad_planned(d)) return wino_wgrad_workspace_bytes(d);
   if (wgrad_c32_ok(d))
     return (long long)wgrad_c32_blocks(d) * ((long long)d->KH * d->KW * d->C + 1) * d->K * (long long)sizeof(float);
   int bm, bn, tm, tn, splits, pps;
@@ -1976,6 +2056,7 @@ extern "C" int contrad_conv2d_wgrad(const contrad_conv_desc* d, const float* x, 
   CONTRAD_ARG(x && gy && dwp && workspace);
   if (vec_ok(d, MODE_WGRAD)) CONTRAD_ARG(aligned16(x, gy, workspace));
   CONTRAD_ARG(workspace_bytes >= contrad_conv2d_wgrad_workspace_bytes(d));
+  if (wino_wgrad_planned(d)) return launch_wino_wgrad(d, x, gy, dwp, dbias, workspace, (hipStream_t)stream);   // wino.h, F(3x3, 2x2)
   if (wgrad_c32_ok(d)) {   // (C = K = 32: vec_ok holds, so the operands were checked for 16-byte alignment above)
     // accumulator-stationary kernel for the 32 -> 32 channel 3x3 layers (wgrad_c32.h): one partial per block, summed
     // by the same fixed-order reduce as the split-K slabs

@@ -448,4 +448,341 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
   }
 }
 
+
+// =====================================================================================================================
+// Weight gradient of the same layers: F(3x3, 2x2) -- the 3x3 filter gradient of one 2x2 tile of gy against its 4x4 input
+// patch costs 16 multiply-adds per channel pair instead of 36:
+//
+//   dW = A'^T [ sum_tiles (G'' gy_t G''^T) (.) (B^T d_t B) ] A'      16 GEMMs  S_xi[c][k] = sum_t V_xi[t][c] Gy_xi[t][k]
+//
+// with the SAME input transform B^T d B as the forward kernel (so V keeps the negated (a, 3) planes: A' below carries the
+// sign), G'' = [[1,0],[1,1],[1,-1],[0,1]] and A'^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,-1]] (tools/micro: derived numerically,
+// exact).  Reference: the weight gradient of F.conv2d (models/gan/sndcgan.py:91-109, stylegan2/layers.py:115-121).
+//
+// Block (512 threads, one per CU) = 64 input channels x 64 output channels x all 16 xi x ONE SPLIT of the tile axis; the
+// contraction runs over chunks of 8 tiles (2 x 4 tiles of one image; 4x4 maps: 2 images).  Waves as in the forward kernel:
+// (32 c x 32 k sub-block, xi half), 128 accumulator registers each; transform waves: raw x box (LDS) -> B^T d B -> V;
+// movers: x box and gy global -> registers -> LDS, gy through G'' gy G''^T on the way (its tiles do not overlap), and the
+// bias gradient (plane (1, 1) = the sum of the tile's four pixels) in the blocks of the first c-block.  LDS rows are
+// CONTRACTION-major here ([xi][tile][64 channels]: the MFMA's k index is the tile), fragments are ds_read_b32 pairs 128
+// dwords apart.  The block's result goes through A' (4x4 -> 3x3) into its slab of the workspace in the packed-weight
+// layout; wgrad_reduce_kernel (igemm.hip) sums the slabs in fixed order, as for the direct kernels.
+constexpr int W_PLANE = 512;                   // dwords per xi plane: 8 tiles x 64 channels
+constexpr int W_VSZ = 16 * W_PLANE;            // V, then Gy
+constexpr int W_STAGE = 2 * W_VSZ;             // 65 536 B
+constexpr int W_RAWPX = 60;                    // raw box capacity: 6 x 10 pixels x 64 channels
+constexpr int W_RAWSZ = W_RAWPX * 64;
+constexpr int W_RAW0 = 2 * W_STAGE;
+constexpr int W_ZERO = W_RAW0 + 2 * W_RAWSZ;   // one pixel of zeros (never written)
+constexpr int W_LDS_DWORDS = W_ZERO + 64;      // 162 048 B
+
+struct WArgs {
+  const float* x;      // [N][H][W][ldx]
+  const float* gy;     // [N][H][W][ldy]
+  float* ws;           // [splits][9 * C][K] partial slabs (packed-weight layout, dense)
+  float* bias_ws;      // [splits][K] partial bias gradients, or NULL
+  int N, H, W, C, K, ldx, ldy;
+  int CTH, CTW, sh_ctw, sh_cthw, CNIMG;   // tiles per image part in a chunk, images per chunk (CTH * CTW * CNIMG = 8)
+  int QH, QW;          // chunks per image along h / w
+  int Q, qps;          // chunks in all, chunks per split
+  int BH, BW, r_org, c_org;   // raw box per image part (see Args)
+  int CB, KB;          // 64-wide blocks of C and of K
+};
+
+template <int ROLE>   // 0: transform waves (xi rows 0, 1), 1: movers (rows 2, 3)
+__device__ __forceinline__ void wbody(const WArgs& p, float* smem) {
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;     // sub-block: 32 input channels x 32 output channels
+  // block -> (c-block, k-block, split): the blocks of one split are neighbours on one XCD (they read the same x and gy)
+  const int per = p.CB * p.KB;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = lin / per, rem = lin - split * per;
+  const int cb = rem / p.KB, kb = rem - cb * p.KB;
+  const int q_begin = split * p.qps, q_end = min(p.Q, q_begin + p.qps);
+  const int T = max(0, q_end - q_begin);
+  const int qpi = p.QH * p.QW;
+
+  // ---- chunk streams (movers): raw x runs 3 chunks ahead, gy 2 ahead ----
+  struct Stream { int q, ng, cy, cx; };
+  auto stream_at = [&](int q) -> Stream {
+    Stream s; s.q = q; s.ng = q / qpi;
+    const int r = q - s.ng * qpi;
+    s.cy = r / p.QW; s.cx = r - s.cy * p.QW;
+    return s;
+  };
+  auto step = [&](Stream& s) { ++s.q; if (++s.cx == p.QW) { s.cx = 0; if (++s.cy == p.QH) { s.cy = 0; ++s.ng; } } };
+
+  // movers, raw x: items (pixel * 16 + channel quad): tid + 256 i
+  int xfix[4], xr[4], xc[4], ximg[4], wrRaw[4];
+  const int npx = p.CNIMG * p.BH * p.BW;
+  // movers, gy: (channel quad, row half of G'' gy G''^T, tile)
+  const int gq = tid & 15, hsel = (tid >> 4) & 1, gt = tid >> 5;
+  int gfix = 0, gimg = 0;
+  const int wrG = W_VSZ + (hsel * 8) * W_PLANE + gt * 64 + gq * 4;
+  if constexpr (ROLE == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int item = tid + 256 * i, px = item >> 4, cq = item & 15;
+      const int bhw = p.BH * p.BW;
+      ximg[i] = px / bhw;
+      const int r2 = px - ximg[i] * bhw;
+      xr[i] = r2 / p.BW + p.r_org; xc[i] = r2 - (r2 / p.BW) * p.BW + p.c_org;      // relative to the chunk's first output pixel
+      if (px >= npx) xr[i] = -(1 << 20);                                             // never valid
+      xfix[i] = ((ximg[i] * p.H + xr[i]) * p.W + xc[i]) * p.ldx * 4 + (cb * 64 + cq * 4) * 4;
+      wrRaw[i] = px * 64 + ((cq ^ ((px & 1) * 8)) * 4);
+    }
+    gimg = gt >> p.sh_cthw;
+    const int ty = (gt >> p.sh_ctw) & (p.CTH - 1), tx = gt & (p.CTW - 1);
+    gfix = ((gimg * p.H + 2 * ty) * p.W + 2 * tx) * p.ldy * 4 + (kb * 64 + gq * 4) * 4;
+  }
+  Stream sx = stream_at(q_begin), sg = stream_at(q_begin);
+  float4 rraw[4], rg[4];
+  float4 colacc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool do_bias = p.bias_ws != nullptr && cb == 0;      // uniform per block
+
+  auto load_raw = [&]() {     // chunk sx into flight, then step the stream
+    const bool on = sx.q < q_end;
+    const float* base = p.x + (size_t)sx.ng * p.CNIMG * p.H * p.W * p.ldx;
+    const __amdgpu_buffer_rsrc_t rs = rsrc(base, on);
+    const int oy = sx.cy * 2 * p.CTH, ox = sx.cx * 2 * p.CTW;
+    const int soff = (oy * p.W + ox) * p.ldx * 4;
+    const int nleft = p.N - sx.ng * p.CNIMG;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = (unsigned)(oy + xr[i]) < (unsigned)p.H && (unsigned)(ox + xc[i]) < (unsigned)p.W && ximg[i] < nleft;
+      rraw[i] = bload4(rs, ok ? (unsigned)(xfix[i] + soff) : OOB, 0);
+    }
+    step(sx);
+  };
+  auto store_raw = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (tid + 256 * i < npx * 16) *reinterpret_cast<float4*>(smem + W_RAW0 + stage * W_RAWSZ + wrRaw[i]) = rraw[i];
+  };
+  auto load_gy = [&]() {
+    const bool on = sg.q < q_end && sg.ng * p.CNIMG + gimg < p.N;
+    const float* base = p.gy + (size_t)sg.ng * p.CNIMG * p.H * p.W * p.ldy;
+    const __amdgpu_buffer_rsrc_t rs = rsrc(base, sg.q < q_end);
+    const unsigned v = on ? (unsigned)(gfix + ((sg.cy * 2 * p.CTH * p.W + sg.cx * 2 * p.CTW) * p.ldy) * 4) : OOB;
+    const unsigned dc = (unsigned)p.ldy * 4u, dr = (unsigned)(p.W * p.ldy) * 4u;
+    rg[0] = bload4(rs, v, 0); rg[1] = bload4(rs, v + dc, 0);
+    rg[2] = bload4(rs, v + dr, 0); rg[3] = bload4(rs, v + dr + dc, 0);
+    step(sg);
+  };
+  const float hs = hsel ? 1.f : 0.f;
+  auto gy_stage_store = [&](int bufoff) {   // G'' gy G''^T, rows 2 hsel, 2 hsel + 1: 8 planes x float4
+    float u0[2][4], u1[2][4];               // [column q][channel]: row a = 2 hsel | 2 hsel + 1 of G'' gy
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float g0 = ((const float*)&rg[q])[e], g1 = ((const float*)&rg[2 + q])[e];
+        u0[q][e] = __builtin_fmaf(-hs, g1, g0);          // hsel 0: g0        hsel 1: g0 - g1
+        u1[q][e] = __builtin_fmaf(1.f - hs, g0, g1);     // hsel 0: g0 + g1   hsel 1: g1
+      }
+#pragma unroll
+    for (int al = 0; al < 2; ++al) {
+      const float (*u)[4] = al ? u1 : u0;
+      float4 o0, o1, o2, o3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ((float*)&o0)[e] = u[0][e]; ((float*)&o1)[e] = u[0][e] + u[1][e];
+        ((float*)&o2)[e] = u[0][e] - u[1][e]; ((float*)&o3)[e] = u[1][e];
+      }
+      float* dst = smem + bufoff + wrG + al * 4 * W_PLANE;
+      *reinterpret_cast<float4*>(dst) = o0;
+      *reinterpret_cast<float4*>(dst + W_PLANE) = o1;
+      *reinterpret_cast<float4*>(dst + 2 * W_PLANE) = o2;
+      *reinterpret_cast<float4*>(dst + 3 * W_PLANE) = o3;
+      if (al == 1 && do_bias) {     // plane (1, 1) of the hsel = 0 lanes = g00 + g01 + g10 + g11
+        asm volatile("" ::: "memory");
+        colacc.x += o1.x; colacc.y += o1.y; colacc.z += o1.z; colacc.w += o1.w;
+      }
+    }
+  };
+
+  // ---- transform waves: (half, channel quad, tile) ----
+  const int half = tid & 1, cq = (tid >> 1) & 15, tile = tid >> 5;
+  const float sgn = half ? -1.f : 1.f;
+  const int wsw = (cq ^ (half ? 4 : 0)) * 4;       // planes written by half 1 (b = 2, 3) keep their rows XOR 16: the lane pair of
+  const int wrV0 = (half ? 3 : 0) * W_PLANE + tile * 64 + wsw;     // a tile then stores to different banks (32 of them for stores)
+  const int wrV1 = (half ? 2 : 1) * W_PLANE + tile * 64 + wsw;
+  int rdRawA[4], rdRawB[4];
+  if constexpr (ROLE == 0) {
+    const int img = tile >> p.sh_cthw, ty = (tile >> p.sh_ctw) & (p.CTH - 1), tx = tile & (p.CTW - 1);
+    const int cA = 2 * tx - 1 + (half ? 2 : 1) - p.c_org, cB = 2 * tx - 1 + (half ? 3 : 0) - p.c_org;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 2 * ty - 1 + i - p.r_org;
+      const bool rok = (unsigned)r < (unsigned)p.BH;
+      const int pa = (img * p.BH + r) * p.BW + cA, pb = (img * p.BH + r) * p.BW + cB;
+      rdRawA[i] = (rok && (unsigned)cA < (unsigned)p.BW) ? pa * 64 + ((cq ^ ((pa & 1) * 8)) * 4) : -1;
+      rdRawB[i] = (rok && (unsigned)cB < (unsigned)p.BW) ? pb * 64 + ((cq ^ ((pb & 1) * 8)) * 4) : -1;
+    }
+  }
+  float4 rxA[4], rxB[4];
+  float tA[4][4], tB[4][4];
+  auto read_raw = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      rxA[i] = *reinterpret_cast<const float4*>(smem + (rdRawA[i] >= 0 ? W_RAW0 + stage * W_RAWSZ + rdRawA[i] : W_ZERO + cq * 4));
+      rxB[i] = *reinterpret_cast<const float4*>(smem + (rdRawB[i] >= 0 ? W_RAW0 + stage * W_RAWSZ + rdRawB[i] : W_ZERO + cq * 4));
+    }
+  };
+  auto col_stage = [&](int c) {
+    const float a0 = ((const float*)&rxA[0])[c], a1 = ((const float*)&rxA[1])[c], a2 = ((const float*)&rxA[2])[c], a3 = ((const float*)&rxA[3])[c];
+    const float b0 = ((const float*)&rxB[0])[c], b1 = ((const float*)&rxB[1])[c], b2 = ((const float*)&rxB[2])[c], b3 = ((const float*)&rxB[3])[c];
+    tA[0][c] = a0 - a2; tA[1][c] = a1 + a2; tA[2][c] = a2 - a1; tA[3][c] = a1 - a3;
+    tB[0][c] = b0 - b2; tB[1][c] = b1 + b2; tB[2][c] = b2 - b1; tB[3][c] = b1 - b3;
+  };
+  auto row_stage_store = [&](int bufoff, int i) {
+    float4 o0, o1;
+    float* q0 = (float*)&o0; float* q1 = (float*)&o1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float r = dpp_swap1(tA[i][c]);
+      q0[c] = tB[i][c] - r;
+      q1[c] = __builtin_fmaf(sgn, r, tA[i][c]);
+    }
+    *reinterpret_cast<float4*>(smem + bufoff + wrV0 + i * 4 * W_PLANE) = o0;
+    *reinterpret_cast<float4*>(smem + bufoff + wrV1 + i * 4 * W_PLANE) = o1;
+  };
+
+  // fragment reads: plane xi = (a, b), a = 2 ROLE + (0 | 1): A = V[t][c row], rows of the b >= 2 planes XOR 16; B = Gy[t][k]
+  const int rdA0 = ROLE * 8 * W_PLANE + lhi * 64 + wm * 32 + l31;           // b = 0, 1
+  const int rdA1 = ROLE * 8 * W_PLANE + lhi * 64 + wm * 32 + (l31 ^ 16);    // b = 2, 3
+  const int rdB = W_VSZ + ROLE * 8 * W_PLANE + lhi * 64 + wn * 32 + l31;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // ---- prologue ----
+  if constexpr (ROLE == 1) {
+    if (tid < 16) *reinterpret_cast<float4*>(smem + W_ZERO + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    load_raw();                // raw 0
+    load_gy();                 // gy 0
+    store_raw(0);
+    load_raw();                // raw 1
+    gy_stage_store(0);
+    load_gy();                 // gy 1
+  }
+  __syncthreads();
+  if constexpr (ROLE == 0) {
+    read_raw(0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) col_stage(c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) row_stage_store(0, i);
+  } else {
+    store_raw(1);
+    load_raw();                // raw 2
+  }
+  __syncthreads();
+
+  // iteration g: MFMAs on stage g & 1;  transform waves: raw (g + 1) -> V stage (g+1)&1;  movers: raw (g + 2) registers -> raw
+  // stage g & 1, raw (g + 3) into flight, gy (g + 1) registers -> G'' gy G''^T -> Gy stage (g+1)&1, gy (g + 2) into flight
+  auto chunk = [&](auto par) {
+    constexpr int P = decltype(par)::value;
+    constexpr int cur = P * W_STAGE, nxt = W_STAGE - cur;
+    float fa[2][4], fb[2][4];
+    auto frags = [&](int xi, int s) {
+      const int ra = (xi & 2) ? rdA1 : rdA0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        fa[s][j] = smem[cur + ra + xi * W_PLANE + j * 128];
+        fb[s][j] = smem[cur + rdB + xi * W_PLANE + j * 128];
+      }
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int xi = 0; xi < 8; ++xi) {
+      if (xi + 1 < 8) frags(xi + 1, (xi + 1) & 1);
+      if constexpr (ROLE == 0) {
+        if (xi == 0) read_raw(1 - P);
+        if (xi == 1) { col_stage(0); col_stage(1); }
+        if (xi == 2) { col_stage(2); col_stage(3); }
+        if (xi >= 3 && xi < 7) row_stage_store(nxt, xi - 3);
+      } else {
+        if (xi == 0) store_raw(P);
+        if (xi == 1) load_raw();
+        if (xi == 3) gy_stage_store(nxt);
+        if (xi == 5) load_gy();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[xi & 1][j], fb[xi & 1][j], acc[xi], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  };
+  for (int t = 0; t < T; t += 2) {
+    chunk(std::integral_constant<int, 0>{});
+    chunk(std::integral_constant<int, 1>{});      // (an odd T runs one chunk of zeros: the streams are off past q_end)
+  }
+
+  // ---- output transform 4x4 -> 3x3 and the slab.  R[a][j] = sum_b S[a][b] ATc[j][b], ATc = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,+1]]
+  // (column 3 sign: the negated V planes); dW[i][j] = sum_a ATr[i][a] R[a][j], ATr = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,-1]]:
+  //   rows a = 0, 1 (ROLE 0): (R0 + .5 R1, .5 R1, .5 R1);   rows a = 2, 3 (ROLE 1): (.5 R2, -.5 R2, .5 R2 - R3)
+  // The movers hand their nine values per element to the transform waves through LDS (free now): [wave][row][tap][lane].
+  auto taps9 = [&](int r, float* o) {
+    float R[2][3];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const float s0 = acc[a * 4 + 0][r], s1 = acc[a * 4 + 1][r], s2 = acc[a * 4 + 2][r], s3 = acc[a * 4 + 3][r];
+      const float hp = 0.5f * (s1 + s2);
+      R[a][0] = s0 + hp; R[a][1] = 0.5f * (s1 - s2); R[a][2] = hp + s3;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (ROLE == 0) { o[0 * 3 + j] = R[0][j] + 0.5f * R[1][j]; o[1 * 3 + j] = 0.5f * R[1][j]; o[2 * 3 + j] = 0.5f * R[1][j]; }
+      else { o[0 * 3 + j] = 0.5f * R[0][j]; o[1 * 3 + j] = -0.5f * R[0][j]; o[2 * 3 + j] = 0.5f * R[0][j] - R[1][j]; }
+    }
+  };
+  float* xch = smem + (wave * 16 * 9) * 64 + lane;
+  if constexpr (ROLE == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float o[9];
+      taps9(r, o);
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) xch[(r * 9 + tp) * 64] = o[tp];
+    }
+    __syncthreads();
+  } else {
+    __syncthreads();
+    float* slab = p.ws + (size_t)split * 9 * p.C * p.K;
+    const int k = kb * 64 + wn * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      __builtin_amdgcn_sched_barrier(0);
+      float o[9];
+      taps9(r, o);
+      const int c = cb * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) slab[((size_t)tp * p.C + c) * p.K + k] = o[tp] + xch[(r * 9 + tp) * 64];
+    }
+  }
+  if (do_bias) {      // uniform: sum the eight tiles' partial column sums (hsel = 0 lanes of the movers)
+    __syncthreads();
+    float* red = smem;      // [8 tiles][64]
+    if (ROLE == 1 && hsel == 0) *reinterpret_cast<float4*>(red + gt * 64 + gq * 4) = colacc;
+    __syncthreads();
+    if (ROLE == 0 && tid < 64) {
+      float sum = 0.f;
+#pragma unroll
+      for (int t8 = 0; t8 < 8; ++t8) sum += red[t8 * 64 + tid];
+      p.bias_ws[(size_t)split * p.K + kb * 64 + tid] = sum;
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (threadIdx.x < 256) wbody<0>(p, smem); else wbody<1>(p, smem);
+}
+
 }  // namespace wino

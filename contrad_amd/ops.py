@@ -87,7 +87,7 @@ def conv_kernel_name(mode, d):
     if path == 6:
         return 'conv_c32_kernel<%d>' % mode
     if path == 7:
-        return 'wino_kernel<%d>' % mode
+        return 'wino_wgrad_kernel' if mode == 2 else 'wino_kernel<%d>' % mode
     if path in (2, 3):
         return 'igemm_lean_kernel<%d, %d, %d>' % (mode, bm.value, bn.value)
     return 'igemm_kernel<%d, %d, %d, %s>' % (mode, bm.value, bn.value, 'true' if path == 1 else 'false')
@@ -195,10 +195,29 @@ def conv2d_wino(mode, inp, wp, C, K, bias=None, ref=None, slope=1.0, gain=1.0, o
                   wp.stride(0))
     if lib().raw('contrad_conv2d_wino_ok')(ctypes.byref(d), mode) != 1:
         raise RuntimeError('contrad_hip: shape not supported by the Winograd kernel')
-    nbytes = lib().raw('contrad_conv2d_wino_workspace_bytes')(ctypes.byref(d))
+    nbytes = lib().raw('contrad_conv2d_wino_workspace_bytes')(ctypes.byref(d), mode)
     ws = _workspace(nbytes, inp.device)
     lib().call('contrad_conv2d_wino', ctypes.byref(d), mode, _p(inp), _p(wp), _p(bias), _p(ref), _p(out),
                float(slope), float(gain), _p(ws), ctypes.c_longlong(nbytes), _stream())
+    return out
+
+
+def conv2d_wino_wgrad(x, gy, ldw=None, out=None, dbias=None):
+    """Weight gradient of a 3x3 stride-1 pad-1 layer on the Winograd kernel F(3x3, 2x2) (forced; conv2d_wgrad picks it by itself
+    when the launch fills the chip).  Returns dwp packed (9 * C, ldw)."""
+    _chk(x, 'x'); _chk(gy, 'gy')
+    N, H, W, C = x.shape
+    K = gy.shape[3]
+    if out is None:
+        out = torch.zeros((9 * C, ldw or round_up(K, 4)), device=x.device, dtype=torch.float32)
+    _chk(out, 'out')
+    d = make_desc(N, H, W, C, K, 3, 3, 1, 1, _ld(x), _ld(gy), out.stride(0))
+    if lib().raw('contrad_conv2d_wino_ok')(ctypes.byref(d), 2) != 1:
+        raise RuntimeError('contrad_hip: shape not supported by the Winograd weight-gradient kernel')
+    nbytes = lib().raw('contrad_conv2d_wino_workspace_bytes')(ctypes.byref(d), 2)
+    ws = _workspace(nbytes, x.device)
+    lib().call('contrad_conv2d_wino_wgrad', ctypes.byref(d), _p(x), _p(gy), _p(out), _p(dbias), _p(ws),
+               ctypes.c_longlong(ws.numel() * 4), _stream())
     return out
 
 

@@ -84,9 +84,14 @@ int contrad_conv2d_dgrad_ws(const contrad_conv_desc* d, const float* gy, const f
  * more -- their *_workspace_bytes then cover the transformed filter (16 * C * K floats, rewritten by every call) --;
  * contrad_conv2d_wino runs it on ANY shape contrad_conv2d_wino_ok accepts (parity tests, integrators with their own plan).
  * mode 0: in = x, out = y = gain * lrelu(conv + bias) [+ ref], bias / ref may be NULL;
- * mode 1: in = gy, out = dx [* act'(ref)], bias must be NULL (semantics of contrad_conv2d_fwd_add / _dgrad_ws). */
+ * mode 1: in = gy, out = dx [* act'(ref)], bias must be NULL (semantics of contrad_conv2d_fwd_add / _dgrad_ws).
+ * The weight gradient of the same layers (mode 2: F(3x3, 2x2), input AND output channels multiples of 64) runs on
+ * wino_wgrad_kernel: contrad_conv2d_wgrad picks it when every CU gets a long enough share of the tiles,
+ * contrad_conv2d_wino_wgrad forces it (arguments and results of contrad_conv2d_wgrad, workspace = split slabs). */
 int contrad_conv2d_wino_ok(const contrad_conv_desc* d, int mode);
-long long contrad_conv2d_wino_workspace_bytes(const contrad_conv_desc* d);
+long long contrad_conv2d_wino_workspace_bytes(const contrad_conv_desc* d, int mode);
+int contrad_conv2d_wino_wgrad(const contrad_conv_desc* d, const float* x, const float* gy, float* dwp, float* dbias,
+                              float* workspace, long long workspace_bytes, contrad_stream_t stream);
 int contrad_conv2d_wino(const contrad_conv_desc* d, int mode, const float* in, const float* wp, const float* bias,
                         const float* ref, float* out, float slope, float gain, float* workspace,
                         long long workspace_bytes, contrad_stream_t stream);
@@ -105,7 +110,7 @@ int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm, int* bn);
  * a rectangle of pixels that share their non-padding taps), 4 = the accumulator-stationary weight-gradient kernel of
  * the 32 -> 32 channel 3x3 layers (wgrad_c32_kernel, mode 2 only), 5 = the single-output 1x1 layer (fwd_k1_kernel, mode 0
  * only: the 512 -> 1 logit of the heads), 6 = the weight-stationary kernel of the 32 -> 32 channel 3x3 stride-1 layers
- * (conv_c32_kernel<mode>, modes 0 and 1), 7 = Winograd F(2x2, 3x3) (wino_kernel<mode>, modes 0 and 1; with a workspace);
+ * (conv_c32_kernel<mode>, modes 0 and 1), 7 = Winograd F(2x2, 3x3) (wino_kernel<mode>, modes 0 and 1; with a workspace) / F(3x3, 2x2) (wino_wgrad_kernel, mode 2);
  * negative = bad descriptor.  Profiling aid. */
 int contrad_conv2d_path(const contrad_conv_desc* d, int mode);
 /* Share of the layer's nominal multiply-adds (2*N*Ho*Wo*K*C*KH*KW, the count every roofline here is quoted on, padding

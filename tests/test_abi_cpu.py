@@ -68,10 +68,10 @@ def test_launch_plans_are_host_logic(built):
             # Round 6: forward and data gradient of the 3x3 stride-1 layers run on the Winograd kernel (path 7, csrc/wino.h; one
             # persistent 512-thread block per CU; the workspace holds the transformed filter)
             Ho = (H + 2 * p - k) // s + 1
-            if mode == 2:
-                want = 3 if (Ho == 4 or (Ho == 8 and k == 3)) else 2
-            elif k == 3:
-                want = 7
+            if k == 3:
+                want = 7           # (the weight gradient too: wino_wgrad_kernel, F(3x3, 2x2), one block per CU over split tile ranges)
+            elif mode == 2:
+                want = 3 if Ho == 4 else 2
             else:
                 want = 3 if (mode == 0 or s == 1 or H == 8) else 2
             assert path(ctypes.byref(d), mode) == want, (H, C, K, mode)
@@ -86,7 +86,12 @@ def test_launch_plans_are_host_logic(built):
         want_ws = 16 * C * K * 4 if k == 3 else 0
         assert built.raw('contrad_conv2d_fwd_workspace_bytes')(ctypes.byref(d)) == want_ws
         assert built.raw('contrad_conv2d_dgrad_workspace_bytes')(ctypes.byref(d)) == want_ws
-        assert built.raw('contrad_conv2d_wino_workspace_bytes')(ctypes.byref(d)) == 16 * C * K * 4
+        assert built.raw('contrad_conv2d_wino_workspace_bytes')(ctypes.byref(d), 0) == 16 * C * K * 4
+        if k == 3:      # weight gradient: 256 / (C/64 * K/64) split slabs of the packed gradient + the bias partials
+            splits = 256 // ((C // 64) * (K // 64))
+            assert built.raw('contrad_conv2d_wgrad_workspace_bytes')(ctypes.byref(d)) == splits * (9 * C + 1) * K * 4
+            assert built.raw('contrad_conv2d_wino_workspace_bytes')(ctypes.byref(d), 2) == splits * (9 * C + 1) * K * 4
+            assert built.raw('contrad_conv2d_grid_blocks')(ctypes.byref(d), 2, 1) == 256
     # Cin = 3 / Cout = 1 / 513 channels: general kernel, scalar or float4 gathers
     assert path(ctypes.byref(_desc(8, 32, 3, 64, 3, 1, 1)), 0) == 0
     d1 = _desc(8, 1, 512, 1, 1, 1, 0)                      # the 512 -> 1 logit: its own one-wave-per-row kernel forward,

@@ -74,6 +74,38 @@ def test_wino_data_gradient(case):
     assert rel(dx.cpu(), ref * torch.where(act > 0, 1.5, 0.3)) < TIGHT
 
 
+# (N, H, W, C, K): C and K multiples of 64
+WCASES = [
+    (3, 16, 16, 64, 64),       # chunks of 2 x 4 tiles: 4 x 2 chunks per image, boxes of 6 x 10 pixels with halo
+    (2, 32, 32, 64, 128),      # boxes with halo on both axes, two k-blocks
+    (5, 8, 8, 128, 64),        # full-width chunks (box 6 x 8), two c-blocks; odd chunk count per split possible
+    (19, 4, 4, 64, 64),        # 2 images per chunk, ragged last chunk
+    (2, 64, 16, 64, 64),       # non-square
+    (1, 4, 8, 64, 64),         # one chunk per image
+    (40, 16, 16, 64, 192),     # many chunks, several splits
+]
+
+
+@pytest.mark.parametrize('case', WCASES)
+def test_wino_weight_gradient(case):
+    N, H, W, C, K = case
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(N, H, W, C, generator=g)
+    gy = torch.randn(N, H, W, K, generator=g)
+    xr = x.permute(0, 3, 1, 2).contiguous().requires_grad_(False)
+    w0 = torch.zeros(K, C, 3, 3, requires_grad=True)
+    b0 = torch.zeros(K, requires_grad=True)
+    F.conv2d(xr, w0, b0, padding=1).backward(gy.permute(0, 3, 1, 2))
+    dev = torch.device('cuda')
+    dbias = torch.empty(K, device=dev)
+    dwp = ops.conv2d_wino_wgrad(x.to(dev), gy.to(dev), dbias=dbias)
+    dw = ops.unpack_weight(dwp, K, C, 3, 3).cpu()
+    assert rel(dw, w0.grad) < TIGHT
+    assert rel(dbias.cpu(), b0.grad) < TIGHT
+    dwp2 = ops.conv2d_wino_wgrad(x.to(dev), gy.to(dev))
+    assert torch.equal(dwp, dwp2)            # deterministic (fixed-order reduce), with or without the bias gradient
+
+
 def test_wino_channel_sliced_views():
     """Input and output are channel slices of wider buffers (leading dimension != channels), as the engine's callers pass them."""
     N, H, W, C, K = 3, 16, 16, 32, 64
@@ -138,3 +170,23 @@ def test_the_plan_takes_winograd_at_the_baseline_shapes_and_matches_torch(shape)
     dx = ops.conv2d_dgrad(y, wp, (N, H, H, C), 3, 3, 1, 1, act_ref=xd, slope=0.1, gain=1.0)
     refd = F.conv_transpose2d(y[sel].cpu().permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1) * torch.where(xs > 0, 1.0, 0.1)
     assert rel(dx[sel].cpu(), refd) < TIGHT
+    # weight gradient at full size: Winograd by the plan; against the direct kernels' result on HALF the images twice (linearity:
+    # dW(all) = dW(first half) + dW(second half), each half small enough for ... the same plan) and against PyTorch-CPU on a
+    # sub-batch through the forced entry point
+    assert lib().raw('contrad_conv2d_path')(ctypes.byref(d), 2) == 7
+    dbias = torch.empty(K, device=dev)
+    dwp = ops.conv2d_wgrad(xd, y, 3, 3, 1, 1, dbias=dbias)
+    nb = 8 if H <= 64 else 2
+    acc = torch.zeros_like(dwp)
+    accb = torch.zeros_like(dbias)
+    step = N // 4
+    for i in range(0, N, step):              # four quarter-batches on whichever kernel the plan picks for them
+        db = torch.empty(K, device=dev)
+        acc += ops.conv2d_wgrad(xd[i:i + step], y[i:i + step], 3, 3, 1, 1, dbias=db)
+        accb += db
+    assert rel(dwp, acc) < 1e-4 and rel(dbias, accb) < 1e-4
+    xs2, ys2 = x[:nb], y[:nb].cpu()
+    w0 = torch.zeros(K, C, 3, 3, requires_grad=True)
+    F.conv2d(xs2.permute(0, 3, 1, 2), w0, None, padding=1).backward(ys2.permute(0, 3, 1, 2))
+    dws = ops.unpack_weight(ops.conv2d_wino_wgrad(xd[:nb], y[:nb]), K, C, 3, 3).cpu()
+    assert rel(dws, w0.grad) < TIGHT
