@@ -72,7 +72,7 @@ def main(d, prefix, command):
     names = [k for k in parsed['fetch'] if all(k in parsed[p] for p in ('write', 'sq', 'misc')) and
              parsed['fetch'][k]['avg_dur_us'] > 10.0 and not k.startswith('at::')]
     ents = {k: entry(k) for k in names}
-    dom = max(ents.values(), key=lambda e: e['avg_dur_us'] * e['dispatches'] if 'igemm' in e['kernel'] else 0)['kernel']
+    dom = max(ents.values(), key=lambda e: e['avg_dur_us'] * e['dispatches'] if ('igemm' in e['kernel'] or 'wino' in e['kernel']) else 0)['kernel']
     sys.path.insert(0, ROOT)
     from bench import _csrc_fingerprint
     js = {
