@@ -815,6 +815,7 @@ int launch(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
 #include "wgrad_c32.h"
 #include "conv_c32.h"
 #include "wino.h"
+#include "wino22.h"
 
 // ---------------- Winograd F(2x2, 3x3) path (wino.h): 3x3 stride-1 pad-1 layers, forward and data gradient ----------------
 // Can the shape run on wino_kernel<mode> at all?  (input channels % 16, output channels % 64, power-of-two maps >= 4)
@@ -876,6 +877,117 @@ long long wino_workspace_bytes(const contrad_conv_desc* d) { return 16ll * d->C 
 int wino_grid(const wino::Args& a) {
   const int l0 = cdiv(a.NP, 8) * a.NKB;           // items of the fullest XCD
   return 8 * std::min(WINO_CUS / 8, l0);
+}
+
+
+// ---------------- Winograd F(2x2, 2x2) path (wino22.h): 4x4 stride-2 pad-1 layers, forward and data gradient ----------------
+bool wino22_ok(const contrad_conv_desc* d, int mode) {
+  if (mode != MODE_FWD && mode != MODE_DGRAD) return false;
+  if (d->KH != 4 || d->KW != 4 || d->stride != 2 || d->pad != 1) return false;
+  if ((d->H & 1) || (d->W & 1) || d->Ho * 2 != d->H || d->Wo * 2 != d->W) return false;
+  auto grid_ok = [](int g) { return g == 4 || g == 8 || g == 16; };
+  if (!grid_ok(d->Ho) || !grid_ok(d->Wo)) return false;
+  const int cin = mode == MODE_FWD ? d->C : d->K, cout = mode == MODE_FWD ? d->K : d->C;
+  const int ldi = mode == MODE_FWD ? d->ldx : d->ldy;
+  if ((cin & (mode == MODE_FWD ? 7 : 15)) || (cout & 63) || (ldi & 3) || (d->ldw & 3)) return false;
+  const long long nimg = wino22::TB / ((d->Ho / 2) * (d->Wo / 2));
+  const long long lim = 1ll << 31;
+  if (nimg * d->H * d->W * std::max(d->ldx, d->ldy) * 4 >= lim) return false;
+  if (4ll * 9 * cin * cout * 4 >= lim) return false;
+  return true;
+}
+
+wino22::Args wino22_args(const contrad_conv_desc* d, int mode) {
+  wino22::Args a{};
+  const bool dg = mode == MODE_DGRAD;
+  a.N = d->N; a.dgrad = dg ? 1 : 0;
+  a.Hi = dg ? d->Ho : d->H; a.Wi = dg ? d->Wo : d->W;
+  a.Hout = dg ? d->H : d->Ho; a.Wout = dg ? d->W : d->Wo;
+  a.Cin = dg ? d->K : d->C; a.Cout = dg ? d->C : d->K;
+  a.ldi = dg ? d->ldy : d->ldx; a.ldo = dg ? d->ldx : d->ldy;
+  a.GH = d->Ho; a.GW = d->Wo;
+  const int tw = a.GW / 2, thw = (a.GH / 2) * tw;
+  a.sh_tw = __builtin_ctz(tw); a.sh_thw = __builtin_ctz(thw);
+  a.NIMG = wino22::TB / thw;
+  a.NTB = cdiv(d->N, a.NIMG);
+  a.NKB = a.Cout / 64;
+  return a;
+}
+
+long long wino22_items(const contrad_conv_desc* d, int mode) {
+  const wino22::Args a = wino22_args(d, mode);
+  return (long long)a.NTB * a.NKB * (mode == MODE_DGRAD ? 4 : 1);
+}
+
+bool wino22_planned(const contrad_conv_desc* d, int mode) {
+  static const bool enabled = []() { const char* e = contrad_dev_env("CONTRAD_WINO22"); return !(e && e[0] == '0'); }();
+  if (!enabled || !wino22_ok(d, mode)) return false;
+  const long long items = wino22_items(d, mode);
+  const long long rounds = cdivll(items, WINO_CUS);
+  // (1.78x fewer multiply-adds, not 2.25x: a last round that is a quarter empty already loses to the direct kernels -- forward of
+  // 256 -> 512 channels at 1536 images, 384 items: 0.622 ms against 0.558, profiles/r06_ab_wino22_layers.txt)
+  return items >= 200 && rounds * WINO_CUS * 100 <= items * 125;
+}
+
+long long wino22_workspace_bytes(const contrad_conv_desc* d) { return 4ll * 9 * d->C * d->K * (long long)sizeof(float); }
+
+template <int MODE>
+int launch_wino22(const contrad_conv_desc* d, const float* in, const float* wp, const float* bias, const float* ref,
+                  float* out, float slope, float gain, float* U, hipStream_t stream) {
+  static const hipError_t attr = hipFuncSetAttribute((const void*)wino22::wino22_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     wino22::LDS_DWORDS * 4);
+  if (attr != hipSuccess) return (int)attr;
+  wino22::Args a = wino22_args(d, MODE);
+  a.x = in; a.U = U; a.y = out; a.bias = bias; a.ref = ref; a.slope = slope; a.gain = gain;
+  const int quads = 4 * (a.Cin / 4) * a.Cout;
+  hipLaunchKernelGGL(wino22::wino22_filter_kernel<MODE>, dim3(cdiv(quads, 256)), dim3(256), 0, stream, wp, U, d->C, d->K, d->ldw);
+  CONTRAD_CHECK_LAUNCH();
+  const int l0 = cdiv(a.NTB, 8) * a.NKB * (MODE == MODE_DGRAD ? 4 : 1);
+  hipLaunchKernelGGL(wino22::wino22_kernel<MODE>, dim3(8 * std::min(WINO_CUS / 8, l0)), dim3(512), wino22::LDS_DWORDS * 4, stream, a);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- weight gradient of the 4x4 stride-2 layers on F(2x2, 2x2) (wino22_wgrad_kernel) ----
+bool wino22_wgrad_ok(const contrad_conv_desc* d) {
+  if (d->KH != 4 || d->KW != 4 || d->stride != 2 || d->pad != 1) return false;
+  if (d->Ho * 2 != d->H || d->Wo * 2 != d->W) return false;
+  auto grid_ok = [](int g) { return g == 4 || g == 8 || g == 16; };
+  if (!grid_ok(d->Ho) || !grid_ok(d->Wo)) return false;
+  if ((d->C != 64 && (d->C & 127)) || (d->K & 63) || (d->ldx & 3) || (d->ldy & 3)) return false;
+  if (2ll * d->H * d->W * std::max(d->ldx, d->ldy) * 4 >= (1ll << 31)) return false;
+  return true;
+}
+
+wino22::WArgs wino22_wgrad_args(const contrad_conv_desc* d) {
+  wino22::WArgs a{};
+  a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.ldx = d->ldx; a.ldy = d->ldy; a.GH = d->Ho; a.GW = d->Wo;
+  a.CTW = std::min(4, a.GW / 2);
+  a.CTH = std::min(8 / a.CTW, a.GH / 2);
+  a.CNIMG = 8 / (a.CTH * a.CTW);
+  a.sh_ctw = __builtin_ctz(a.CTW); a.sh_cthw = __builtin_ctz(a.CTH * a.CTW);
+  a.QH = a.GH / (2 * a.CTH); a.QW = a.GW / (2 * a.CTW);
+  a.Q = cdiv(d->N, a.CNIMG) * a.QH * a.QW;
+  a.RBN = 4 * d->C / 128; a.KB = d->K / 64;
+  a.CPB = std::min(d->C, 128); a.sh_cpb = __builtin_ctz(a.CPB);
+  const int splits = std::max(1, std::min(a.Q, WINO_CUS / (a.RBN * a.KB)));
+  a.qps = cdiv(a.Q, splits);
+  return a;
+}
+int wino22_wgrad_splits(const wino22::WArgs& a) { return cdiv(a.Q, a.qps); }
+
+bool wino22_wgrad_planned(const contrad_conv_desc* d) {
+  static const bool enabled = []() { const char* e = contrad_dev_env("CONTRAD_WINO22_WGRAD"); return !(e && e[0] == '0'); }();
+  static const bool enabled2 = []() { const char* e = contrad_dev_env("CONTRAD_WINO22"); return !(e && e[0] == '0'); }();
+  if (!enabled || !enabled2 || !wino22_wgrad_ok(d)) return false;
+  const wino22::WArgs a = wino22_wgrad_args(d);
+  const long long blocks = (long long)a.RBN * a.KB * wino22_wgrad_splits(a);
+  return a.qps >= 48 && blocks * 10 >= WINO_CUS * 7 && blocks <= WINO_CUS;
+}
+
+long long wino22_wgrad_workspace_bytes(const contrad_conv_desc* d) {
+  const wino22::WArgs a = wino22_wgrad_args(d);
+  return (long long)wino22_wgrad_splits(a) * (16ll * d->C + 1) * d->K * (long long)sizeof(float);
 }
 
 // ---- weight gradient on the Winograd kernel (wino_wgrad_kernel): C % 64, K % 64 ----
@@ -1660,6 +1772,28 @@ __global__ void dgrad_reduce_kernel(const float* __restrict__ ws, int splits, lo
   }
 }
 
+int launch_wino22_wgrad(const contrad_conv_desc* d, const float* x, const float* gy, float* dwp, float* dbias,
+                        float* workspace, hipStream_t stream) {
+  static const hipError_t attr = hipFuncSetAttribute((const void*)wino22::wino22_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     wino22::W_LDS_DWORDS * 4);
+  if (attr != hipSuccess) return (int)attr;
+  wino22::WArgs a = wino22_wgrad_args(d);
+  const int splits = wino22_wgrad_splits(a);
+  const long long total = 16ll * d->C * d->K;
+  a.x = x; a.gy = gy; a.ws = workspace;
+  a.bias_ws = dbias ? workspace + (size_t)splits * total : nullptr;
+  hipLaunchKernelGGL(wino22::wino22_wgrad_kernel, dim3(a.RBN * a.KB * splits), dim3(512), wino22::W_LDS_DWORDS * 4, stream, a);
+  CONTRAD_CHECK_LAUNCH();
+  int R = 1;
+  while (R < 64 && R * 2 <= splits && (total / 4) * R < 65536) R <<= 1;
+  long long rb = ((total / 4) * R + 255) / 256;
+  if (rb > 2048) rb = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)rb), dim3(256), 0, stream, workspace, dwp, 16 * d->C, d->K, d->ldw, splits,
+                     a.bias_ws, dbias, R);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
 int launch_wino_wgrad(const contrad_conv_desc* d, const float* x, const float* gy, float* dwp, float* dbias,
                       float* workspace, hipStream_t stream) {
   static const hipError_t attr = hipFuncSetAttribute((const void*)wino::wino_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1689,6 +1823,7 @@ extern "C" int contrad_abi_version(void) { return 2; }
 extern "C" long long contrad_conv2d_fwd_workspace_bytes(const contrad_conv_desc* d) {
   if (check_desc(d)) return -22;
   if (wino_planned(d, MODE_FWD)) return wino_workspace_bytes(d);
+  if (wino22_planned(d, MODE_FWD)) return wino22_workspace_bytes(d);
   const FwdPlan p = fwd_plan(d);
   if (p.splits <= 1) return 0;
   return (long long)p.splits * d->N * d->Ho * d->Wo * d->K * (long long)sizeof(float);
@@ -1710,6 +1845,10 @@ extern "C" int contrad_conv2d_fwd_add(const contrad_conv_desc* d, const float* x
   if (wino_planned(d, MODE_FWD) && workspace && workspace_bytes >= wino_workspace_bytes(d)) {   // Winograd F(2x2, 3x3), wino.h
     CONTRAD_ARG(aligned16(x, wp, workspace));
     return launch_wino<MODE_FWD>(d, x, wp, bias, addend, y, slope, gain, workspace, (hipStream_t)stream);
+  }
+  if (wino22_planned(d, MODE_FWD) && workspace && workspace_bytes >= wino22_workspace_bytes(d)) {   // F(2x2, 2x2) on the phases, wino22.h
+    CONTRAD_ARG(aligned16(x, wp, workspace));
+    return launch_wino22<MODE_FWD>(d, x, wp, bias, addend, y, slope, gain, workspace, (hipStream_t)stream);
   }
   if (conv_c32_ok(d))   // weight-stationary kernel (conv_c32.h); (alignment is an argument error above, so the dispatch is
                         // exactly what contrad_conv2d_path / _grid_blocks report)
@@ -1767,6 +1906,7 @@ extern "C" int contrad_conv2d_fwd(const contrad_conv_desc* d, const float* x, co
 extern "C" long long contrad_conv2d_dgrad_workspace_bytes(const contrad_conv_desc* d) {
   if (check_desc(d)) return -22;
   if (wino_planned(d, MODE_DGRAD)) return wino_workspace_bytes(d);
+  if (wino22_planned(d, MODE_DGRAD)) return wino22_workspace_bytes(d);
   const FwdPlan p = dgrad_plan(d, true);
   if (p.splits <= 1) return 0;
   return (long long)p.splits * d->N * d->H * d->W * d->ldx * (long long)sizeof(float);
@@ -1782,6 +1922,10 @@ extern "C" int contrad_conv2d_dgrad_ws(const contrad_conv_desc* d, const float* 
   if (wino_planned(d, MODE_DGRAD) && workspace && workspace_bytes >= wino_workspace_bytes(d)) {   // wino.h: mirrored filter
     CONTRAD_ARG(aligned16(gy, wp, workspace));
     return launch_wino<MODE_DGRAD>(d, gy, wp, nullptr, act_ref, dx, slope, gain, workspace, (hipStream_t)stream);
+  }
+  if (wino22_planned(d, MODE_DGRAD) && workspace && workspace_bytes >= wino22_workspace_bytes(d)) {   // wino22.h: one item per dx phase
+    CONTRAD_ARG(aligned16(gy, wp, workspace));
+    return launch_wino22<MODE_DGRAD>(d, gy, wp, nullptr, act_ref, dx, slope, gain, workspace, (hipStream_t)stream);
   }
   if (conv_c32_ok(d))   // stride-1 pad-1 3x3: the same weight-stationary kernel with the filter mirrored (conv_c32.h)
     return launch_conv_c32<MODE_DGRAD>(d, gy, wp, dx, nullptr, nullptr, act_ref, slope, gain, (hipStream_t)stream);
@@ -1876,14 +2020,14 @@ extern "C" int contrad_conv2d_dgrad(const contrad_conv_desc* d, const float* gy,
 
 extern "C" int contrad_conv2d_wino_ok(const contrad_conv_desc* d, int mode) {
   if (check_desc(d)) return -22;
-  if (mode == MODE_WGRAD) return wino_wgrad_ok(d) ? 1 : 0;
-  return wino_ok(d, mode) ? 1 : 0;
+  if (mode == MODE_WGRAD) return (wino_wgrad_ok(d) || wino22_wgrad_ok(d)) ? 1 : 0;
+  return (wino_ok(d, mode) || wino22_ok(d, mode)) ? 1 : 0;
 }
 
 extern "C" long long contrad_conv2d_wino_workspace_bytes(const contrad_conv_desc* d, int mode) {
   if (check_desc(d) || mode < 0 || mode > 2) return -22;
-  if (mode == MODE_WGRAD) return wino_wgrad_ok(d) ? wino_wgrad_workspace_bytes(d) : -22;
-  return wino_workspace_bytes(d);
+  if (mode == MODE_WGRAD) return wino_wgrad_ok(d) ? wino_wgrad_workspace_bytes(d) : wino22_wgrad_ok(d) ? wino22_wgrad_workspace_bytes(d) : -22;
+  return d->KH == 4 ? wino22_workspace_bytes(d) : wino_workspace_bytes(d);
 }
 
 extern "C" int contrad_conv2d_wino_wgrad(const contrad_conv_desc* d, const float* x, const float* gy, float* dwp,
@@ -1891,8 +2035,12 @@ extern "C" int contrad_conv2d_wino_wgrad(const contrad_conv_desc* d, const float
                                          contrad_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
-  CONTRAD_ARG(x && gy && dwp && workspace && wino_wgrad_ok(d));
-  CONTRAD_ARG(aligned16(x, gy, workspace) && workspace_bytes >= wino_wgrad_workspace_bytes(d));
+  CONTRAD_ARG(x && gy && dwp && workspace && aligned16(x, gy, workspace));
+  if (wino22_wgrad_ok(d)) {
+    CONTRAD_ARG(workspace_bytes >= wino22_wgrad_workspace_bytes(d));
+    return launch_wino22_wgrad(d, x, gy, dwp, dbias, workspace, (hipStream_t)stream);
+  }
+  CONTRAD_ARG(wino_wgrad_ok(d) && workspace_bytes >= wino_wgrad_workspace_bytes(d));
   return launch_wino_wgrad(d, x, gy, dwp, dbias, workspace, (hipStream_t)stream);
 }
 
@@ -1902,8 +2050,13 @@ extern "C" int contrad_conv2d_wino(const contrad_conv_desc* d, int mode, const f
   int rc = check_desc(d);
   if (rc) return rc;
   CONTRAD_ARG(in && wp && out && workspace && (mode == MODE_FWD || mode == MODE_DGRAD));
-  CONTRAD_ARG(wino_ok(d, mode) && workspace_bytes >= wino_workspace_bytes(d));
   CONTRAD_ARG(aligned16(in, wp, workspace));
+  if (wino22_ok(d, mode)) {        // 4x4 stride 2: F(2x2, 2x2) on the phases (wino22.h)
+    CONTRAD_ARG(workspace_bytes >= wino22_workspace_bytes(d) && (mode == MODE_FWD || bias == nullptr));
+    if (mode == MODE_FWD) return launch_wino22<MODE_FWD>(d, in, wp, bias, ref, out, slope, gain, workspace, (hipStream_t)stream);
+    return launch_wino22<MODE_DGRAD>(d, in, wp, nullptr, ref, out, slope, gain, workspace, (hipStream_t)stream);
+  }
+  CONTRAD_ARG(wino_ok(d, mode) && workspace_bytes >= wino_workspace_bytes(d));
   if (mode == MODE_FWD) return launch_wino<MODE_FWD>(d, in, wp, bias, ref, out, slope, gain, workspace, (hipStream_t)stream);
   CONTRAD_ARG(bias == nullptr);
   return launch_wino<MODE_DGRAD>(d, in, wp, nullptr, ref, out, slope, gain, workspace, (hipStream_t)stream);
@@ -1930,7 +2083,9 @@ extern "C" int contrad_conv2d_path(const contrad_conv_desc* d, int mode) {
   if (check_desc(d) || mode < 0 || mode > 2) return -22;
   if (mode == MODE_FWD && fwd_k1_ok(d)) return 5;
   if (mode != MODE_WGRAD && wino_planned(d, mode)) return 7;
+  if (mode != MODE_WGRAD && wino22_planned(d, mode)) return 8;
   if (mode == MODE_WGRAD && wino_wgrad_planned(d)) return 7;
+  if (mode == MODE_WGRAD && wino22_wgrad_planned(d)) return 8;
   if (mode != MODE_WGRAD && conv_c32_ok(d)) return 6;
   if (!vec_ok(d, mode)) return 0;
   if (mode == MODE_WGRAD && wgrad_c32_ok(d)) return 4;
@@ -1954,6 +2109,7 @@ extern "C" int contrad_conv2d_path(const contrad_conv_desc* d, int mode) {
 extern "C" double contrad_conv2d_executed_fraction(const contrad_conv_desc* d, int mode) {
   if (check_desc(d) || mode < 0 || mode > 2) return -22.0;
   if (contrad_conv2d_path(d, mode) == 7) return 4.0 / 9.0;   // 16 transform-domain multiply-adds per 2x2 tile instead of 36
+  if (contrad_conv2d_path(d, mode) == 8) return 9.0 / 16.0;  // four phases x 9 per 2x2 tile instead of 64
   if (contrad_conv2d_path(d, mode) != 3) return 1.0;
   return mode == MODE_DGRAD ? dgrad_valid_tap_fraction(d) : fwd_valid_tap_fraction(d);
 }
@@ -1961,6 +2117,10 @@ extern "C" double contrad_conv2d_executed_fraction(const contrad_conv_desc* d, i
 extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int mode, int with_workspace) {
   if (check_desc(d) || mode < 0 || mode > 2) return -22;
   if (mode != MODE_WGRAD && with_workspace && wino_planned(d, mode)) return wino_grid(wino_args(d, mode));   // (512 threads each)
+  if (mode != MODE_WGRAD && with_workspace && wino22_planned(d, mode)) {
+    const wino22::Args a = wino22_args(d, mode);
+    return 8 * std::min(WINO_CUS / 8, cdiv(a.NTB, 8) * a.NKB * (mode == MODE_DGRAD ? 4 : 1));
+  }
   if (mode == MODE_FWD) {
     const FwdPlan p = fwd_plan(d);
     const long long M = (long long)d->N * d->Ho * d->Wo;
@@ -1990,6 +2150,7 @@ extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int 
     return (long long)tm_pad * tiles_n * s * s;
   }
   if (wino_wgrad_planned(d)) { const wino::WArgs a = wino_wgrad_args(d); return (long long)a.CB * a.KB * wino_wgrad_splits(a); }
+  if (wino22_wgrad_planned(d)) { const wino22::WArgs a = wino22_wgrad_args(d); return (long long)a.RBN * a.KB * wino22_wgrad_splits(a); }
   if (wgrad_c32_ok(d)) return wgrad_c32_blocks(d);
   int bm, bn, tm, tn, splits, pps;
   wgrad_plan(d, &bm, &bn, &tm, &tn, &splits, &pps);
@@ -2041,6 +2202,7 @@ extern "C" int contrad_conv2d_tile_order(const contrad_conv_desc* d, int mode, u
 extern "C" long long contrad_conv2d_wgrad_workspace_bytes(const contrad_conv_desc* d) {
   if (check_desc(d)) return -22;
   if (wino_wgrad_planned(d)) return wino_wgrad_workspace_bytes(d);
+  if (wino22_wgrad_planned(d)) return wino22_wgrad_workspace_bytes(d);
   if (wgrad_c32_ok(d))
     return (long long)wgrad_c32_blocks(d) * ((long long)d->KH * d->KW * d->C + 1) * d->K * (long long)sizeof(float);
   int bm, bn, tm, tn, splits, pps;
@@ -2057,6 +2219,7 @@ extern "C" int contrad_conv2d_wgrad(const contrad_conv_desc* d, const float* x, 
   if (vec_ok(d, MODE_WGRAD)) CONTRAD_ARG(aligned16(x, gy, workspace));
   CONTRAD_ARG(workspace_bytes >= contrad_conv2d_wgrad_workspace_bytes(d));
   if (wino_wgrad_planned(d)) return launch_wino_wgrad(d, x, gy, dwp, dbias, workspace, (hipStream_t)stream);   // wino.h, F(3x3, 2x2)
+  if (wino22_wgrad_planned(d)) return launch_wino22_wgrad(d, x, gy, dwp, dbias, workspace, (hipStream_t)stream);   // wino22.h
   if (wgrad_c32_ok(d)) {   // (C = K = 32: vec_ok holds, so the operands were checked for 16-byte alignment above)
     // accumulator-stationary kernel for the 32 -> 32 channel 3x3 layers (wgrad_c32.h): one partial per block, summed
     // by the same fixed-order reduce as the split-K slabs

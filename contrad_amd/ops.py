@@ -88,6 +88,8 @@ def conv_kernel_name(mode, d):
         return 'conv_c32_kernel<%d>' % mode
     if path == 7:
         return 'wino_wgrad_kernel' if mode == 2 else 'wino_kernel<%d>' % mode
+    if path == 8:
+        return 'wino22_wgrad_kernel' if mode == 2 else 'wino22_kernel<%d>' % mode
     if path in (2, 3):
         return 'igemm_lean_kernel<%d, %d, %d>' % (mode, bm.value, bn.value)
     return 'igemm_kernel<%d, %d, %d, %s>' % (mode, bm.value, bn.value, 'true' if path == 1 else 'false')
@@ -180,21 +182,31 @@ def conv2d_dgrad(gy, wp, x_shape, KH, KW, stride, pad, act_ref=None, slope=1.0, 
     return out
 
 
-def conv2d_wino(mode, inp, wp, C, K, bias=None, ref=None, slope=1.0, gain=1.0, out=None):
-    """Winograd F(2x2, 3x3) on ANY shape ``contrad_conv2d_wino_ok`` accepts (conv2d_fwd / conv2d_dgrad pick it by themselves
-    for launches that fill the chip).  mode 0: inp = x (N,H,W,C) -> y (N,H,W,K); mode 1: inp = gy (N,H,W,K) -> dx (N,H,W,C)."""
+def conv2d_wino(mode, inp, wp, C, K, bias=None, ref=None, slope=1.0, gain=1.0, out=None, k4s2=False):
+    """Winograd kernels on ANY shape ``contrad_conv2d_wino_ok`` accepts (conv2d_fwd / conv2d_dgrad pick them by themselves for
+    launches that fill the chip).  3x3 stride 1 pad 1 (F(2x2,3x3), csrc/wino.h) -- mode 0: inp = x (N,H,W,C) -> y (N,H,W,K);
+    mode 1: inp = gy (N,H,W,K) -> dx (N,H,W,C) -- or, ``k4s2``, 4x4 stride 2 pad 1 (F(2x2,2x2) on the four phases,
+    csrc/wino22.h): mode 0: x (N,H,W,C) -> y (N,H/2,W/2,K); mode 1: gy (N,Ho,Wo,K) -> dx (N,2Ho,2Wo,C)."""
     _chk(inp, 'inp'); _chk(wp, 'wp'); _chk(bias, 'bias'); _chk(ref, 'ref')
-    N, H, W, _ = inp.shape
+    N, Hi, Wi, _ = inp.shape
     co = K if mode == 0 else C
+    if k4s2:
+        H, W = (Hi, Wi) if mode == 0 else (2 * Hi, 2 * Wi)          # the conv's input map
+        oshape = (N, H // 2, W // 2, co) if mode == 0 else (N, H, W, co)
+        geo = (4, 4, 2, 1)
+    else:
+        H, W = Hi, Wi
+        oshape = (N, H, W, co)
+        geo = (3, 3, 1, 1)
     if out is None:
-        out = torch.empty((N, H, W, co), device=inp.device, dtype=torch.float32)
+        out = torch.empty(oshape, device=inp.device, dtype=torch.float32)
     _chk(out, 'out')
     if ref is not None and (tuple(ref.shape) != tuple(out.shape) or _ld(ref) != _ld(out)):
         raise RuntimeError('contrad_hip: ref must match the output in shape and leading dimension')
-    d = make_desc(N, H, W, C, K, 3, 3, 1, 1, _ld(inp) if mode == 0 else _ld(out), _ld(out) if mode == 0 else _ld(inp),
-                  wp.stride(0))
+    d = make_desc(N, H, W, C, K, geo[0], geo[1], geo[2], geo[3], _ld(inp) if mode == 0 else _ld(out),
+                  _ld(out) if mode == 0 else _ld(inp), wp.stride(0))
     if lib().raw('contrad_conv2d_wino_ok')(ctypes.byref(d), mode) != 1:
-        raise RuntimeError('contrad_hip: shape not supported by the Winograd kernel')
+        raise RuntimeError('contrad_hip: shape not supported by the Winograd kernels')
     nbytes = lib().raw('contrad_conv2d_wino_workspace_bytes')(ctypes.byref(d), mode)
     ws = _workspace(nbytes, inp.device)
     lib().call('contrad_conv2d_wino', ctypes.byref(d), mode, _p(inp), _p(wp), _p(bias), _p(ref), _p(out),
@@ -203,15 +215,17 @@ def conv2d_wino(mode, inp, wp, C, K, bias=None, ref=None, slope=1.0, gain=1.0, o
 
 
 def conv2d_wino_wgrad(x, gy, ldw=None, out=None, dbias=None):
-    """Weight gradient of a 3x3 stride-1 pad-1 layer on the Winograd kernel F(3x3, 2x2) (forced; conv2d_wgrad picks it by itself
-    when the launch fills the chip).  Returns dwp packed (9 * C, ldw)."""
+    """Weight gradient of a 3x3 stride-1 pad-1 layer (gy as large as x: F(3x3, 2x2), csrc/wino.h) or of a 4x4 stride-2 pad-1
+    layer (gy half as large: F(2x2, 2x2) per input phase, csrc/wino22.h) on the Winograd kernels (forced; conv2d_wgrad picks
+    them by itself when the launch fills the chip).  Returns dwp packed (KH * KW * C, ldw)."""
     _chk(x, 'x'); _chk(gy, 'gy')
     N, H, W, C = x.shape
     K = gy.shape[3]
+    k, st = (3, 1) if gy.shape[1] == H else (4, 2)
     if out is None:
-        out = torch.zeros((9 * C, ldw or round_up(K, 4)), device=x.device, dtype=torch.float32)
+        out = torch.zeros((k * k * C, ldw or round_up(K, 4)), device=x.device, dtype=torch.float32)
     _chk(out, 'out')
-    d = make_desc(N, H, W, C, K, 3, 3, 1, 1, _ld(x), _ld(gy), out.stride(0))
+    d = make_desc(N, H, W, C, K, k, k, st, 1, _ld(x), _ld(gy), out.stride(0))
     if lib().raw('contrad_conv2d_wino_ok')(ctypes.byref(d), 2) != 1:
         raise RuntimeError('contrad_hip: shape not supported by the Winograd weight-gradient kernel')
     nbytes = lib().raw('contrad_conv2d_wino_workspace_bytes')(ctypes.byref(d), 2)

@@ -67,31 +67,36 @@ def test_launch_plans_are_host_logic(built):
             # where at most 0.85 of the tap-positions are valid
             # Round 6: forward and data gradient of the 3x3 stride-1 layers run on the Winograd kernel (path 7, csrc/wino.h; one
             # persistent 512-thread block per CU; the workspace holds the transformed filter)
+            # ... and the 4x4 stride-2 layers on F(2x2, 2x2) over the four input phases (path 8, csrc/wino22.h) -- except the
+            # forward of 256 -> 512 channels: 384 items of 128 tiles x 64 channels are a round and a half of the 256 CUs, where
+            # the direct kernel (pixel-major tiles, padding taps skipped) is faster
             Ho = (H + 2 * p - k) // s + 1
             if k == 3:
                 want = 7           # (the weight gradient too: wino_wgrad_kernel, F(3x3, 2x2), one block per CU over split tile ranges)
-            elif mode == 2:
-                want = 3 if Ho == 4 else 2
+            elif not (mode == 0 and C == 256):
+                want = 8
             else:
-                want = 3 if (mode == 0 or s == 1 or H == 8) else 2
+                want = 3
             assert path(ctypes.byref(d), mode) == want, (H, C, K, mode)
-            if want == 7:
+            if want in (7, 8):
                 assert built.raw('contrad_conv2d_grid_blocks')(ctypes.byref(d), mode, 1) == 256
-                assert abs(built.raw('contrad_conv2d_executed_fraction')(ctypes.byref(d), mode) - 4.0 / 9.0) < 1e-12
+                frac = 4.0 / 9.0 if want == 7 else (9.0 / 16.0 if mode != 2 else 1.0)
+                if mode != 2 or want == 7:
+                    assert abs(built.raw('contrad_conv2d_executed_fraction')(ctypes.byref(d), mode) - frac) < 1e-12
                 assert built.raw('contrad_conv2d_wino_ok')(ctypes.byref(d), mode) == 1
                 continue
             assert tile(ctypes.byref(d), mode, ctypes.byref(bm), ctypes.byref(bn)) == 0
             want_bn = 64 if (mode == 1 and C == 64) else 128        # dgrad's columns are the input channels
             assert (bm.value, bn.value) == (128, want_bn), (H, C, K, mode, bm.value, bn.value)
-        want_ws = 16 * C * K * 4 if k == 3 else 0
-        assert built.raw('contrad_conv2d_fwd_workspace_bytes')(ctypes.byref(d)) == want_ws
+        want_ws = 16 * C * K * 4 if k == 3 else 36 * C * K * 4       # the transformed filter: 16 planes / 4 phases x 9 planes
+        assert built.raw('contrad_conv2d_fwd_workspace_bytes')(ctypes.byref(d)) == (want_ws if not (k == 4 and C == 256) else 0)
         assert built.raw('contrad_conv2d_dgrad_workspace_bytes')(ctypes.byref(d)) == want_ws
-        assert built.raw('contrad_conv2d_wino_workspace_bytes')(ctypes.byref(d), 0) == 16 * C * K * 4
-        if k == 3:      # weight gradient: 256 / (C/64 * K/64) split slabs of the packed gradient + the bias partials
-            splits = 256 // ((C // 64) * (K // 64))
-            assert built.raw('contrad_conv2d_wgrad_workspace_bytes')(ctypes.byref(d)) == splits * (9 * C + 1) * K * 4
-            assert built.raw('contrad_conv2d_wino_workspace_bytes')(ctypes.byref(d), 2) == splits * (9 * C + 1) * K * 4
-            assert built.raw('contrad_conv2d_grid_blocks')(ctypes.byref(d), 2, 1) == 256
+        assert built.raw('contrad_conv2d_wino_workspace_bytes')(ctypes.byref(d), 0) == want_ws
+        # weight gradient: 256 / (row blocks x 64-wide k blocks) split slabs of the packed gradient + the bias partials
+        splits = 256 // ((C // 64) * (K // 64)) if k == 3 else 256 // ((4 * C // 128) * (K // 64))
+        assert built.raw('contrad_conv2d_wgrad_workspace_bytes')(ctypes.byref(d)) == splits * (k * k * C + 1) * K * 4
+        assert built.raw('contrad_conv2d_wino_workspace_bytes')(ctypes.byref(d), 2) == splits * (k * k * C + 1) * K * 4
+        assert built.raw('contrad_conv2d_grid_blocks')(ctypes.byref(d), 2, 1) == 256
     # Cin = 3 / Cout = 1 / 513 channels: general kernel, scalar or float4 gathers
     assert path(ctypes.byref(_desc(8, 32, 3, 64, 3, 1, 1)), 0) == 0
     d1 = _desc(8, 1, 512, 1, 1, 1, 0)                      # the 512 -> 1 logit: its own one-wave-per-row kernel forward,
@@ -120,7 +125,7 @@ def test_launch_plans_are_host_logic(built):
     assert wok(ctypes.byref(_desc(8, 16, 24, 64, 3, 1, 1)), 0) == 0 and wok(ctypes.byref(_desc(8, 16, 32, 48, 3, 1, 1)), 0) == 0
     assert wok(ctypes.byref(_desc(8, 16, 32, 48, 3, 1, 1)), 1) == 0 and wok(ctypes.byref(_desc(8, 16, 64, 48, 3, 1, 1)), 1) == 1
     assert wok(ctypes.byref(_desc(8, 12, 32, 64, 3, 1, 1)), 0) == 0 and wok(ctypes.byref(_desc(8, 16, 32, 64, 3, 2, 1)), 0) == 0
-    assert built.raw('contrad_conv2d_dgrad_workspace_bytes')(ctypes.byref(_desc(192, 8, 256, 512, 4, 2, 1))) == 0   # strided
+    assert built.raw('contrad_conv2d_dgrad_workspace_bytes')(ctypes.byref(_desc(192, 8, 260, 512, 4, 2, 1))) == 0   # strided (not F(2x2,2x2): Cin)
     # contrastive column splits: ~256 blocks
     assert built.raw('contrad_contrast_workspace_bytes')(1024, 128) == 16 * 1024 * 128 * 4
 
@@ -148,7 +153,7 @@ def test_padding_skipping_tile_plans_without_gpu(built):
     seen = set()
     # (the 3x3 stride-1 layers with channel counts the Winograd kernel does not take -- it needs output channels % 64 --: the
     # direct kernels and their padding-skipping tiles serve them as they served 128 / 256 / 512 channels until round 5)
-    nowino = [(H, C - 32, K - 32, k, s, p) if k == 3 else (H, C, K, k, s, p) for (H, C, K, k, s, p) in _SNDCGAN]
+    nowino = [(H, C - 32, K - 32, k, s, p) for (H, C, K, k, s, p) in _SNDCGAN]
     for (H, C, K, k, s, p) in nowino:
         d = _desc(N, H, C, K, k, s, p)
         Ho = (H + 2 * p - k) // s + 1

@@ -74,6 +74,78 @@ def test_wino_data_gradient(case):
     assert rel(dx.cpu(), ref * torch.where(act > 0, 1.5, 0.3)) < TIGHT
 
 
+# 4x4 stride-2 pad-1 layers on F(2x2, 2x2) over the four phases (csrc/wino22.h): (N, H, W, C, K), H / 2 and W / 2 in {4, 8, 16}
+S2CASES = [
+    (3, 32, 32, 8, 64),        # 16 x 16 output grid: 2 images per block, ragged; one chunk per phase
+    (9, 16, 16, 16, 128),      # 8 x 8 grid: 8 images per block, ragged; two cout blocks
+    (40, 8, 8, 32, 64),        # 4 x 4 grid: 32 images per block, ragged
+    (2, 32, 16, 24, 64),       # non-square 16 x 8 grid (4 images per block); Cin = 24: three chunks per phase
+    (70, 8, 8, 16, 192),       # several items per block, three cout blocks
+]
+
+
+@pytest.mark.parametrize('case', S2CASES)
+def test_wino22_forward(case):
+    N, H, W, C, K = case
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(N, H, W, C, generator=g)
+    w = torch.randn(K, C, 4, 4, generator=g) * 0.1
+    b = torch.randn(K, generator=g)
+    add = torch.randn(N, H // 2, W // 2, K, generator=g)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, stride=2, padding=1).permute(0, 2, 3, 1)
+    dev = torch.device('cuda')
+    wp = ops.pack_weight(w).to(dev)
+    y = ops.conv2d_wino(0, x.to(dev), wp, C, K, bias=b.to(dev), slope=0.1, gain=1.2, k4s2=True)
+    assert rel(y.cpu(), F.leaky_relu(ref, 0.1) * 1.2) < TIGHT
+    y = ops.conv2d_wino(0, x.to(dev), wp, C, K, ref=add.to(dev), k4s2=True)
+    assert rel(y.cpu(), F.conv2d(x.permute(0, 3, 1, 2), w, None, stride=2, padding=1).permute(0, 2, 3, 1) + add) < TIGHT
+
+
+@pytest.mark.parametrize('case', S2CASES)
+def test_wino22_data_gradient(case):
+    N, H, W, K, C = case           # (roles swapped: gy has K channels -- a multiple of 16 --, dx has C -- a multiple of 64)
+    if K % 16:
+        K = 16
+    g = torch.Generator().manual_seed(22)
+    gy = torch.randn(N, H // 2, W // 2, K, generator=g)
+    w = torch.randn(K, C, 4, 4, generator=g) * 0.1
+    act = torch.randn(N, H, W, C, generator=g)
+    ref = F.conv_transpose2d(gy.permute(0, 3, 1, 2), w, stride=2, padding=1).permute(0, 2, 3, 1)
+    dev = torch.device('cuda')
+    wp = ops.pack_weight(w).to(dev)
+    dx = ops.conv2d_wino(1, gy.to(dev), wp, C, K, k4s2=True)
+    assert rel(dx.cpu(), ref) < TIGHT
+    dx = ops.conv2d_wino(1, gy.to(dev), wp, C, K, ref=act.to(dev), slope=0.1, gain=1.0, k4s2=True)
+    assert rel(dx.cpu(), ref * torch.where(act > 0, 1.0, 0.1)) < TIGHT
+
+
+# weight gradient of the 4x4 stride-2 layers: (N, H, W, C, K), C = 64 or a multiple of 128, K a multiple of 64
+S2WCASES = [
+    (3, 32, 32, 64, 64),       # 16 x 16 grid: chunks of 2 x 4 tiles, boxes 5 x 9; C = 64: two phases per row block
+    (5, 16, 16, 128, 128),     # 8 x 8 grid (full-width chunks); C = 128: one phase per row block, two k-blocks
+    (19, 8, 8, 256, 64),       # 4 x 4 grid: 2 images per chunk, ragged last chunk; two row blocks per phase
+    (2, 32, 16, 64, 64),       # non-square 16 x 8 grid
+    (130, 16, 16, 64, 64),     # many chunks, several splits with odd chunk counts
+]
+
+
+@pytest.mark.parametrize('case', S2WCASES)
+def test_wino22_weight_gradient(case):
+    N, H, W, C, K = case
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(N, H, W, C, generator=g)
+    gy = torch.randn(N, H // 2, W // 2, K, generator=g)
+    w0 = torch.zeros(K, C, 4, 4, requires_grad=True)
+    b0 = torch.zeros(K, requires_grad=True)
+    F.conv2d(x.permute(0, 3, 1, 2), w0, b0, stride=2, padding=1).backward(gy.permute(0, 3, 1, 2))
+    dev = torch.device('cuda')
+    dbias = torch.empty(K, device=dev)
+    dwp = ops.conv2d_wino_wgrad(x.to(dev), gy.to(dev), dbias=dbias)
+    assert rel(ops.unpack_weight(dwp, K, C, 4, 4).cpu(), w0.grad) < TIGHT
+    assert rel(dbias.cpu(), b0.grad) < TIGHT
+    assert torch.equal(dwp, ops.conv2d_wino_wgrad(x.to(dev), gy.to(dev)))
+
+
 # (N, H, W, C, K): C and K multiples of 64
 WCASES = [
     (3, 16, 16, 64, 64),       # chunks of 2 x 4 tiles: 4 x 2 chunks per image, boxes of 6 x 10 pixels with halo
