@@ -803,7 +803,8 @@ __device__ __forceinline__ void lean_tile(const IgemmArgs& p, float* smem, const
         }
       }
     };
-    if (st_nt) store_rows(std::true_type{}); else store_rows(std::false_type{});
+    // (split-K slabs of the stride-1 data gradient stay plain, like the forward's: the reduce reads them back at once)
+    if (st_nt && !(MODE == MODE_DGRAD && pl_dsplits > 1)) store_rows(std::true_type{}); else store_rows(std::false_type{});
   } else {
     const bool slab = (MODE == MODE_WGRAD) || p.ny > 1;              // split-K partial slab [split][M][Ncol]
     const bool pxm = (MODE == MODE_FWD) && pl_pixmajor;               // rows = images at one pixel: pitch = one image of y

@@ -251,12 +251,23 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
   // iteration g (chunk t of the current item): MFMAs on stage g & 1;  transform waves: raw (g + 1) -> V stage (g+1)&1;
   //   movers: raw (g + 2) registers -> raw stage g & 1, raw (g + 3) into flight, U (g + 1) registers -> U stage (g+1)&1,
   //   U (g + 2) into flight
+  // The chunk's barrier sits BEFORE the MFMAs of its last plane, and the first plane's fragments of the NEXT chunk are fetched
+  // right behind it (every read of this stage has been issued by then: the last plane's fragments are in registers, and
+  // every write of the next stage is done by slot 6) -- so the LDS latency after the barrier hides behind four MFMAs per
+  // wave instead of leaving the matrix pipe empty (WINO_EARLY_BARRIER=0: the barrier at the end of the chunk, round-6 A/B).
+#ifndef WINO_EARLY_BARRIER
+#define WINO_EARLY_BARRIER 1
+#endif
+  float4 fa[2], fb[2];
+  fa[0] = *reinterpret_cast<const float4*>(smem + rdA);
+  fb[0] = *reinterpret_cast<const float4*>(smem + rdB);
   auto chunk = [&](auto par) {
     constexpr int P = decltype(par)::value;
     constexpr int cur = P * BUF, nxt = BUF - cur;
-    float4 fa[2], fb[2];
+#if !WINO_EARLY_BARRIER
     fa[0] = *reinterpret_cast<const float4*>(smem + cur + rdA);
     fb[0] = *reinterpret_cast<const float4*>(smem + cur + rdB);
+#endif
 #pragma unroll
     for (int xi = 0; xi < 8; ++xi) {
       if (xi + 1 < 8) {
@@ -275,6 +286,13 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
         if (xi >= 3 && xi < 7) { load_u(2 * (xi - 3)); load_u(2 * (xi - 3) + 1); }
         if (xi == 6) step_u();
       }
+#if WINO_EARLY_BARRIER
+      if (xi == 7) {
+        __syncthreads();
+        fa[0] = *reinterpret_cast<const float4*>(smem + nxt + rdA);
+        fb[0] = *reinterpret_cast<const float4*>(smem + nxt + rdB);
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
       const float* a = (const float*)&fa[xi & 1];
       const float* b = (const float*)&fb[xi & 1];
@@ -282,7 +300,9 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
       for (int j = 0; j < 4; ++j) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[xi], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+#if !WINO_EARLY_BARRIER
     __syncthreads();
+#endif
   };
 
   // exchange area (stage 1 is the free one at an item's end): [sub-block][16 rows][lane] float4 = 64 KB

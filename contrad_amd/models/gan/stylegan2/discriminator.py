@@ -406,7 +406,8 @@ class ResidualDiscriminatorP(BaseDiscriminator):
         neither the per-call split nor the concatenation, forward or backward."""
         self._batch_splits = [int(n) for n in sizes]
         try:
-            assert sum(self._batch_splits) == x.shape[0]
+            if sum(self._batch_splits) != x.shape[0]:      # (not an assert: a wrong split silently mis-segments the minibatch stddev)
+                raise ValueError('call_merged: sizes %r do not add up to the %d rows of x' % (self._batch_splits, x.shape[0]))
             return self(x, **flags)
         finally:
             self._batch_splits = None

@@ -420,8 +420,15 @@ class Generator(nn.Module):
         return x
 
     def _style(self, mc, w_lat, c):
-        gi, bias = c['mod'][mc]
         B = w_lat.shape[0]
+        if mc not in c['mod']:
+            # forward-only cache (_prepare_forward_only): the modulation linears exist only side by side in ONE matrix; a
+            # caller that did not take its style from _all_styles gets this layer's columns of the full product
+            off, n = c['mod_cols'][mc]
+            wp = c['packed'][c['mod_all']]
+            full = ops.conv2d_fwd(w_lat.contiguous().view(B, 1, 1, -1), wp, c['mod_bias_all'], wp.shape[1], 1, 1, 1, 0)
+            return full.view(B, -1)[:, off:off + n].contiguous()
+        gi, bias = c['mod'][mc]
         if c['differentiable']:
             return A.ConvBiasActFn.apply(w_lat.contiguous().view(B, 1, 1, -1), c['packed'][gi], bias,
                                          (mc.in_channel, 1, 1, 1, 0), 1.0, 1.0).view(B, mc.in_channel)

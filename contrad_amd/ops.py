@@ -548,6 +548,13 @@ def axpby_(y, x, a, b):
 # --------------------------------------------------------------------------------------------------
 # augmentation
 # --------------------------------------------------------------------------------------------------
+def _chk_out(out, like, name):
+    """A caller-provided output buffer: same shape, fp32, on the device, dense (the kernels write it with flat indices)."""
+    _chk(out, 'out')
+    if tuple(out.shape) != tuple(like.shape) or not out.is_contiguous() or out.device != like.device:
+        raise RuntimeError('contrad_hip: %s: out must be a contiguous tensor of shape %s on %s' % (name, tuple(like.shape), like.device))
+
+
 def simclr_augment(x, params, contrast_first, has_contrast, out=None):
     """x NCHW (B,3,H,W); params (B, AUG_NPARAM) on the same device."""
     _chk(x, 'x'); _chk(params, 'params')
@@ -558,6 +565,7 @@ def simclr_augment(x, params, contrast_first, has_contrast, out=None):
         raise RuntimeError('contrad_hip: simclr_augment is defined for RGB images')
     if out is None:
         out = torch.empty_like(x)
+    _chk_out(out, x, 'simclr_augment')
     nbytes = lib().raw('contrad_simclr_workspace_bytes')(B, H, W)
     ws = _workspace(nbytes, x.device)
     lib().call('contrad_simclr_augment', _p(x), _p(out), _p(params), B, H, W, int(contrast_first), int(has_contrast),
@@ -566,10 +574,14 @@ def simclr_augment(x, params, contrast_first, has_contrast, out=None):
 
 
 def gaussian_blur_masked(x, params, kernel1d, radius, out=None):
+    _chk(x, 'x'); _chk(params, 'params'); _chk(kernel1d, 'kernel1d')
+    if not x.is_contiguous():
+        raise RuntimeError('contrad_hip: gaussian_blur_masked needs a contiguous NCHW input')
     B, C, H, W = x.shape
     tmp = torch.empty_like(x)
     if out is None:
         out = torch.empty_like(x)
+    _chk_out(out, x, 'gaussian_blur_masked')
     lib().call('contrad_gaussian_blur_masked', _p(x), _p(tmp), _p(out), _p(params), _p(kernel1d), B, H, W,
                int(radius), _stream())
     return out
@@ -765,6 +777,16 @@ def upfirdn2d_modconv(x, kernel, pad, demod, noise, noise_w, bias, post_scale=No
         raise RuntimeError('contrad_hip: upfirdn2d_modconv needs a dense NHWC input and the 4x4 FIR')
     N, H, W, K = x.shape
     oh, ow = H + pad[2] + pad[3] - 4 + 1, W + pad[0] + pad[1] - 4 + 1
+    # the kernel reads demod / post_scale as float4 at [N][K], bias at [K], noise at [N][oh][ow]: wrong sizes read out of bounds
+    for t, nm, shape in ((demod, 'demod', (N, K)), (post_scale, 'post_scale', (N, K)), (bias, 'bias', (K,)),
+                         (noise, 'noise', (N, 1, oh, ow))):
+        if t is None:
+            continue
+        _chk(t, nm)
+        if t.numel() != int(torch.Size(shape).numel()) or not t.is_contiguous():
+            raise RuntimeError('contrad_hip: upfirdn2d_modconv: %s must be a contiguous tensor of %s elements' % (nm, shape))
+    if K % 4:
+        raise RuntimeError('contrad_hip: upfirdn2d_modconv needs a channel count that is a multiple of 4')
     out = torch.empty(N, oh, ow, K, device=x.device, dtype=torch.float32)
     lib().call('contrad_upfirdn2d_modconv', _p(x), _p(kernel), _p(out), N, H, W, K, int(pad[0]), int(pad[1]), int(pad[2]),
                int(pad[3]), _p(demod), _p(noise), _p(noise_w), _p(bias), _p(post_scale), _stream())

@@ -423,6 +423,31 @@ def test_call_batches_equals_separate_calls():
         assert l2(p.grad, q.grad) < 1e-4, (k, l2(p.grad, q.grad))
 
 
+def test_call_merged_equals_call_batches_bit_for_bit():
+    """ResidualDiscriminatorP.call_merged (the product path of the StyleGAN2 ContraD step: real views and fakes already side
+    by side in one buffer) is call_batches without the split and the concatenation: logits, both projections and every
+    parameter gradient bitwise equal; a wrong split is an error, not a silently mis-segmented minibatch stddev."""
+    import copy
+    torch.manual_seed(6)
+    D = ResidualDiscriminatorP(32, small32=True).to(DEV).train()
+    D2 = copy.deepcopy(D)
+    a, b = torch.rand(8, 3, 32, 32, device=DEV), torch.rand(4, 3, 32, 32, device=DEV)
+    flags = dict(sg_linear=True, projection=True, projection2=True)
+    lm, xm = D.call_merged(torch.cat([a, b]), [8, 4], **flags)
+    (la, xa), (lb, xb) = D2.call_batches([a, b], **flags)
+    assert torch.equal(lm, torch.cat([la, lb]))
+    for k in ('projection', 'projection2'):
+        assert torch.equal(xm[k], torch.cat([xa[k], xb[k]]))
+    w = torch.randn(12, 1, device=DEV)
+    ((lm * w).sum() + xm['projection'].pow(2).sum() + xm['projection2'].sin().sum()).backward()
+    ((torch.cat([la, lb]) * w).sum() + torch.cat([xa['projection'], xb['projection']]).pow(2).sum() +
+     torch.cat([xa['projection2'], xb['projection2']]).sin().sum()).backward()
+    for (k, p), q in zip(D.named_parameters(), D2.parameters()):
+        assert torch.equal(p.grad, q.grad), k
+    with pytest.raises(ValueError):
+        D.call_merged(torch.cat([a, b]), [8, 8], **flags)
+
+
 @pytest.mark.parametrize('size,small32,N', [(32, True, 8), (64, False, 4)])
 def test_fused_r1_trunk_equals_the_node_family(size, small32, N):
     """_TrunkR1Fn / _TrunkVJPFn (round 3: the R1 call and the generator step on two fused nodes -- the trunk's backward
