@@ -869,7 +869,11 @@ bool wino_planned(const contrad_conv_desc* d, int mode) {
   if (!enabled || !wino_ok(d, mode)) return false;
   const long long items = wino_items(d, mode);
   const long long rounds = cdivll(items, WINO_CUS);
-  return items >= 200 && rounds * WINO_CUS * 10 <= items * 14;
+  static const long long min_items = []() { const char* e = contrad_dev_env("CONTRAD_WINO_MIN_ITEMS"); return e ? atoll(e) : 150ll; }();
+  // (a single partial round: from 150 items.  Per-rank batches of the headline config on one GPU, profiles/r06_ab_plan_thresholds.txt:
+  // 200 / 150 / 90 items -> 3.12 / 2.82 / 2.89 ms per step at batch 64, 4.39 / 4.25 / 4.24 at batch 128)
+  if (items < WINO_CUS) return items >= min_items;
+  return rounds * WINO_CUS * 10 <= items * 14;
 }
 
 long long wino_workspace_bytes(const contrad_conv_desc* d) { return 16ll * d->C * d->K * (long long)sizeof(float); }
@@ -926,7 +930,9 @@ bool wino22_planned(const contrad_conv_desc* d, int mode) {
   const long long rounds = cdivll(items, WINO_CUS);
   // (1.78x fewer multiply-adds, not 2.25x: a last round that is a quarter empty already loses to the direct kernels -- forward of
   // 256 -> 512 channels at 1536 images, 384 items: 0.622 ms against 0.558, profiles/r06_ab_wino22_layers.txt)
-  return items >= 200 && rounds * WINO_CUS * 100 <= items * 125;
+  static const long long min_items = []() { const char* e = contrad_dev_env("CONTRAD_WINO22_MIN_ITEMS"); return e ? atoll(e) : 150ll; }();
+  if (items < WINO_CUS) return items >= min_items;
+  return rounds * WINO_CUS * 100 <= items * 125;
 }
 
 long long wino22_workspace_bytes(const contrad_conv_desc* d) { return 4ll * 9 * d->C * d->K * (long long)sizeof(float); }
@@ -982,7 +988,8 @@ bool wino22_wgrad_planned(const contrad_conv_desc* d) {
   if (!enabled || !enabled2 || !wino22_wgrad_ok(d)) return false;
   const wino22::WArgs a = wino22_wgrad_args(d);
   const long long blocks = (long long)a.RBN * a.KB * wino22_wgrad_splits(a);
-  return a.qps >= 48 && blocks * 10 >= WINO_CUS * 7 && blocks <= WINO_CUS;
+  static const int min_qps = []() { const char* e = contrad_dev_env("CONTRAD_WINO_MIN_QPS"); return e ? atoi(e) : 16; }();
+  return a.qps >= min_qps && blocks * 10 >= WINO_CUS * 7 && blocks <= WINO_CUS;
 }
 
 long long wino22_wgrad_workspace_bytes(const contrad_conv_desc* d) {
@@ -1025,7 +1032,8 @@ bool wino_wgrad_planned(const contrad_conv_desc* d) {
   if (!enabled || !enabled2 || !wino_wgrad_ok(d)) return false;
   const wino::WArgs a = wino_wgrad_args(d);
   const long long blocks = (long long)a.CB * a.KB * wino_wgrad_splits(a);
-  return a.qps >= 48 && blocks * 10 >= WINO_CUS * 7 && blocks <= WINO_CUS;
+  static const int min_qps = []() { const char* e = contrad_dev_env("CONTRAD_WINO_MIN_QPS"); return e ? atoi(e) : 16; }();
+  return a.qps >= min_qps && blocks * 10 >= WINO_CUS * 7 && blocks <= WINO_CUS;
 }
 
 long long wino_wgrad_workspace_bytes(const contrad_conv_desc* d) {

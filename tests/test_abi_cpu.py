@@ -187,9 +187,11 @@ def test_padding_skipping_tile_plans_without_gpu(built):
             assert blocks(ctypes.byref(d), mode, 1) == want, (H, k, mode, want)
     assert seen == {'pixel-major', 'border classes', 'strided pixel-major'}
     # too few images for a tile of the smallest class on every XCD: image-major tiles, everything issued
-    d = _desc(192, 8, 256, 256, 3, 1, 1)        # (192 Winograd items: below the plan's threshold too)
+    d = _desc(192, 8, 256, 224, 3, 1, 1)        # (224 output channels: not a Winograd shape)
     assert path(ctypes.byref(d), 0) == 2 and frac(ctypes.byref(d), 0) == 1.0
     assert path(ctypes.byref(d), 2) == 3 and abs(frac(ctypes.byref(d), 2) - 484.0 / 576.0) < 1e-12   # (WGRAD: pixel-major positions)
+    # one rank of the 8-GPU headline config (3N = 192 images): Winograd from 150 items of a single round (0.59 of the CUs)
+    assert path(ctypes.byref(_desc(192, 8, 256, 256, 3, 1, 1)), 0) == 7 and path(ctypes.byref(_desc(192, 8, 256, 256, 3, 1, 1)), 2) == 7
 
 
 def test_shipped_library_reads_no_environment(built):
