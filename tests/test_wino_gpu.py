@@ -192,6 +192,34 @@ def test_wino_channel_sliced_views():
     assert (yb[..., :8] == -3.0).all() and (yb[..., 8 + K:] == -3.0).all()      # nothing outside the slice is written
 
 
+def test_strided_and_gradient_kernels_on_channel_sliced_views():
+    """The same for the 4x4 stride-2 kernel (forward and data gradient) and for both weight-gradient kernels: every operand a
+    channel slice of a wider buffer."""
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(31)
+    N, H, C, K = 5, 16, 64, 64
+    x = torch.randn(N, H, H, C, generator=g)
+    w4 = torch.randn(K, C, 4, 4, generator=g) * 0.1
+    xb = torch.full((N, H, H, C + 12), 5.0, device=dev); xb[..., 8:8 + C] = x.to(dev)
+    yb = torch.full((N, H // 2, H // 2, K + 4), -2.0, device=dev)
+    ops.conv2d_wino(0, xb[..., 8:8 + C], ops.pack_weight(w4).to(dev), C, K, out=yb[..., 4:4 + K], k4s2=True)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w4, None, stride=2, padding=1).permute(0, 2, 3, 1)
+    assert rel(yb[..., 4:4 + K].cpu(), ref) < TIGHT and (yb[..., :4] == -2.0).all()
+    gy = torch.randn(N, H // 2, H // 2, K, generator=g)
+    gb = torch.full((N, H // 2, H // 2, K + 8), 3.0, device=dev); gb[..., :K] = gy.to(dev)
+    dxb = torch.full((N, H, H, C + 4), -1.0, device=dev)
+    ops.conv2d_wino(1, gb[..., :K], ops.pack_weight(w4).to(dev), C, K, out=dxb[..., :C], k4s2=True)
+    refd = F.conv_transpose2d(gy.permute(0, 3, 1, 2), w4, stride=2, padding=1).permute(0, 2, 3, 1)
+    assert rel(dxb[..., :C].cpu(), refd) < TIGHT and (dxb[..., C:] == -1.0).all()
+    # weight gradients: 4x4 stride 2 (gy half the size) and 3x3 stride 1 (gy as large as x)
+    for k, st, gyt in ((4, 2, gy), (3, 1, torch.randn(N, H, H, K, generator=g))):
+        w0 = torch.zeros(K, C, k, k, requires_grad=True)
+        F.conv2d(x.permute(0, 3, 1, 2), w0, None, stride=st, padding=1).backward(gyt.permute(0, 3, 1, 2))
+        gb2 = torch.full(tuple(gyt.shape[:3]) + (K + 8,), 3.0, device=dev); gb2[..., 4:4 + K] = gyt.to(dev)
+        dwp = ops.conv2d_wino_wgrad(xb[..., 8:8 + C], gb2[..., 4:4 + K])
+        assert rel(ops.unpack_weight(dwp, K, C, k, k).cpu(), w0.grad) < TIGHT
+
+
 def test_wino_is_deterministic_and_batch_independent():
     N, H, W, C, K = 24, 8, 8, 32, 64
     x, w, b = _inputs(N, H, W, C, K, 7)
