@@ -24,6 +24,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import re
 import os
 import socket
 import subprocess
@@ -257,7 +258,7 @@ def _pmc_traffic(config, kernel):
                 # the engine names an instance by its first three
                 want = kernel.replace(' ', '')
                 for k, v in pmc.get('kernels', {}).items():
-                    kk = k.replace(' ', '').replace('(anonymousnamespace)::', '').replace('wino::', '')
+                    kk = re.sub(r'wino(22)?::', '', k.replace(' ', '').replace('(anonymousnamespace)::', ''))
                     if kk == want or kk == want[:-1] + ',false>':
                         ent = v
                         break
