@@ -335,8 +335,8 @@ static double run_case(int N, int H, int C, int K, int reps) {
   unsigned s = 12345u;
   auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xFFFF) / 65536.f - 0.5f; };
   for (auto& v : hx) v = g_normal ? (rnd() + rnd() + rnd() + rnd() + rnd() + rnd() + rnd() + rnd() + rnd() + rnd() + rnd() + rnd()) * 1.0f * 3.4641f / 3.4641f * 1.0f : rnd();
-  if (g_normal) for (auto& v : hx) v *= 1.0f;
   for (auto& v : hw) v = rnd() * 0.1f;
+  if (g_normal == 2) { for (auto& v : hx) v = 0.f; for (auto& v : hw) v = 0.f; }
   make_U(hw, C, K, hU);
   float *dx, *dU, *dy;
   (void)hipMalloc(&dx, nx * 4); (void)hipMalloc(&dU, hU.size() * 4); (void)hipMalloc(&dy, ny * 4);
@@ -388,6 +388,7 @@ static double run_case(int N, int H, int C, int K, int reps) {
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 20;
   if (argc > 2 && argv[2][0] == 'n') g_normal = 1;
+  else if (argc > 2 && argv[2][0] == 'z') g_normal = 2;      // all-zero x and weights: the chip's clock under the same instruction stream without data toggling
   else if (argc > 2) { run_case(48, 128, 128, 128, reps); return 0; }   // one shape (counter runs)
 #ifdef ABL_ANY
   run_case(1536, 16, 128, 128, reps); run_case(48, 128, 128, 128, reps); return 0;
