@@ -326,7 +326,8 @@ def _csrc_fingerprint():
     return h.hexdigest()[:16]
 
 
-def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=None, graph=None, eager_line=None):
+def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=None, graph=None, eager_line=None,
+               overlap=None):
     from contrad_amd import config, ops
     from contrad_amd.augment import get_augment
     from contrad_amd.engine import (GradAllReducer, OverlappedGradReducer, d_step, d_step_stylegan2,
@@ -370,7 +371,9 @@ def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=
         from contrad_amd.engine import setup_grad_exchange
         # per-layer collectives hidden behind the backward (D_SNDCGAN: everything; ResidualDiscriminatorP: the packed
         # weight gradients, the biases in one packed collective afterwards); CONTRAD_NO_OVERLAP: flat collectives after it
-        reducer = setup_grad_exchange(D, overlap=not os.environ.get('CONTRAD_NO_OVERLAP'))
+        if overlap is None:
+            overlap = not os.environ.get('CONTRAD_NO_OVERLAP')
+        reducer = setup_grad_exchange(D, overlap=overlap)
     set_grad(G, False); set_grad(D, True)
     images = torch.rand(n_local, 3, size, size, device=dev)     # synthetic batch, resident in HBM
 
@@ -533,6 +536,8 @@ def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=
                           "global_batch": global_batch, "per_gpu_batch": n_local,
                           "parallelism": "dp%d" % world, "losses_finite": finite,
                           "launch": launch,
+                          "grad_exchange": None if not multi else ("overlapped with the backward (per-layer collectives)" if overlap
+                                                                   else "after the backward (flat collectives)"),
                           "rccl_ranks": dist.get_world_size() if multi else 1,
                           "backend": dist.get_backend() if multi else None,
                           "peak_hbm_gib": round((peak_box[0] or torch.cuda.max_memory_allocated(dev)) / 2 ** 30, 2)},
@@ -722,6 +727,11 @@ def main():
     ap.add_argument('--graph-timeout', type=float, default=240.0,
                     help='N > 1: seconds a workload may spend on capturing its step and timing the replay (every workload has '
                          'been timed eagerly before); past that every rank stops and rank 0 prints the line with the eager results')
+    ap.add_argument('--exchange', default='auto', choices=['auto', 'overlap', 'serial'],
+                    help="N > 1: the gradient exchange overlapped with the backward (per-layer collectives on RCCL's stream), after it "
+                         "(flat collectives), or -- auto -- whichever of the two EAGER measurements is faster for the workload: "
+                         "the Winograd kernels' blocks need whole CUs, and what a concurrent RCCL ring costs them has never been "
+                         "measured on hardware (DESIGN.md section 6)")
     ap.add_argument('--dev-backend', default='nccl', choices=['nccl', 'gloo'],
                     help="dev: process-group backend.  'gloo' lets several ranks share ONE GPU (RCCL refuses that), so the "
                          "self-launch, the barriers, the MAX over ranks and the fallback order can be exercised on a 1-GPU box")
@@ -808,15 +818,35 @@ def main():
         except Exception as e:
             return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}, True
 
+    chosen = {}                                  # workload -> gradient exchange overlapped with the backward?
+    fixed = {'overlap': True, 'serial': False}.get(args.exchange) if world > 1 else None
     for i, name in enumerate(names):
-        results[name], _ok = guarded(name, i == 0, graph='off' if two_phase else None)
+        results[name], _ok = guarded(name, i == 0, graph='off' if two_phase else None, overlap=fixed)
+        chosen[name] = fixed
+        if world > 1 and args.exchange == 'auto':
+            # the same workload once more, eagerly, with the exchange after the backward: keep the faster of the two lines
+            # (every rank must take the same decision: rank 0 decides, the others are told)
+            alt, _ok2 = guarded(name, False, graph='off', overlap=False)
+            pick = torch.zeros(1, device=dev)
+            if rank == 0:
+                a, b = results[name] or {}, alt or {}
+                if 'ms_per_step' in b and ('ms_per_step' not in a or b['ms_per_step'] < 0.97 * a['ms_per_step']):
+                    pick.fill_(1.0)
+            dist.broadcast(pick, 0)
+            serial = bool(pick.item() > 0.5)
+            if rank == 0 and 'ms_per_step' in (results[name] or {}) and 'ms_per_step' in (alt or {}):
+                both = {"overlapped": results[name]['ms_per_step'], "after_the_backward": alt['ms_per_step']}
+                if serial:
+                    results[name] = alt
+                results[name]["config"]["eager_ms_per_step_by_exchange"] = both
+            chosen[name] = (not serial)
     if two_phase:
         for i, name in enumerate(names):
             if rank == 0 and "error" in (results[name] or {}):
                 continue
             try:
                 out, ok = run_config(name, args, world, rank, dev, multi, wd.keep, wd.arm, wd.disarm, graph='on',
-                                     eager_line=results[name])
+                                     eager_line=results[name], overlap=chosen.get(name))
             except Exception as e:               # (anything else that goes wrong in the graph phase: keep the eager lines)
                 sys.stderr.write('bench.py: graph phase of %s failed (%r); keeping the eager lines\n' % (name, e))
                 break

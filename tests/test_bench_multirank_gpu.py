@@ -13,11 +13,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra, env_extra=None, timeout=600, config='c10_b512'):
+def _run(extra, env_extra=None, timeout=600, config='c10_b512', exchange='overlap'):
     env = dict(os.environ)
     env.update(env_extra or {})
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dev-backend', 'gloo', '--config', config,
-           '--steps', '2', '--warmup', '1', '--no-cpu-baseline'] + extra
+           '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--exchange', exchange] + extra
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     return r, lines
@@ -34,6 +34,22 @@ def test_two_gloo_ranks_eager_line():
     assert out['config']['losses_finite'] and out['value'] > 0
     assert abs(out['value'] - 512 * 2 / (out['ms_per_step'] * 2e-3)) < 1e-2 * out['value']
     assert out['roofline']['kernel'] and 'cpu_baseline' not in out
+
+
+def test_two_gloo_ranks_pick_the_faster_gradient_exchange():
+    """--exchange auto (the default with several ranks, round 6): every workload is timed eagerly with the exchange overlapped
+    with the backward AND after it; every rank takes rank 0's decision; the line says which one it carries and shows both."""
+    r, lines = _run(['--graph', 'off'], exchange='auto')
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    both = out['config']['eager_ms_per_step_by_exchange']
+    assert set(both) == {'overlapped', 'after_the_backward'} and min(both.values()) > 0
+    picked_serial = out['config']['grad_exchange'].startswith('after')
+    assert abs(out['ms_per_step'] - (both['after_the_backward'] if picked_serial else both['overlapped'])) < 1e-6
+    if picked_serial:
+        assert both['after_the_backward'] < 0.97 * both['overlapped']
+    assert out['config']['losses_finite'] and out['n_gpus'] == 2
 
 
 def test_graph_capture_that_never_returns_reports_the_eager_result():
