@@ -218,6 +218,50 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, float* smem) {
   // iteration g (chunk t of the current item): MFMAs on stage g & 1;  transform waves: raw (g + 1) -> V stage (g+1)&1;
   //   movers: raw (g + 2) registers -> raw stage g & 1, raw (g + 3) into flight, U (g + 1) registers -> U stage (g+1)&1,
   //   U (g + 2) into flight
+#ifdef WAVE_REUSE
+  // TIMING EXPERIMENT (results are wrong: the epilogue still assumes the (sub-block, xi half) layout): wave = (xi quarter,
+  // cout half) with BOTH tile groups -- the B fragment of a plane feeds two MFMA tiles: 12 fragment reads per chunk, not 16
+  auto chunk = [&](auto par) {
+    constexpr int P = decltype(par)::value;
+    constexpr int cur = P * BUF, nxt = BUF - cur;
+    const int w8 = (ROLE * 4 + wave), q = w8 >> 1, cn = w8 & 1;
+    const int ra0 = q * 4 * PL + lhi * KQS + l31 * 4, ra1 = ra0 + 32 * 4;
+    const int rb = V_SZ + q * 4 * PL + lhi * KQS + (cn * 32 + l31) * 4;
+    float4 fa0[2], fa1[2], fb[2];
+    fa0[0] = *reinterpret_cast<const float4*>(smem + cur + ra0);
+    fa1[0] = *reinterpret_cast<const float4*>(smem + cur + ra1);
+    fb[0] = *reinterpret_cast<const float4*>(smem + cur + rb);
+#pragma unroll
+    for (int xi = 0; xi < 8; ++xi) {      // slot xi: plane xi >> 1, tile group xi & 1
+      if ((xi & 1) == 0 && xi + 2 < 8) {
+        const int pl = (xi >> 1) + 1, s2 = pl & 1;
+        fa0[s2] = *reinterpret_cast<const float4*>(smem + cur + ra0 + pl * PL);
+        fa1[s2] = *reinterpret_cast<const float4*>(smem + cur + ra1 + pl * PL);
+        fb[s2] = *reinterpret_cast<const float4*>(smem + cur + rb + pl * PL);
+      }
+      if constexpr (ROLE == 0) {
+        if (xi == 0) read_raw(1 - P);
+        if (xi == 1) { col_stage(0); col_stage(1); }
+        if (xi == 2) { col_stage(2); col_stage(3); }
+        if (xi >= 3 && xi < 7) row_stage_store(nxt, xi - 3);
+      } else {
+        if (xi == 0) { store_raw(P, 0); store_raw(P, 1); store_raw(P, 2); }
+        if (xi == 1) load_raw3();
+        if (xi >= 2 && xi < 6) { store_u(nxt, 2 * (xi - 2)); store_u(nxt, 2 * (xi - 2) + 1); }
+        if (xi >= 3 && xi < 7) { load_u(2 * (xi - 3)); load_u(2 * (xi - 3) + 1); }
+        if (xi == 6) step_u();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const int s1 = (xi >> 1) & 1;
+      const float* a = (xi & 1) ? (const float*)&fa1[s1] : (const float*)&fa0[s1];
+      const float* b = (const float*)&fb[s1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[xi], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  };
+#else
   auto chunk = [&](auto par) {
     constexpr int P = decltype(par)::value;
     constexpr int cur = P * BUF, nxt = BUF - cur;
@@ -251,6 +295,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, float* smem) {
     }
     __syncthreads();
   };
+#endif
 
   float4* xch = reinterpret_cast<float4*>(smem + BUF) + (wave * 16) * 64 + lane;   // stage 1 is the free one at an item's end
   for (; w_cur < L; w_cur += nslots) {
