@@ -937,21 +937,31 @@ bool wino22_planned(const contrad_conv_desc* d, int mode) {
 
 long long wino22_workspace_bytes(const contrad_conv_desc* d) { return 4ll * 9 * d->C * d->K * (long long)sizeof(float); }
 
+template <int MODE, int NRAW>
+int launch_wino22_inst(const wino22::Args& a, int blocks, hipStream_t stream) {
+  static const hipError_t attr = hipFuncSetAttribute((const void*)wino22::wino22_kernel<MODE, NRAW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     wino22::LDS_DWORDS * 4);
+  if (attr != hipSuccess) return (int)attr;
+  hipLaunchKernelGGL((wino22::wino22_kernel<MODE, NRAW>), dim3(blocks), dim3(512), wino22::LDS_DWORDS * 4, stream, a);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int MODE>
 int launch_wino22(const contrad_conv_desc* d, const float* in, const float* wp, const float* bias, const float* ref,
                   float* out, float slope, float gain, float* U, hipStream_t stream) {
-  static const hipError_t attr = hipFuncSetAttribute((const void*)wino22::wino22_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     wino22::LDS_DWORDS * 4);
-  if (attr != hipSuccess) return (int)attr;
   wino22::Args a = wino22_args(d, MODE);
   a.x = in; a.U = U; a.y = out; a.bias = bias; a.ref = ref; a.slope = slope; a.gain = gain;
   const int quads = 4 * (a.Cin / 4) * a.Cout;
   hipLaunchKernelGGL(wino22::wino22_filter_kernel<MODE>, dim3(cdiv(quads, 256)), dim3(256), 0, stream, wp, U, d->C, d->K, d->ldw);
   CONTRAD_CHECK_LAUNCH();
   const int l0 = cdiv(a.NTB, 8) * a.NKB * (MODE == MODE_DGRAD ? 4 : 1);
-  hipLaunchKernelGGL(wino22::wino22_kernel<MODE>, dim3(8 * std::min(WINO_CUS / 8, l0)), dim3(512), wino22::LDS_DWORDS * 4, stream, a);
-  CONTRAD_CHECK_LAUNCH();
-  return 0;
+  const int blocks = 8 * std::min(WINO_CUS / 8, l0);
+  const int items = 2 * a.NIMG * (a.GH + 1) * (a.GW + 1);      // raw box pieces per chunk (pixel x k-quad)
+  const int nraw = cdiv(items, 256);
+  if (nraw <= 5) return launch_wino22_inst<MODE, 5>(a, blocks, stream);
+  if (nraw == 6) return launch_wino22_inst<MODE, 6>(a, blocks, stream);
+  return launch_wino22_inst<MODE, 7>(a, blocks, stream);
 }
 
 // ---- weight gradient of the 4x4 stride-2 layers on F(2x2, 2x2) (wino22_wgrad_kernel) ----

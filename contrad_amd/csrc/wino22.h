@@ -38,7 +38,8 @@ constexpr int RAW_SZ = RAW_PX * 8;
 constexpr int RAW0 = 2 * BUF;
 constexpr int LDS_DWORDS = 2 * BUF + 2 * RAW_SZ;     // 161 792 B
 constexpr unsigned OOB = 0x80000000u;
-constexpr int NRAW = 7, NU = 5;                 // float4 pieces per mover thread and chunk: 1600 / 256, 1152 / 256
+constexpr int NU = 5;                           // float4 pieces of U per thread and chunk: 1152 / 256
+// (raw box pieces per mover thread and chunk = template parameter NRAW: 5 / 6 / 7 for grids of 16 / 8 / 4 -- 1156 / 1296 / 1600 items)
 
 struct Args {
   const float* x;      // input [N][Hi][Wi][ldi]   (FWD: x, Hi = 2 G;  DGRAD: gy, Hi = G)
@@ -62,7 +63,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const float* base, bool o
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, on ? (int)0x80000000u : 0, 0x00020000);
 }
 
-template <int MODE, int ROLE>   // ROLE 0: transform waves (0-3), 1: movers (4-7)
+template <int MODE, int ROLE, int NRAW>   // ROLE 0: transform waves (0-3), 1: movers (4-7)
 __device__ __forceinline__ void body(const Args& p, float* smem) {
   const int tid = threadIdx.x & 255, lane = threadIdx.x & 63, w8 = threadIdx.x >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -355,10 +356,10 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
   }
 }
 
-template <int MODE>
+template <int MODE, int NRAW>
 __global__ __launch_bounds__(512, 2) void wino22_kernel(const Args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (threadIdx.x < 256) body<MODE, 0>(p, smem); else body<MODE, 1>(p, smem);
+  if (threadIdx.x < 256) body<MODE, 0, NRAW>(p, smem); else body<MODE, 1, NRAW>(p, smem);
 }
 
 // U_ph = G g_ph G^T (G = [[1,0],[1,1],[0,1]]) per phase from the packed 4x4 weight Wp[(kh * 4 + kw) * C + c][ldw]:
