@@ -816,6 +816,7 @@ int launch(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
 #include "conv_c32.h"
 #include "wino.h"
 #include "wino22.h"
+#include "wino44.h"
 
 // ---------------- Winograd F(2x2, 3x3) path (wino.h): 3x3 stride-1 pad-1 layers, forward and data gradient ----------------
 // Can the shape run on wino_kernel<mode> at all?  (input channels % 16, output channels % 64, power-of-two maps >= 4)
@@ -861,12 +862,14 @@ long long wino_items(const contrad_conv_desc* d, int mode) {
 }
 
 constexpr int WINO_CUS = 256;      // one persistent block per CU of the MI355X
+bool wino44_planned(const contrad_conv_desc* d, int mode);     // (below: F(4x4, 3x3) goes first)
 
 // Does the plan send the layer there?  A block is a whole CU and an item (64 tiles x 64 couts x all channels) its unit of
 // work: the launch needs about a round of items, and the last round must not be mostly empty.
 bool wino_planned(const contrad_conv_desc* d, int mode) {
   static const bool enabled = []() { const char* e = contrad_dev_env("CONTRAD_WINO"); return !(e && e[0] == '0'); }();
   if (!enabled || !wino_ok(d, mode)) return false;
+  if (wino44_planned(d, mode)) return false;       // (F(4x4, 3x3) takes the launch)
   const long long items = wino_items(d, mode);
   const long long rounds = cdivll(items, WINO_CUS);
   static const long long min_items = []() { const char* e = contrad_dev_env("CONTRAD_WINO_MIN_ITEMS"); return e ? atoll(e) : 150ll; }();
@@ -883,6 +886,84 @@ int wino_grid(const wino::Args& a) {
   return 8 * std::min(WINO_CUS / 8, l0);
 }
 
+
+// ---------------- Winograd F(4x4, 3x3) path (wino44.h): the same layers as wino.h on maps of 8x8 and larger ----------------
+// (input channels % 32, output channels % 64, power-of-two maps >= 8; 2.25 multiply-adds per output instead of 4)
+bool wino44_ok(const contrad_conv_desc* d, int mode) {
+  if (mode != MODE_FWD && mode != MODE_DGRAD) return false;
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1) return false;
+  if (d->H < 8 || d->W < 8 || (d->H & (d->H - 1)) || (d->W & (d->W - 1)) || (d->W < 32 ? d->H != d->W : d->H < 16)) return false;
+  const int cin = mode == MODE_FWD ? d->C : d->K, cout = mode == MODE_FWD ? d->K : d->C;
+  const int ldi = mode == MODE_FWD ? d->ldx : d->ldy, ldo = mode == MODE_FWD ? d->ldy : d->ldx;
+  if ((cin & 31) || (cout & 63) || (ldi & 3) || (d->ldw & 3)) return false;
+  const long long lim = 1ll << 31;
+  const long long nimg = d->W >= 32 ? 1 : d->W == 16 ? 2 : 8;
+  if (nimg * d->H * d->W * std::max(ldi, ldo) * 4 >= lim) return false;     // block-relative byte offsets
+  if (36ll * cin * cout * 4 >= lim) return false;
+  return true;
+}
+
+wino44::Args wino44_args(const contrad_conv_desc* d, int mode) {
+  wino44::Args a{};
+  a.N = d->N; a.H = d->H; a.W = d->W;
+  a.Cin = mode == MODE_FWD ? d->C : d->K;
+  a.Cout = mode == MODE_FWD ? d->K : d->C;
+  a.ldi = mode == MODE_FWD ? d->ldx : d->ldy;
+  a.ldo = mode == MODE_FWD ? d->ldy : d->ldx;
+  a.TW = std::min(8, d->W / 4); a.TH = std::min(4, d->H / 4);      // 4x4-pixel tiles per image part of an item: 4 x 8, 4 x 4 (16x16 maps), 2 x 2 (8x8)
+  a.sh_tw = __builtin_ctz(a.TW); a.sh_thw = __builtin_ctz(a.TH * a.TW);
+  a.NIMG = 32 / (a.TH * a.TW);
+  a.PH = d->H / (4 * a.TH); a.PW = d->W / (4 * a.TW);
+  a.NP = cdiv(d->N, a.NIMG) * a.PH * a.PW;
+  a.NKB = a.Cout / 64;
+  a.BH = 4 * a.TH + 2; a.BW = 4 * a.TW + 2;       // raw box: always with the halo
+  return a;
+}
+
+long long wino44_items(const contrad_conv_desc* d, int mode) {
+  const wino44::Args a = wino44_args(d, mode);
+  return (long long)a.NP * a.NKB;
+}
+
+// An item is 512 output pixels x 64 couts x all channels on a whole CU: twice wino.h's.  The plan takes F(4x4, 3x3) when the
+// launch has a full round of them and its last round is not mostly empty; else the layer falls through to wino_planned.
+bool wino44_planned(const contrad_conv_desc* d, int mode) {
+  static const bool enabled = []() { const char* e = contrad_dev_env("CONTRAD_WINO44"); return !(e && e[0] == '0'); }();
+  static const bool enabled2 = []() { const char* e = contrad_dev_env("CONTRAD_WINO"); return !(e && e[0] == '0'); }();
+  if (!enabled || !enabled2 || !wino44_ok(d, mode)) return false;
+  const long long items = wino44_items(d, mode);
+  static const long long min_items = []() { const char* e = contrad_dev_env("CONTRAD_WINO44_MIN_ITEMS"); return e ? atoll(e) : 230ll; }();
+  if (items < WINO_CUS) return items >= min_items;
+  return cdivll(items, WINO_CUS) * WINO_CUS * 10 <= items * 14;
+}
+
+long long wino44_workspace_bytes(const contrad_conv_desc* d) { return 36ll * d->C * d->K * (long long)sizeof(float); }
+
+int wino44_grid(const wino44::Args& a) {
+  const int l0 = cdiv(a.NP, 8) * a.NKB;           // items of the fullest XCD
+  return 8 * std::min(WINO_CUS / 8, l0);
+}
+
+template <int MODE, int BOXW>
+int launch_wino44_inst(const wino44::Args& a, hipStream_t stream) {
+  static const hipError_t attr = hipFuncSetAttribute((const void*)wino44::wino44_kernel<MODE, BOXW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     wino44::LDS_DWORDS * 4);
+  if (attr != hipSuccess) return (int)attr;
+  hipLaunchKernelGGL((wino44::wino44_kernel<MODE, BOXW>), dim3(wino44_grid(a)), dim3(512), wino44::LDS_DWORDS * 4, stream, a);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int MODE>
+int launch_wino44(const contrad_conv_desc* d, const float* in, const float* wp, const float* bias, const float* ref,
+                  float* out, float slope, float gain, float* U, hipStream_t stream) {
+  wino44::Args a = wino44_args(d, MODE);
+  a.x = in; a.U = U; a.y = out; a.bias = bias; a.ref = ref; a.slope = slope; a.gain = gain;
+  const int quads = (a.Cin / 4) * a.Cout;
+  hipLaunchKernelGGL(wino44::wino44_filter_kernel<MODE>, dim3(cdiv(quads, 256)), dim3(256), 0, stream, wp, U, d->C, d->K, d->ldw);
+  CONTRAD_CHECK_LAUNCH();
+  return a.BW == 34 ? launch_wino44_inst<MODE, 34>(a, stream) : a.BW == 18 ? launch_wino44_inst<MODE, 18>(a, stream) : launch_wino44_inst<MODE, 10>(a, stream);
+}
 
 // ---------------- Winograd F(2x2, 2x2) path (wino22.h): 4x4 stride-2 pad-1 layers, forward and data gradient ----------------
 bool wino22_ok(const contrad_conv_desc* d, int mode) {
@@ -1840,6 +1921,7 @@ extern "C" int contrad_abi_version(void) { return 2; }
 
 extern "C" long long contrad_conv2d_fwd_workspace_bytes(const contrad_conv_desc* d) {
   if (check_desc(d)) return -22;
+  if (wino44_planned(d, MODE_FWD)) return wino44_workspace_bytes(d);
   if (wino_planned(d, MODE_FWD)) return wino_workspace_bytes(d);
   if (wino22_planned(d, MODE_FWD)) return wino22_workspace_bytes(d);
   const FwdPlan p = fwd_plan(d);
@@ -1860,6 +1942,10 @@ extern "C" int contrad_conv2d_fwd_add(const contrad_conv_desc* d, const float* x
   CONTRAD_ARG(M < (1ll << 31));
   a.M = (int)M; a.Ncol = d->K; a.Kg = d->KH * d->KW * d->C;
   a.st_nt = st_nt_for(M, d->ldy);
+  if (wino44_planned(d, MODE_FWD) && workspace && workspace_bytes >= wino44_workspace_bytes(d)) {   // Winograd F(4x4, 3x3), wino44.h
+    CONTRAD_ARG(aligned16(x, wp, workspace));
+    return launch_wino44<MODE_FWD>(d, x, wp, bias, addend, y, slope, gain, workspace, (hipStream_t)stream);
+  }
   if (wino_planned(d, MODE_FWD) && workspace && workspace_bytes >= wino_workspace_bytes(d)) {   // Winograd F(2x2, 3x3), wino.h
     CONTRAD_ARG(aligned16(x, wp, workspace));
     return launch_wino<MODE_FWD>(d, x, wp, bias, addend, y, slope, gain, workspace, (hipStream_t)stream);
@@ -1923,6 +2009,7 @@ extern "C" int contrad_conv2d_fwd(const contrad_conv_desc* d, const float* x, co
 
 extern "C" long long contrad_conv2d_dgrad_workspace_bytes(const contrad_conv_desc* d) {
   if (check_desc(d)) return -22;
+  if (wino44_planned(d, MODE_DGRAD)) return wino44_workspace_bytes(d);
   if (wino_planned(d, MODE_DGRAD)) return wino_workspace_bytes(d);
   if (wino22_planned(d, MODE_DGRAD)) return wino22_workspace_bytes(d);
   const FwdPlan p = dgrad_plan(d, true);
@@ -1937,6 +2024,10 @@ extern "C" int contrad_conv2d_dgrad_ws(const contrad_conv_desc* d, const float* 
   if (rc) return rc;
   CONTRAD_ARG(gy && wp && dx);
   if (vec_ok(d, MODE_DGRAD)) CONTRAD_ARG(aligned16(gy, wp, dx) && aligned16(act_ref, nullptr, nullptr));
+  if (wino44_planned(d, MODE_DGRAD) && workspace && workspace_bytes >= wino44_workspace_bytes(d)) {   // wino44.h: mirrored filter
+    CONTRAD_ARG(aligned16(gy, wp, workspace));
+    return launch_wino44<MODE_DGRAD>(d, gy, wp, nullptr, act_ref, dx, slope, gain, workspace, (hipStream_t)stream);
+  }
   if (wino_planned(d, MODE_DGRAD) && workspace && workspace_bytes >= wino_workspace_bytes(d)) {   // wino.h: mirrored filter
     CONTRAD_ARG(aligned16(gy, wp, workspace));
     return launch_wino<MODE_DGRAD>(d, gy, wp, nullptr, act_ref, dx, slope, gain, workspace, (hipStream_t)stream);
@@ -2080,6 +2171,29 @@ extern "C" int contrad_conv2d_wino(const contrad_conv_desc* d, int mode, const f
   return launch_wino<MODE_DGRAD>(d, in, wp, nullptr, ref, out, slope, gain, workspace, (hipStream_t)stream);
 }
 
+extern "C" int contrad_conv2d_wino44_ok(const contrad_conv_desc* d, int mode) {
+  if (check_desc(d)) return -22;
+  return wino44_ok(d, mode) ? 1 : 0;
+}
+
+extern "C" long long contrad_conv2d_wino44_workspace_bytes(const contrad_conv_desc* d) {
+  if (check_desc(d)) return -22;
+  return wino44_workspace_bytes(d);
+}
+
+extern "C" int contrad_conv2d_wino44(const contrad_conv_desc* d, int mode, const float* in, const float* wp,
+                                     const float* bias, const float* ref, float* out, float slope, float gain,
+                                     float* workspace, long long workspace_bytes, contrad_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  CONTRAD_ARG(in && wp && out && workspace && (mode == MODE_FWD || mode == MODE_DGRAD));
+  CONTRAD_ARG(aligned16(in, wp, workspace) && aligned16(ref, nullptr, nullptr));
+  CONTRAD_ARG(wino44_ok(d, mode) && workspace_bytes >= wino44_workspace_bytes(d));
+  if (mode == MODE_FWD) return launch_wino44<MODE_FWD>(d, in, wp, bias, ref, out, slope, gain, workspace, (hipStream_t)stream);
+  CONTRAD_ARG(bias == nullptr);
+  return launch_wino44<MODE_DGRAD>(d, in, wp, nullptr, ref, out, slope, gain, workspace, (hipStream_t)stream);
+}
+
 extern "C" int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm, int* bn) {
   int rc = check_desc(d);
   if (rc) return rc;
@@ -2100,6 +2214,7 @@ extern "C" int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm
 extern "C" int contrad_conv2d_path(const contrad_conv_desc* d, int mode) {
   if (check_desc(d) || mode < 0 || mode > 2) return -22;
   if (mode == MODE_FWD && fwd_k1_ok(d)) return 5;
+  if (mode != MODE_WGRAD && wino44_planned(d, mode)) return 9;
   if (mode != MODE_WGRAD && wino_planned(d, mode)) return 7;
   if (mode != MODE_WGRAD && wino22_planned(d, mode)) return 8;
   if (mode == MODE_WGRAD && wino_wgrad_planned(d)) return 7;
@@ -2126,6 +2241,7 @@ extern "C" int contrad_conv2d_path(const contrad_conv_desc* d, int mode) {
 
 extern "C" double contrad_conv2d_executed_fraction(const contrad_conv_desc* d, int mode) {
   if (check_desc(d) || mode < 0 || mode > 2) return -22.0;
+  if (contrad_conv2d_path(d, mode) == 9) return 0.25;        // 36 transform-domain multiply-adds per 4x4 tile instead of 144
   if (contrad_conv2d_path(d, mode) == 7) return 4.0 / 9.0;   // 16 transform-domain multiply-adds per 2x2 tile instead of 36
   if (contrad_conv2d_path(d, mode) == 8) return 9.0 / 16.0;  // four phases x 9 per 2x2 tile instead of 64
   if (contrad_conv2d_path(d, mode) != 3) return 1.0;
@@ -2134,7 +2250,8 @@ extern "C" double contrad_conv2d_executed_fraction(const contrad_conv_desc* d, i
 
 extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int mode, int with_workspace) {
   if (check_desc(d) || mode < 0 || mode > 2) return -22;
-  if (mode != MODE_WGRAD && with_workspace && wino_planned(d, mode)) return wino_grid(wino_args(d, mode));   // (512 threads each)
+  if (mode != MODE_WGRAD && with_workspace && wino44_planned(d, mode)) return wino44_grid(wino44_args(d, mode));   // (512 threads each)
+  if (mode != MODE_WGRAD && with_workspace && wino_planned(d, mode)) return wino_grid(wino_args(d, mode));
   if (mode != MODE_WGRAD && with_workspace && wino22_planned(d, mode)) {
     const wino22::Args a = wino22_args(d, mode);
     return 8 * std::min(WINO_CUS / 8, cdiv(a.NTB, 8) * a.NKB * (mode == MODE_DGRAD ? 4 : 1));

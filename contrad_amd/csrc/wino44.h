@@ -1,4 +1,4 @@
-// Winograd F(4x4, 3x3) in fp32 on v_mfma_f32_32x32x2_f32 for the 3x3 stride-1 pad-1 layers with maps >= 16x16 (included by
+// Winograd F(4x4, 3x3) in fp32 on v_mfma_f32_32x32x2_f32 for the 3x3 stride-1 pad-1 layers with maps >= 8x8 (included by
 // igemm.hip after wino.h).
 //
 // Same layers as wino.h (reference: models/gan/sndcgan.py:91-109, models/gan/stylegan2/layers.py:95-123,
@@ -32,12 +32,11 @@ constexpr int NT = 32;                          // tiles per item
 constexpr int KQS = NT * 4;                     // dwords per (plane, k-quad): 32 rows x 4
 constexpr int PL = 2 * KQS;                     // per plane
 constexpr int V_SZ = 36 * PL;                   // 9 216 dwords
-constexpr int RAW_PX = 648;                     // raw box capacity: 2 x 18 x 18 (16x16 maps), 18 x 34 (wider maps)
 constexpr int RPS = 10;                         // dwords per raw pixel (8 channels + 2): the four tiles of a 32-lane read group are
                                                 // 4 pixels = 40 dwords = 8 banks apart
-constexpr int RAW_SZ = RAW_PX * RPS;            // 6 480 dwords
+constexpr int RAW_SZ = 800 * RPS;               // 8 000 dwords: boxes of 18 x 34 = 612 (+ padding to 5 x 128 pieces), 2 x 18 x 18 = 648, 8 x 10 x 10 = 800 pixels
 constexpr int RAW0 = 2 * V_SZ;
-constexpr int LDS_DWORDS = 2 * V_SZ + 2 * RAW_SZ;     // 125 568 B
+constexpr int LDS_DWORDS = 2 * V_SZ + 2 * RAW_SZ;     // 137 728 B
 constexpr unsigned OOB = 0x80000000u;
 
 struct Args {
@@ -81,17 +80,27 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
   o[3] = __builtin_fmaf(8.f, v, q) + m5;
 }
 
-// MODE: MODE_FWD / MODE_DGRAD (epilogue);  ROLE 0: transform waves (0-3), 1: movers (4-7);  BOXW: raw box width, 18 (16x16 maps, two
-// images per block) or 34 (wider maps) -- compile-time, so that the transform threads' 36 window offsets are immediates
+// MODE: MODE_FWD / MODE_DGRAD (epilogue);  ROLE 0: transform waves (0-3), 1: movers (4-7);  BOXW: raw box width, 10 (8x8 maps: 2 x 2
+// tiles of eight images per block), 18 (16x16 maps: 4 x 4 tiles of two images) or 34 (wider maps: 4 x 8 tiles of one image) --
+// compile-time, so that the transform threads' 36 window offsets are immediates and the movers' piece -> pixel split divides
+// by constants
 template <int MODE, int ROLE, int BOXW>
 __device__ __forceinline__ void body(const Args& p, float* smem) {
-  constexpr int NRAW = (BOXW == 34) ? 5 : 6;      // raw pieces per mover thread and chunk: 18 x 34 x 2 = 1224, 2 x 18 x 18 x 2 = 1296
+  constexpr int TW = (BOXW == 34) ? 8 : (BOXW == 18) ? 4 : 2, TH = (BOXW == 10) ? 2 : 4, NIMG = 32 / (TH * TW), BH = 4 * TH + 2;
+  constexpr int SH_TW = (BOXW == 34) ? 3 : (BOXW == 18) ? 2 : 1, SH_THW = SH_TW + ((BOXW == 10) ? 1 : 2);
+  // BOXW 18 / 10: the whole image sits in the box (16x16 / 8x8 maps, 2 / 8 images per block): the movers fetch its interior
+  // only (512 pixels) and the halo of both raw stages is zeroed once;  BOXW 34: 18 x 34 pixels of a larger image, all fetched
+  // (outside the image: hardware zero fills)
+  constexpr bool INTERIOR = BOXW != 34;
+  constexpr int IW = BOXW - 2, IH = BH - 2;        // interior (= image) size when INTERIOR
+  constexpr int NPX = INTERIOR ? NIMG * IH * IW : BH * BOXW;     // fetched pixels: 512 / 612
+  constexpr int NRAW = (2 * NPX + 255) / 256;      // raw pieces (pixel, k-quad) per mover thread and chunk: 4 / 5
   const int tid = threadIdx.x & 255, lane = threadIdx.x & 63;
   const int w8 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // (wave-uniform: scalar registers)
   const int l31 = lane & 31, lhi = lane >> 5;
   const int wn = w8 & 1, grp = ROLE * 2 + ((w8 >> 1) & 1);     // cout half, xi group (planes 9 grp .. 9 grp + 8)
   const int NKB = p.NKB;
-  const int NCH = p.Cin >> 3;
+  const int NCH = p.Cin >> 3;                      // (>= 4, even)
   const int ppi = p.PH * p.PW;
   // work list: items w = slot, slot + nslots, ... of this XCD's list (item -> kb = w % NKB, patch = (w / NKB) * 8 + xcd)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
@@ -104,58 +113,58 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
     it.kb = w % NKB;
     const int patch = (w / NKB) * 8 + xcd;
     const int g = patch / ppi, pr = patch - g * ppi;
-    it.n_first = g * p.NIMG;
+    it.n_first = g * NIMG;
     it.ph = pr / p.PW; it.pw = pr - it.ph * p.PW;
     return it;
   };
 
-  // ---- movers: raw box pieces (pixel * 2 + k-quad): tid + 256 i ----
-  int rpk[NRAW];                     // image << 16 | box row << 8 | box column  (image 0x7FFF: no such pixel)
-  unsigned vraw[NRAW];
-  const int npx = p.NIMG * p.BH * p.BW;
-  if constexpr (ROLE == 1) {
-    const int bhw = p.BH * p.BW;
-#pragma unroll
-    for (int i = 0; i < NRAW; ++i) {
-      const int piece = tid + 256 * i, px = piece >> 1;
-      const int im = px / bhw, rem = px - im * bhw, rr = rem / p.BW, rc = rem - rr * p.BW;
-      rpk[i] = (px < npx) ? (im << 16 | rr << 8 | rc) : 0x7FFF0000;
-    }
-  }
-  const float* xb_raw = nullptr;     // first image of the item the raw stream is in (nullptr: past the end)
-  int t_raw = 0, w_raw = 0;
-  auto raw_item = [&](int w) {
+  // ---- movers: raw box pieces (pixel * 2 + k-quad): tid + 256 i.  Two offset sets: the item being multiplied and the next one
+  // (the raw stream runs three chunks ahead and crosses into the next item in the last three chunks: a select per load, no
+  // branch in the chunk loop -- with control flow there the compiler drains the whole vector-memory queue at every join) ----
+  unsigned vraw_cur[NRAW], vraw_nxt[NRAW];
+  const float *xb_cur = nullptr, *xb_nxt = nullptr;       // first image of the item (nullptr: no such item)
+  auto raw_offsets = [&](int w, unsigned* v, const float*& xb) {
     if (w < L) {
       const Item it = decode(w);
-      xb_raw = p.x + (size_t)it.n_first * p.H * p.W * p.ldi;
+      xb = p.x + (size_t)it.n_first * p.H * p.W * p.ldi;
       const int nleft = p.N - it.n_first;
 #pragma unroll
       for (int i = 0; i < NRAW; ++i) {
-        const int im = rpk[i] >> 16, rr = (rpk[i] >> 8) & 255, rc = rpk[i] & 255;
-        const int hh = it.ph * 4 * p.TH - 1 + rr, ww = it.pw * 4 * p.TW - 1 + rc;
-        const bool ok = (unsigned)hh < (unsigned)p.H && (unsigned)ww < (unsigned)p.W && im < nleft;
-        vraw[i] = ok ? (unsigned)((((im * p.H + hh) * p.W + ww) * p.ldi + ((tid + 256 * i) & 1) * 4) * 4) : OOB;
+        const int piece = tid + 256 * i, px = piece >> 1;
+        int im, hh, ww;
+        if constexpr (INTERIOR) { im = px / (IH * IW); hh = (px / IW) % IH; ww = px % IW; }
+        else { im = 0; hh = it.ph * 4 * TH - 1 + px / BOXW; ww = it.pw * 4 * TW - 1 + px % BOXW; }
+        const bool ok = px < NPX && (unsigned)hh < (unsigned)p.H && (unsigned)ww < (unsigned)p.W && im < nleft;
+        v[i] = ok ? (unsigned)((((im * p.H + hh) * p.W + ww) * p.ldi + (piece & 1) * 4) * 4) : OOB;
       }
     } else {
-      xb_raw = nullptr;
+      xb = nullptr;
+#pragma unroll
+      for (int i = 0; i < NRAW; ++i) v[i] = OOB;
     }
   };
   float4 rraw[NRAW];
-  auto load_raw = [&]() {            // the raw stream's next chunk into flight, then step the stream
-    const __amdgpu_buffer_rsrc_t rs = rsrc(xb_raw, xb_raw != nullptr);
+  auto load_raw = [&](int k) {       // chunk k of the current item (k >= NCH: chunk k - NCH of the next one) into flight
+    const bool nx = k >= NCH;
+    const float* xb = nx ? xb_nxt : xb_cur;
+    const __amdgpu_buffer_rsrc_t rs = rsrc(xb, xb != nullptr);
+    const unsigned soff = (unsigned)(nx ? k - NCH : k) * 32u;
 #pragma unroll
-    for (int i = 0; i < NRAW; ++i) rraw[i] = bload4(rs, vraw[i], (unsigned)t_raw * 32u);
-    if (++t_raw == NCH) { t_raw = 0; w_raw += nslots; raw_item(w_raw); }
+    for (int i = 0; i < NRAW; ++i) rraw[i] = bload4(rs, nx ? vraw_nxt[i] : vraw_cur[i], soff);
   };
+  int wraw[NRAW];                    // LDS dword offset of the thread's pieces inside a raw stage
+#pragma unroll
+  for (int i = 0; i < NRAW; ++i) {
+    const int piece = tid + 256 * i, px = piece >> 1;
+    const int bpx = INTERIOR ? ((px / (IH * IW)) * BH + (px / IW) % IH + 1) * BOXW + px % IW + 1 : px;
+    wraw[i] = bpx * RPS + (piece & 1) * 4;         // (BOXW 34: pieces past the box land in the stage's padding: no branch)
+  }
   auto store_raw = [&](int stage) {
 #pragma unroll
     for (int i = 0; i < NRAW; ++i) {
-      const int piece = tid + 256 * i;
-      if (piece < 2 * npx) {
-        float* dst = smem + RAW0 + stage * RAW_SZ + (piece >> 1) * RPS + (piece & 1) * 4;
-        *reinterpret_cast<float2*>(dst) = make_float2(rraw[i].x, rraw[i].y);
-        *reinterpret_cast<float2*>(dst + 2) = make_float2(rraw[i].z, rraw[i].w);
-      }
+      float* dst = smem + RAW0 + stage * RAW_SZ + wraw[i];
+      *reinterpret_cast<float2*>(dst) = make_float2(rraw[i].x, rraw[i].y);
+      *reinterpret_cast<float2*>(dst + 2) = make_float2(rraw[i].z, rraw[i].w);
     }
   };
 
@@ -163,8 +172,8 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
   const int tch = tid & 7, ttile = tid >> 3;
   int rd0 = 0;
   if constexpr (ROLE == 0) {
-    const int img = ttile >> p.sh_thw, ty = (ttile >> p.sh_tw) & (p.TH - 1), tx = ttile & (p.TW - 1);
-    rd0 = RAW0 + ((img * p.BH + 4 * ty) * BOXW + 4 * tx) * RPS + tch;
+    const int img = ttile >> SH_THW, ty = (ttile >> SH_TW) & (TH - 1), tx = ttile & (TW - 1);
+    rd0 = RAW0 + ((img * BH + 4 * ty) * BOXW + 4 * tx) * RPS + tch;
   }
   constexpr int rowstep = BOXW * RPS;
   const int wrV = (tch >> 2) * KQS + ttile * 4 + (tch & 3);
@@ -186,14 +195,9 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) dst[j * PL] = d[i][j];
   };
-  auto transform = [&](int rstage, int vstage) {      // raw stage -> B^T d B -> V stage (outside the chunk loop)
-    tr_read(rstage); tr_cols(0); tr_cols(3);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) tr_row(vstage, i);
-  };
 
   // ---- every wave: its U fragments, global -> registers (xi plane 9 grp + i; lane: k-quad lhi, cout wn * 32 + l31): a ring of
-  // six float4, refilled in place six MFMA slots (~1.2 us) ahead ----
+  // six float4, refilled in place six MFMA slots ahead ----
   const unsigned u_voff = (unsigned)((lhi * p.Cout + wn * 32 + l31) * 16);
   const unsigned u_plane = (unsigned)(NCH * 2 * p.Cout * 16), u_step = (unsigned)(2 * p.Cout * 16);
   const unsigned u_grp = (unsigned)(9 * grp) * u_plane;
@@ -213,88 +217,122 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+  if constexpr (INTERIOR) {          // the halo of both raw stages: zeros, never written again
+    for (int i = threadIdx.x; i < 2 * RAW_SZ / 4; i += 512) reinterpret_cast<float4*>(smem + RAW0)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+  }
   // ---- prologue (first item): raw 0 / 1 in their stages, raw 2 in flight;  the first six U fragments in flight ----
   if constexpr (ROLE == 1) {
-    w_raw = w_cur; raw_item(w_raw);
-    load_raw(); store_raw(0);
-    load_raw(); store_raw(1);
-    load_raw();
+    raw_offsets(w_cur, vraw_cur, xb_cur);
+    raw_offsets(w_cur + nslots, vraw_nxt, xb_nxt);
+    load_raw(0); store_raw(0);
+    load_raw(1); store_raw(1);
+    load_raw(2);
   }
+  // (the raw loads BEFORE the U fragments, here and after the epilogue, as in the chunk loop: the compiler's wait counts at
+  // the loop head are the merge of both ways in, and with the raw pieces youngest on one of them it drains the queue there)
   unsigned u_pair = u_base(w_cur);      // soffset of (plane 9 grp, first chunk of the current pair)
 #pragma unroll
   for (int i = 0; i < 6; ++i) load_u(i, u_pair + (unsigned)i * u_plane, true);
 
   const float g1 = p.gain, g0 = p.gain * p.slope;
 
+  // A pair of chunks (t on V stage 0, t + 1 on stage 1) = 18 slots of four MFMAs, one basic block.  Chunk c: transform waves raw
+  // (c + 1) -> V stage (c + 1) & 1 (not in the item's last chunk: both V stages are the exchange area next);  movers: raw (c + 2)
+  // registers -> raw stage c & 1, raw (c + 3) into flight (the item's last one: after the epilogue, like the U fragments of the
+  // next item -- in flight across the epilogue they cost it 50 - 60 registers).  LAST: the item's last pair (its own copy of the
+  // code: no branch inside a pair).
+  auto pair = [&](auto last_c, int t) {
+    constexpr bool LAST = decltype(last_c)::value;
+    float4 fa[2];
+    fa[0] = *reinterpret_cast<const float4*>(smem + rdA);
+#pragma unroll
+    for (int s = 0; s < 18; ++s) {
+      const int P = s / 9, xi = s - 9 * P;
+      if (xi + 1 < 9) fa[(s + 1) & 1] = *reinterpret_cast<const float4*>(smem + P * V_SZ + rdA + (xi + 1) * PL);
+      if constexpr (ROLE == 1) {
+#ifndef W44_NO_RAW
+        if (xi == 0) store_raw(P);
+        if (xi == 1 && !(P == 1 && LAST)) load_raw(t + P + 3);
+#endif
+      } else if (!(P == 1 && LAST)) {
+#ifndef W44_NO_TRANSFORM
+        if (xi == 0) tr_read(1 - P);
+        if (xi == 1) tr_cols(0);
+        if (xi == 2) tr_cols(3);
+        if (xi >= 3) tr_row(1 - P, xi - 3);
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const float* a = (const float*)&fa[s & 1];
+      const float* b = (const float*)&ru[s % 6];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[xi], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // the fragment of slot s + 6 into the ring entry just consumed
+#ifndef W44_NO_ULOAD
+      if (s + 6 < 18) load_u(s % 6, u_pair + (unsigned)((s + 6) / 9) * u_step + (unsigned)((s + 6) % 9) * u_plane, true);
+      else if (!LAST) load_u(s % 6, u_pair + 2u * u_step + (unsigned)(s - 12) * u_plane, true);
+#endif
+      if (xi == 8) {
+        __syncthreads();
+        if (P == 0) fa[(s + 1) & 1] = *reinterpret_cast<const float4*>(smem + V_SZ + rdA);
+      }
+    }
+    u_pair += 2u * u_step;
+  };
+
   for (; w_cur < L; w_cur += nslots) {
     __syncthreads();                 // raw 0 (and 1) of this item are in LDS; the exchange area is free again
-    if constexpr (ROLE == 0) transform(0, 0);
+    if constexpr (ROLE == 0) {
+      tr_read(0); tr_cols(0); tr_cols(3);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) tr_row(0, i);
+    }
     __syncthreads();
 
-    // A pair of chunks (t on V stage 0, t + 1 on stage 1) = 18 slots of four MFMAs.  Chunk c: transform waves raw (c + 1) -> V
-    // stage (c + 1) & 1 (not in the item's last chunk: both V stages are the exchange area next);  movers: raw (c + 2) registers
-    // -> raw stage c & 1, raw (c + 3) into flight (the item's last one: after the epilogue, like the U fragments of the next
-    // item -- in flight across the epilogue they cost it 50 - 60 registers)
-    for (int t = 0; t < NCH; t += 2) {
-      const bool last = t + 2 >= NCH;
-      float4 fa[2];
-      fa[0] = *reinterpret_cast<const float4*>(smem + rdA);
-#pragma unroll
-      for (int s = 0; s < 18; ++s) {
-        const int P = s / 9, xi = s - 9 * P;
-        if (xi + 1 < 9) fa[(s + 1) & 1] = *reinterpret_cast<const float4*>(smem + P * V_SZ + rdA + (xi + 1) * PL);
-        if constexpr (ROLE == 1) {
-          if (xi == 0) store_raw(P);
-          if (xi == 1 && !(P == 1 && last)) load_raw();
-        } else if (!(P == 1 && last)) {
-          if (xi == 0) tr_read(1 - P);
-          if (xi == 1) tr_cols(0);
-          if (xi == 2) tr_cols(3);
-          if (xi >= 3) tr_row(1 - P, xi - 3);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const float* a = (const float*)&fa[s & 1];
-        const float* b = (const float*)&ru[s % 6];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[xi], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        // the fragment of slot s + 6 into the ring entry just consumed
-        if (s + 6 < 18) load_u(s % 6, u_pair + (unsigned)((s + 6) / 9) * u_step + (unsigned)((s + 6) % 9) * u_plane, true);
-        else if (!last) load_u(s % 6, u_pair + 2u * u_step + (unsigned)(s - 12) * u_plane, true);
-        if (xi == 8) {
-          __syncthreads();
-          if (P == 0) fa[(s + 1) & 1] = *reinterpret_cast<const float4*>(smem + V_SZ + rdA);
-        }
-      }
-      u_pair += 2u * u_step;
-    }
+    for (int t = 0; t + 2 < NCH; t += 2) pair(std::false_type{}, t);
+    pair(std::true_type{}, NCH - 2);
 
     // ---- output transform through the exchange area: [wave][xi][lane] float4 = accumulator rows 4q .. 4q + 3 ----
+    // In pass q this wave owns accumulator row r = 4 q + grp = tile (r & 3) + 8 (r >> 2) + 4 lhi = grp + 8 q + 4 lhi of its cout half.
+    // (image, tile row, tile column) are bit fields of the tile index and only bit 2 (lhi) is per lane: byte offset = lane part
+    // (one register for the whole kernel) + a wave-uniform part that travels in the buffer instructions' scalar offset.
+    // (Written as img / ty / tx arithmetic per pass the compiler hoisted per-lane values out of the item loop into scratch,
+    // and every reload waits for the stores in flight.)
     const Item it = decode(w_cur);
-    const int cout = it.kb * 64 + wn * 32 + l31;
+    auto bit_off = [&](int bb) -> unsigned {      // offset contribution of tile-index bit bb (uniform)
+      return bb < SH_TW ? (unsigned)((4 << bb) * p.ldo * 4)
+             : bb < SH_THW ? (unsigned)((4 << (bb - SH_TW)) * p.W * p.ldo * 4)
+                           : (unsigned)((1 << (bb - SH_THW)) * p.H * p.W * p.ldo * 4);
+    };
+    const unsigned lane_off = (lhi ? bit_off(2) : 0u) + (unsigned)((wn * 32 + l31) * 4);
+    const unsigned item_off = (unsigned)((((it.ph * TH * 4) * p.W + it.pw * TW * 4) * p.ldo + it.kb * 64) * 4)
+                              + ((grp & 1) ? bit_off(0) : 0u) + ((grp & 2) ? bit_off(1) : 0u);
     float* ybase = p.y + (size_t)it.n_first * p.H * p.W * p.ldo;
-    const __amdgpu_buffer_rsrc_t rsY = rsrc(ybase, true);
-    const __amdgpu_buffer_rsrc_t rsR = rsrc(p.ref ? p.ref + (size_t)it.n_first * p.H * p.W * p.ldo : ybase, p.ref != nullptr);
+    const float* rbase = p.ref ? p.ref + (size_t)it.n_first * p.H * p.W * p.ldo : ybase;
     const unsigned dcol = (unsigned)p.ldo * 4u, drow = (unsigned)(p.W * p.ldo) * 4u;
-    const float bj = (MODE == MODE_FWD && p.bias) ? p.bias[cout] : 0.f;
+    const float bj = (MODE == MODE_FWD && p.bias) ? p.bias[it.kb * 64 + wn * 32 + l31] : 0.f;
+    const float ron = p.ref ? 1.f : 0.f;          // (uniform; with no second operand the loads below are off and return zeros)
     float4* xw = reinterpret_cast<float4*>(smem) + (w8 * 9) * 64 + lane;
     // reader: the wave of (cout half wn, group g') is w8' = (g' >> 1) * 4 + (g' & 1) * 2 + wn
     const float* xr = smem + (wn * 9 * 64 + lane) * 4 + grp;
+#ifdef W44_NO_EPILOGUE
+    if (p.N < 0)
+#endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      // this wave's element: accumulator row r = 4 q + grp -> tile (r & 3) + 8 (r >> 2) + 4 lhi = grp + 8 q + 4 lhi
-      const int tile = grp + 8 * q + 4 * lhi;
-      const int img = tile >> p.sh_thw, ty = (tile >> p.sh_tw) & (p.TH - 1), tx = tile & (p.TW - 1);
-      const bool ok = it.n_first + img < p.N;
-      const unsigned o0 = ok ? (unsigned)((((img * p.H + (it.ph * p.TH + ty) * 4) * p.W + (it.pw * p.TW + tx) * 4) * p.ldo + cout) * 4) : OOB;
-      float rv[4][4];
-      if (p.ref) {                   // (uniform) the epilogue's second operand goes into flight before the exchange
+      // (the element's image exists?  per lane only where a half-wave step of four tiles crosses images: 8x8 maps)
+      const unsigned voff = (it.n_first + ((grp + 8 * q + 4 * lhi) >> SH_THW) < p.N) ? lane_off : OOB;
+      const __amdgpu_buffer_rsrc_t rsY = rsrc(ybase, true);
+      const __amdgpu_buffer_rsrc_t rsR = rsrc(rbase, p.ref != nullptr);
+      const unsigned s0 = item_off + ((q & 1) ? bit_off(3) : 0u) + ((q & 2) ? bit_off(4) : 0u);
+      float rv[4][4];                // the epilogue's second operand goes into flight before the exchange
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            rv[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)(o0 + (unsigned)i * drow + (unsigned)j * dcol), 0, 0));
-      }
+        for (int i = 0; i < 4; ++i)
+          rv[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)voff, (int)(s0 + (unsigned)i * drow + (unsigned)j * dcol), 0));
 #pragma unroll
       for (int xi = 0; xi < 9; ++xi)
         xw[xi * 64] = make_float4(acc[xi][4 * q], acc[xi][4 * q + 1], acc[xi][4 * q + 2], acc[xi][4 * q + 3]);
@@ -302,6 +340,7 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
       float S[6][4];
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
+        if ((a & 1) == 0) __builtin_amdgcn_sched_barrier(0);      // (two rows of M in flight at a time: all 36 at once spill)
         float m[6];
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
@@ -310,6 +349,7 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
         }
         at6(m[0], m[1], m[2], m[3], m[4], m[5], S[a]);
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float v[4];
@@ -317,13 +357,14 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if constexpr (MODE == MODE_DGRAD) {
-            if (p.ref) v[i] *= (rv[j][i] > 0.f) ? g1 : g0;
+            const float gsel = (rv[j][i] > 0.f) ? g1 : g0;
+            v[i] *= (ron > 0.f) ? gsel : 1.f;
           } else {
             v[i] += bj;
             v[i] *= (v[i] > 0.f) ? g1 : g0;
-            if (p.ref) v[i] += rv[j][i];
+            v[i] += rv[j][i];
           }
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rsY, (int)(o0 + (unsigned)i * drow + (unsigned)j * dcol), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rsY, (int)voff, (int)(s0 + (unsigned)i * drow + (unsigned)j * dcol), 0);
         }
       }
       if (q < 3) __syncthreads();    // (after the last pass: the barrier at the top of the item loop)
@@ -333,12 +374,18 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     __builtin_amdgcn_sched_barrier(0);
-    // the prefetches the last chunk skipped
+    // the prefetches the last chunk skipped, and the movers' offsets one item further on
     const int w_next = w_cur + nslots;
+    if constexpr (ROLE == 1) {
+#pragma unroll
+      for (int i = 0; i < NRAW; ++i) vraw_cur[i] = vraw_nxt[i];
+      xb_cur = xb_nxt;
+      load_raw(2);
+    }
     u_pair = u_base(w_next);
 #pragma unroll
     for (int i = 0; i < 6; ++i) load_u(i, u_pair + (unsigned)i * u_plane, w_next < L);
-    if constexpr (ROLE == 1) load_raw();
+    if constexpr (ROLE == 1) raw_offsets(w_next + nslots, vraw_nxt, xb_nxt);
   }
 }
 

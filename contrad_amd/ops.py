@@ -90,6 +90,8 @@ def conv_kernel_name(mode, d):
         return 'wino_wgrad_kernel' if mode == 2 else 'wino_kernel<%d>' % mode
     if path == 8:
         return 'wino22_wgrad_kernel' if mode == 2 else 'wino22_kernel<%d>' % mode
+    if path == 9:
+        return 'wino44_kernel<%d>' % mode
     if path in (2, 3):
         return 'igemm_lean_kernel<%d, %d, %d>' % (mode, bm.value, bn.value)
     return 'igemm_kernel<%d, %d, %d, %s>' % (mode, bm.value, bn.value, 'true' if path == 1 else 'false')
@@ -182,9 +184,10 @@ def conv2d_dgrad(gy, wp, x_shape, KH, KW, stride, pad, act_ref=None, slope=1.0, 
     return out
 
 
-def conv2d_wino(mode, inp, wp, C, K, bias=None, ref=None, slope=1.0, gain=1.0, out=None, k4s2=False):
+def conv2d_wino(mode, inp, wp, C, K, bias=None, ref=None, slope=1.0, gain=1.0, out=None, k4s2=False, f44=False):
     """Winograd kernels on ANY shape ``contrad_conv2d_wino_ok`` accepts (conv2d_fwd / conv2d_dgrad pick them by themselves for
-    launches that fill the chip).  3x3 stride 1 pad 1 (F(2x2,3x3), csrc/wino.h) -- mode 0: inp = x (N,H,W,C) -> y (N,H,W,K);
+    launches that fill the chip).  3x3 stride 1 pad 1 (F(2x2,3x3), csrc/wino.h; ``f44``: F(4x4,3x3), csrc/wino44.h, maps of
+    16x16 and larger) -- mode 0: inp = x (N,H,W,C) -> y (N,H,W,K);
     mode 1: inp = gy (N,H,W,K) -> dx (N,H,W,C) -- or, ``k4s2``, 4x4 stride 2 pad 1 (F(2x2,2x2) on the four phases,
     csrc/wino22.h): mode 0: x (N,H,W,C) -> y (N,H/2,W/2,K); mode 1: gy (N,Ho,Wo,K) -> dx (N,2Ho,2Wo,C)."""
     _chk(inp, 'inp'); _chk(wp, 'wp'); _chk(bias, 'bias'); _chk(ref, 'ref')
@@ -205,11 +208,16 @@ def conv2d_wino(mode, inp, wp, C, K, bias=None, ref=None, slope=1.0, gain=1.0, o
         raise RuntimeError('contrad_hip: ref must match the output in shape and leading dimension')
     d = make_desc(N, H, W, C, K, geo[0], geo[1], geo[2], geo[3], _ld(inp) if mode == 0 else _ld(out),
                   _ld(out) if mode == 0 else _ld(inp), wp.stride(0))
-    if lib().raw('contrad_conv2d_wino_ok')(ctypes.byref(d), mode) != 1:
-        raise RuntimeError('contrad_hip: shape not supported by the Winograd kernels')
-    nbytes = lib().raw('contrad_conv2d_wino_workspace_bytes')(ctypes.byref(d), mode)
+    if f44:
+        if k4s2 or lib().raw('contrad_conv2d_wino44_ok')(ctypes.byref(d), mode) != 1:
+            raise RuntimeError('contrad_hip: shape not supported by the F(4x4, 3x3) Winograd kernel')
+        nbytes = lib().raw('contrad_conv2d_wino44_workspace_bytes')(ctypes.byref(d))
+    else:
+        if lib().raw('contrad_conv2d_wino_ok')(ctypes.byref(d), mode) != 1:
+            raise RuntimeError('contrad_hip: shape not supported by the Winograd kernels')
+        nbytes = lib().raw('contrad_conv2d_wino_workspace_bytes')(ctypes.byref(d), mode)
     ws = _workspace(nbytes, inp.device)
-    lib().call('contrad_conv2d_wino', ctypes.byref(d), mode, _p(inp), _p(wp), _p(bias), _p(ref), _p(out),
+    lib().call('contrad_conv2d_wino44' if f44 else 'contrad_conv2d_wino', ctypes.byref(d), mode, _p(inp), _p(wp), _p(bias), _p(ref), _p(out),
                float(slope), float(gain), _p(ws), ctypes.c_longlong(nbytes), _stream())
     return out
 

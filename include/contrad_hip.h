@@ -96,6 +96,20 @@ int contrad_conv2d_wino(const contrad_conv_desc* d, int mode, const float* in, c
                         const float* ref, float* out, float slope, float gain, float* workspace,
                         long long workspace_bytes, contrad_stream_t stream);
 
+/* Winograd F(4x4, 3x3) in fp32 (csrc/wino44.h) for the same 3x3 stride-1 pad-1 layers on power-of-two maps >= 16x16 whose
+ * input channels are a multiple of 32 and output channels a multiple of 64: 2.25 multiply-adds per output instead of 4
+ * (F(2x2, 3x3)) or 9 (direct); standard interpolation points (0, +-1, +-2, inf), round-off rel-L2 1 - 5e-6 against fp64 (the
+ * contract of this path is 1e-3; reference as above: F.conv2d of models/gan/sndcgan.py:91-109, stylegan2/layers.py:115-121).
+ * contrad_conv2d_fwd_add / contrad_conv2d_dgrad_ws choose it ahead of F(2x2, 3x3) for launches of a full round of its items
+ * (512 output pixels x 64 output channels per CU) -- their *_workspace_bytes then cover 36 * C * K floats --;
+ * contrad_conv2d_wino44 forces it on any shape contrad_conv2d_wino44_ok accepts (arguments and semantics of
+ * contrad_conv2d_wino, modes 0 and 1). */
+int contrad_conv2d_wino44_ok(const contrad_conv_desc* d, int mode);
+long long contrad_conv2d_wino44_workspace_bytes(const contrad_conv_desc* d);
+int contrad_conv2d_wino44(const contrad_conv_desc* d, int mode, const float* in, const float* wp, const float* bias,
+                          const float* ref, float* out, float slope, float gain, float* workspace,
+                          long long workspace_bytes, contrad_stream_t stream);
+
 /* dwp[(kh,kw,c),k] = sum_{n,ho,wo} x[n,ho*s-p+kh,wo*s-p+kw,c] * gy[n,ho,wo,k]      (split over the
  * n*ho*wo axis into deterministic partial slabs in `workspace`, then reduced in fixed order).
  * dbias (may be NULL; needs C, K, ldx, ldy multiples of 4): dbias[k] = sum_{n,ho,wo} gy[n,ho,wo,k], the bias
@@ -110,13 +124,14 @@ int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm, int* bn);
  * a rectangle of pixels that share their non-padding taps), 4 = the accumulator-stationary weight-gradient kernel of
  * the 32 -> 32 channel 3x3 layers (wgrad_c32_kernel, mode 2 only), 5 = the single-output 1x1 layer (fwd_k1_kernel, mode 0
  * only: the 512 -> 1 logit of the heads), 6 = the weight-stationary kernel of the 32 -> 32 channel 3x3 stride-1 layers
- * (conv_c32_kernel<mode>, modes 0 and 1), 7 = Winograd F(2x2, 3x3) (wino_kernel<mode>, modes 0 and 1; with a workspace) / F(3x3, 2x2) (wino_wgrad_kernel, mode 2);
- * negative = bad descriptor.  Profiling aid. */
+ * (conv_c32_kernel<mode>, modes 0 and 1), 7 = Winograd F(2x2, 3x3) (wino_kernel<mode>, modes 0 and 1; with a workspace) / F(3x3, 2x2) (wino_wgrad_kernel, mode 2),
+ * 8 = F(2x2, 2x2) on the phases of the 4x4 stride-2 layers (wino22_kernel<mode> / wino22_wgrad_kernel), 9 = Winograd F(4x4, 3x3)
+ * (wino44_kernel<mode>, modes 0 and 1; with a workspace);  negative = bad descriptor.  Profiling aid. */
 int contrad_conv2d_path(const contrad_conv_desc* d, int mode);
 /* Share of the layer's nominal multiply-adds (2*N*Ho*Wo*K*C*KH*KW, the count every roofline here is quoted on, padding
  * taps included as in the reference's dense layer) that the kernel actually issues: 1 except on pixel-major tiles (path
  * 3), which skip the tap-positions that read padding (0.69 for a 3x3 pad-1 layer on a 4x4 map), and on the Winograd path
- * (7): 4/9, the transform-domain multiply-adds.  (A weight-gradient tile
+ * (7): 4/9, (8): 9/16, (9): 1/4 -- the transform-domain multiply-adds.  (A weight-gradient tile
  * that also sums the bias gradient visits everything: not reflected.)  Profiling aid. */
 double contrad_conv2d_executed_fraction(const contrad_conv_desc* d, int mode);
 /* Workgroups (256 threads each) of the main igemm launch this geometry gets for `mode` (with_workspace != 0: the plan the

@@ -71,16 +71,20 @@ def test_launch_plans_are_host_logic(built):
             # forward of 256 -> 512 channels: 384 items of 128 tiles x 64 channels are a round and a half of the 256 CUs, where
             # the direct kernel (pixel-major tiles, padding taps skipped) is faster
             Ho = (H + 2 * p - k) // s + 1
+            # ... and, later in round 6, forward and data gradient of the 3x3 layers on 16x16 / 8x8 maps on F(4x4, 3x3) (path 9,
+            # csrc/wino44.h: 1536 / 768 items of 512 pixels x 64 channels; the 4x4 maps stay on F(2x2, 3x3): 384 items there)
             if k == 3:
-                want = 7           # (the weight gradient too: wino_wgrad_kernel, F(3x3, 2x2), one block per CU over split tile ranges)
+                want = 9 if (mode != 2 and H >= 8) else 7   # (the weight gradient: wino_wgrad_kernel, F(3x3, 2x2), one block per CU over split tile ranges)
             elif not (mode == 0 and C == 256):
                 want = 8
             else:
                 want = 3
             assert path(ctypes.byref(d), mode) == want, (H, C, K, mode)
-            if want in (7, 8):
+            if want in (7, 8, 9):
                 assert built.raw('contrad_conv2d_grid_blocks')(ctypes.byref(d), mode, 1) == 256
-                frac = 4.0 / 9.0 if want == 7 else (9.0 / 16.0 if mode != 2 else 1.0)
+                frac = 0.25 if want == 9 else 4.0 / 9.0 if want == 7 else (9.0 / 16.0 if mode != 2 else 1.0)
+                if want == 9:
+                    assert built.raw('contrad_conv2d_wino44_ok')(ctypes.byref(d), mode) == 1
                 if mode != 2 or want == 7:
                     assert abs(built.raw('contrad_conv2d_executed_fraction')(ctypes.byref(d), mode) - frac) < 1e-12
                 assert built.raw('contrad_conv2d_wino_ok')(ctypes.byref(d), mode) == 1
@@ -89,9 +93,13 @@ def test_launch_plans_are_host_logic(built):
             want_bn = 64 if (mode == 1 and C == 64) else 128        # dgrad's columns are the input channels
             assert (bm.value, bn.value) == (128, want_bn), (H, C, K, mode, bm.value, bn.value)
         want_ws = 16 * C * K * 4 if k == 3 else 36 * C * K * 4       # the transformed filter: 16 planes / 4 phases x 9 planes
-        assert built.raw('contrad_conv2d_fwd_workspace_bytes')(ctypes.byref(d)) == (want_ws if not (k == 4 and C == 256) else 0)
-        assert built.raw('contrad_conv2d_dgrad_workspace_bytes')(ctypes.byref(d)) == want_ws
+        plan_ws = 36 * C * K * 4 if (k == 3 and H >= 8) else want_ws  # (F(4x4, 3x3): 36 planes)
+        assert built.raw('contrad_conv2d_fwd_workspace_bytes')(ctypes.byref(d)) == (plan_ws if not (k == 4 and C == 256) else 0)
+        assert built.raw('contrad_conv2d_dgrad_workspace_bytes')(ctypes.byref(d)) == plan_ws
         assert built.raw('contrad_conv2d_wino_workspace_bytes')(ctypes.byref(d), 0) == want_ws
+        if k == 3:
+            assert built.raw('contrad_conv2d_wino44_workspace_bytes')(ctypes.byref(d)) == 36 * C * K * 4
+            assert built.raw('contrad_conv2d_wino44_ok')(ctypes.byref(d), 0) == (1 if H >= 8 else 0)
         # weight gradient: 256 / (row blocks x 64-wide k blocks) split slabs of the packed gradient + the bias partials
         splits = 256 // ((C // 64) * (K // 64)) if k == 3 else 256 // ((4 * C // 128) * (K // 64))
         assert built.raw('contrad_conv2d_wgrad_workspace_bytes')(ctypes.byref(d)) == splits * (k * k * C + 1) * K * 4
@@ -125,6 +133,13 @@ def test_launch_plans_are_host_logic(built):
     assert wok(ctypes.byref(_desc(8, 16, 24, 64, 3, 1, 1)), 0) == 0 and wok(ctypes.byref(_desc(8, 16, 32, 48, 3, 1, 1)), 0) == 0
     assert wok(ctypes.byref(_desc(8, 16, 32, 48, 3, 1, 1)), 1) == 0 and wok(ctypes.byref(_desc(8, 16, 64, 48, 3, 1, 1)), 1) == 1
     assert wok(ctypes.byref(_desc(8, 12, 32, 64, 3, 1, 1)), 0) == 0 and wok(ctypes.byref(_desc(8, 16, 32, 64, 3, 2, 1)), 0) == 0
+    # F(4x4, 3x3): a full round of its 512-pixel items (from 230), input channels % 32, maps >= 8x8
+    w44 = built.raw('contrad_conv2d_wino44_ok')
+    assert path(ctypes.byref(_desc(256, 16, 128, 128, 3, 1, 1)), 0) == 9 and path(ctypes.byref(_desc(256, 16, 128, 128, 3, 1, 1)), 1) == 9   # 256 items
+    assert path(ctypes.byref(_desc(16, 64, 256, 256, 3, 1, 1)), 0) == 9         # StyleGAN2_512, 64x64 maps of 16 images: 512 items
+    assert path(ctypes.byref(_desc(16, 16, 512, 512, 3, 1, 1)), 0) != 9         # 64 items
+    assert w44(ctypes.byref(_desc(8, 16, 48, 64, 3, 1, 1)), 0) == 0 and w44(ctypes.byref(_desc(8, 4, 64, 64, 3, 1, 1)), 0) == 0
+    assert w44(ctypes.byref(_desc(8, 8, 64, 64, 3, 1, 1)), 0) == 1 and w44(ctypes.byref(_desc(8, 8, 64, 64, 3, 1, 1)), 2) == 0
     assert built.raw('contrad_conv2d_dgrad_workspace_bytes')(ctypes.byref(_desc(192, 8, 260, 512, 4, 2, 1))) == 0   # strided (not F(2x2,2x2): Cin)
     # contrastive column splits: ~256 blocks
     assert built.raw('contrad_contrast_workspace_bytes')(1024, 128) == 16 * 1024 * 128 * 4

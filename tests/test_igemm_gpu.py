@@ -282,7 +282,9 @@ def test_full_size_sndcgan_layer_linearity():
     # batch independence: the first 8 images alone give the same rows (a small batch may be planned with another
     # tile / split-K, i.e. another fp32 summation order, so this is not bitwise), and a repeated call IS bitwise equal
     y8 = ops.conv2d_fwd(x[:8].contiguous(), wp, None, 128, 3, 3, 1, 1)
-    assert rel(y[:8], y8) < 1e-5
+    # (the full batch runs on Winograd F(4x4, 3x3), the eight images on the direct kernel: 1.3e-5 apart -- round-off of the
+    # 6x6 transforms, csrc/wino44.h; the contract is 1e-3)
+    assert rel(y[:8], y8) < 1e-4
     assert torch.equal(y, ops.conv2d_fwd(x, wp, None, 128, 3, 3, 1, 1))
     # adjoint identity <conv(x), gy> == <x, dgrad(gy)>
     gy = torch.randn_like(y)

@@ -1,4 +1,4 @@
-"""GPU parity: Winograd F(2x2, 3x3) kernel (csrc/wino.h) through the C ABI vs PyTorch-CPU fp32 F.conv2d -- the reference's
+"""GPU parity: Winograd F(2x2, 3x3) / F(4x4, 3x3) kernels (csrc/wino.h, wino44.h) through the C ABI vs PyTorch-CPU fp32 F.conv2d -- the reference's
 own arithmetic for these layers (models/gan/sndcgan.py:91-109, models/gan/stylegan2/layers.py:115-121).
 
 ``contrad_conv2d_wino`` forces the kernel on every shape it supports (the automatic plan of conv2d_fwd / conv2d_dgrad only
@@ -241,6 +241,78 @@ def test_wino_rejects_what_it_cannot_run():
             ops.conv2d_wino(0, x, wp, C, K)
 
 
+# F(4x4, 3x3) (csrc/wino44.h): maps >= 8x8, input channels % 32, output channels % 64.  Round-off one order above F(2x2, 3x3)
+# (interpolation points 0, +-1, +-2: observed 6e-7 ... 5e-6 of the tensor's max), two orders below the contract.
+TIGHT44 = 1e-4
+CASES44 = [
+    (3, 16, 16, 32, 64),      # two images per item (box = image + halo of zeros), ragged last item
+    (2, 32, 32, 32, 128),     # 4 x 8 tiles: one patch wide, two high; two cout blocks
+    (5, 8, 8, 64, 64),        # eight images per item, ragged: the half-waves of a pass sit in different images
+    (2, 64, 32, 32, 64),      # non-square: four patches high
+    (3, 16, 32, 64, 192),     # one patch per image, three cout blocks
+    (40, 16, 16, 32, 64),     # several items per block of the persistent grid
+    (17, 8, 8, 32, 192),
+    (1, 128, 64, 32, 64),     # 8 x 2 patches: boxes with real halos on every side
+    (9, 16, 16, 128, 64),     # 16 chunks: eight pairs
+]
+
+
+@pytest.mark.parametrize('case', CASES44)
+def test_wino44_forward(case):
+    N, H, W, C, K = case
+    x, w, b = _inputs(N, H, W, C, K, 21)
+    add = torch.randn(N, H, W, K, generator=torch.Generator().manual_seed(22))
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1).permute(0, 2, 3, 1)
+    dev = torch.device('cuda')
+    wp = ops.pack_weight(w).to(dev)
+    y = ops.conv2d_wino(0, x.to(dev), wp, C, K, bias=b.to(dev), slope=0.2, gain=1.3, f44=True)
+    assert rel(y.cpu(), F.leaky_relu(ref, 0.2) * 1.3) < TIGHT44
+    y = ops.conv2d_wino(0, x.to(dev), wp, C, K, bias=None, ref=add.to(dev), slope=1.0, gain=1.0, f44=True)
+    assert rel(y.cpu(), F.conv2d(x.permute(0, 3, 1, 2), w, None, padding=1).permute(0, 2, 3, 1) + add) < TIGHT44
+    # against F(2x2, 3x3) where both run: the two transforms agree to round-off
+    if C % 16 == 0 and K % 64 == 0:
+        y2 = ops.conv2d_wino(0, x.to(dev), wp, C, K, bias=None, ref=add.to(dev), slope=1.0, gain=1.0)
+        assert rel(y, y2) < TIGHT44
+
+
+@pytest.mark.parametrize('case', CASES44)
+def test_wino44_data_gradient(case):
+    N, H, W, K, C = case          # (roles swapped: gy has K channels, dx has C; the kernel needs K % 32 == 0, C % 64 == 0)
+    g = torch.Generator().manual_seed(23)
+    gy = torch.randn(N, H, W, K, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.1
+    act = torch.randn(N, H, W, C, generator=g)
+    ref = F.conv_transpose2d(gy.permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1)
+    dev = torch.device('cuda')
+    wp = ops.pack_weight(w).to(dev)
+    dx = ops.conv2d_wino(1, gy.to(dev), wp, C, K, f44=True)
+    assert rel(dx.cpu(), ref) < TIGHT44
+    dx = ops.conv2d_wino(1, gy.to(dev), wp, C, K, ref=act.to(dev), slope=0.2, gain=1.5, f44=True)
+    assert rel(dx.cpu(), ref * torch.where(act > 0, 1.5, 0.3)) < TIGHT44
+
+
+def test_wino44_channel_sliced_views_determinism_and_rejects():
+    N, H, W, C, K = 6, 16, 16, 32, 64
+    x, w, b = _inputs(N, H, W, C, K, 25)
+    dev = torch.device('cuda')
+    wp = ops.pack_weight(w).to(dev)
+    xb = torch.randn(N, H, W, C + 12, device=dev)
+    xb[..., 4:4 + C] = x.to(dev)
+    yb = torch.full((N, H, W, K + 16), 7.0, device=dev)
+    ops.conv2d_wino(0, xb[..., 4:4 + C], wp, C, K, bias=b.to(dev), slope=0.1, gain=1.0, out=yb[..., 8:8 + K], f44=True)
+    ref = F.leaky_relu(F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1), 0.1).permute(0, 2, 3, 1)
+    assert rel(yb[..., 8:8 + K].cpu(), ref) < TIGHT44
+    assert (yb[..., :8] == 7.0).all() and (yb[..., 8 + K:] == 7.0).all()
+    y1 = ops.conv2d_wino(0, x.to(dev), wp, C, K, bias=b.to(dev), f44=True)
+    y2 = ops.conv2d_wino(0, x.to(dev), wp, C, K, bias=b.to(dev), f44=True)
+    assert torch.equal(y1, y2)
+    y3 = ops.conv2d_wino(0, x[2:4].contiguous().to(dev), wp, C, K, bias=b.to(dev), f44=True)     # (an item = two images)
+    assert torch.equal(y1[2:4], y3)
+    for (h, c, k) in ((4, 32, 64), (16, 16, 64), (16, 32, 32), (12, 32, 64)):
+        with pytest.raises(RuntimeError):
+            ops.conv2d_wino(0, torch.zeros(2, h, h, c, device=dev), torch.zeros(9 * c, k, device=dev), c, k, f44=True)
+
+
 # the 3x3 stride-1 layers of the BASELINE workloads: (N, H, C) -- SNDCGAN at 3N = 1536, StyleGAN2_512 at 3N = 48
 PLANNED = [(1536, 16, 128), (1536, 8, 256), (48, 128, 128), (48, 64, 256), (48, 32, 512), (48, 256, 64)]
 
@@ -258,18 +330,18 @@ def test_the_plan_takes_winograd_at_the_baseline_shapes_and_matches_torch(shape)
     b = torch.randn(K, generator=g)
     wp = ops.pack_weight(w).to(dev)
     d = ops.make_desc(N, H, H, C, K, 3, 3, 1, 1, C, K, wp.stride(0))
-    assert lib().raw('contrad_conv2d_path')(ctypes.byref(d), 0) == 7
-    assert lib().raw('contrad_conv2d_path')(ctypes.byref(d), 1) == 7
-    assert abs(lib().raw('contrad_conv2d_executed_fraction')(ctypes.byref(d), 0) - 4.0 / 9.0) < 1e-12
+    assert lib().raw('contrad_conv2d_path')(ctypes.byref(d), 0) == 9      # (F(4x4, 3x3) on all of them: maps >= 8x8, full rounds)
+    assert lib().raw('contrad_conv2d_path')(ctypes.byref(d), 1) == 9
+    assert abs(lib().raw('contrad_conv2d_executed_fraction')(ctypes.byref(d), 0) - 0.25) < 1e-12
     xd = x.to(dev)
     y = ops.conv2d_fwd(xd, wp, b.to(dev), K, 3, 3, 1, 1, slope=0.1, gain=1.0)
     sel = [0, 1, N - 2, N - 1] if H <= 64 else [0, N - 1]
     xs = x[sel]
     ref = F.leaky_relu(F.conv2d(xs.permute(0, 3, 1, 2), w, b, padding=1), 0.1).permute(0, 2, 3, 1)
-    assert rel(y[sel].cpu(), ref) < TIGHT
+    assert rel(y[sel].cpu(), ref) < TIGHT44
     dx = ops.conv2d_dgrad(y, wp, (N, H, H, C), 3, 3, 1, 1, act_ref=xd, slope=0.1, gain=1.0)
     refd = F.conv_transpose2d(y[sel].cpu().permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1) * torch.where(xs > 0, 1.0, 0.1)
-    assert rel(dx[sel].cpu(), refd) < TIGHT
+    assert rel(dx[sel].cpu(), refd) < TIGHT44
     # weight gradient at full size: Winograd by the plan; against the direct kernels' result on HALF the images twice (linearity:
     # dW(all) = dW(first half) + dW(second half), each half small enough for ... the same plan) and against PyTorch-CPU on a
     # sub-batch through the forced entry point
