@@ -24,6 +24,11 @@
 // At the end of an item the waves exchange accumulators through LDS (both V stages: exactly 8 waves x 9 xi x 4 rows x 64 lanes
 // x 4 B) in four passes of four accumulator rows; in pass q wave (half, group g) owns row 4q + g: reads all 36 M values of
 // its element, runs A^T M A (100 operations), the epilogue, and stores 16 pixels x its cout.
+// Measured (tools/micro/wino44_proto.hip, one MI355X, kernel alone, F(2x2, 3x3) in the step beside it): 1536 x 16^2 x 128 -> 128
+// 346 us (492), 1536 x 8^2 x 256 312 (476), 48 x 128^2 x 128 655 (1110), 48 x 64^2 x 256 590 (1017), 48 x 32^2 x 512 555 (957),
+// 48 x 256^2 x 64 793 (1297).  Where the time goes at 128 channels (ablations W44_NO_*: timing only, results wrong): MFMAs +
+// fragment reads alone 220 us (the matrix pipe full at the clock the chip holds), + epilogue 58, + transform 24, + raw 16, + U 12,
+// + 19 of them together.
 #pragma once
 
 namespace wino44 {
@@ -313,7 +318,8 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
     const float* rbase = p.ref ? p.ref + (size_t)it.n_first * p.H * p.W * p.ldo : ybase;
     const unsigned dcol = (unsigned)p.ldo * 4u, drow = (unsigned)(p.W * p.ldo) * 4u;
     const float bj = (MODE == MODE_FWD && p.bias) ? p.bias[it.kb * 64 + wn * 32 + l31] : 0.f;
-    const float ron = p.ref ? 1.f : 0.f;          // (uniform; with no second operand the loads below are off and return zeros)
+    // (with no second operand the loads below are off and return zeros: FWD adds them; DGRAD's two gains are then both 1)
+    const float ga = p.ref ? g1 : 1.f, gb = p.ref ? g0 : 1.f;
     float4* xw = reinterpret_cast<float4*>(smem) + (w8 * 9) * 64 + lane;
     // reader: the wave of (cout half wn, group g') is w8' = (g' >> 1) * 4 + (g' & 1) * 2 + wn
     const float* xr = smem + (wn * 9 * 64 + lane) * 4 + grp;
@@ -340,7 +346,7 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
       float S[6][4];
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
-        if ((a & 1) == 0) __builtin_amdgcn_sched_barrier(0);      // (two rows of M in flight at a time: all 36 at once spill)
+        if ((a & 1) == 0) __builtin_amdgcn_sched_barrier(0);      // (two rows of M in flight at a time; 3 or 6 rows: the same time)
         float m[6];
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
@@ -357,12 +363,10 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if constexpr (MODE == MODE_DGRAD) {
-            const float gsel = (rv[j][i] > 0.f) ? g1 : g0;
-            v[i] *= (ron > 0.f) ? gsel : 1.f;
+            v[i] *= (rv[j][i] > 0.f) ? ga : gb;
           } else {
             v[i] += bj;
-            v[i] *= (v[i] > 0.f) ? g1 : g0;
-            v[i] += rv[j][i];
+            v[i] = __builtin_fmaf(v[i], (v[i] > 0.f) ? g1 : g0, rv[j][i]);
           }
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rsY, (int)voff, (int)(s0 + (unsigned)i * drow + (unsigned)j * dcol), 0);
         }

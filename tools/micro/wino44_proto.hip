@@ -142,8 +142,8 @@ int main(int argc, char** argv) {
   if (argc > 2 && argv[2][0] == 'z') g_data = 2;
   if (!(argc > 3 && argv[3][0] == 's')) {
     double worst = 0;
-    worst = std::max(worst, check(0, 3, 16, 16, 16, 64));
-    worst = std::max(worst, check(1, 3, 16, 16, 64, 16));
+    worst = std::max(worst, check(0, 3, 16, 16, 32, 64));
+    worst = std::max(worst, check(1, 3, 16, 16, 64, 32));
     worst = std::max(worst, check(0, 2, 32, 64, 32, 64));
     worst = std::max(worst, check(1, 1, 64, 32, 128, 32));
     worst = std::max(worst, check(0, 17, 16, 16, 32, 128));
