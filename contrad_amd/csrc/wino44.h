@@ -21,20 +21,21 @@
 // LDS holds V only (double-buffered, 2 x 36 KB) and the raw input box (2 x 26 KB):
 //   * waves 4-7 ("movers"): the raw input box of the item (every pixel once per block and chunk), global -> registers -> LDS;
 //   * waves 0-3 ("transform"): one (tile, channel) per thread: 36 raw values -> B^T d B (144 FMA-class operations) -> V.
-// At the end of an item the waves exchange accumulators through LDS (both V stages: exactly 8 waves x 9 xi x 4 rows x 64 lanes
+// At the end of an item the waves exchange accumulators through LDS (both V stages: exactly 4 rows x 8 waves x 9 xi x 64 lanes
 // x 4 B) in four passes of four accumulator rows; in pass q wave (half, group g) owns row 4q + g: reads all 36 M values of
 // its element, runs A^T M A (100 operations), the epilogue, and stores 16 pixels x its cout.
 // Measured (tools/micro/wino44_proto.hip, one MI355X, kernel alone, F(2x2, 3x3) in the step beside it): 1536 x 16^2 x 128 -> 128
-// 346 us (492), 1536 x 8^2 x 256 312 (476), 48 x 128^2 x 128 655 (1110), 48 x 64^2 x 256 590 (1017), 48 x 32^2 x 512 555 (957),
-// 48 x 256^2 x 64 793 (1297).  Where the time goes at 128 channels (ablations W44_NO_*: timing only, results wrong): MFMAs +
-// fragment reads alone 220 us (the matrix pipe full at the clock the chip holds), + epilogue 58, + transform 24, + raw 16, + U 12,
-// + 19 of them together.
+// 336 us (492), 1536 x 8^2 x 256 305 (476), 48 x 128^2 x 128 630 (1110), 48 x 64^2 x 256 580 (1017), 48 x 32^2 x 512 540 (957),
+// 48 x 256^2 x 64 752 (1297).  Where the time goes at 128 channels (ablations W44_NO_*: timing only, results wrong): MFMAs +
+// fragment reads alone 220 us (the matrix pipe full at the clock the chip holds), + epilogue 48, + transform 24, + raw 16, + U 12,
+// + 19 of them together.  Counters: matrix pipe busy 0.57 at 2.19 GHz (F(2x2, 3x3): 0.81 at 2.0 - 2.1).
 #pragma once
 
 namespace wino44 {
 
 constexpr int NT = 32;                          // tiles per item
-constexpr int KQS = NT * 4;                     // dwords per (plane, k-quad): 32 rows x 4
+constexpr int KQS = NT * 4;                     // dwords per (plane, k-quad): 32 rows x 4 (the two k-quads of a transform thread's
+                                                // ds_write_b32 pair share banks: 2-way, free on stores -- 16 dwords of padding: no change)
 constexpr int PL = 2 * KQS;                     // per plane
 constexpr int V_SZ = 36 * PL;                   // 9 216 dwords
 constexpr int RPS = 10;                         // dwords per raw pixel (8 channels + 2): the four tiles of a 32-lane read group are
@@ -320,9 +321,12 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
     const float bj = (MODE == MODE_FWD && p.bias) ? p.bias[it.kb * 64 + wn * 32 + l31] : 0.f;
     // (with no second operand the loads below are off and return zeros: FWD adds them; DGRAD's two gains are then both 1)
     const float ga = p.ref ? g1 : 1.f, gb = p.ref ? g0 : 1.f;
-    float4* xw = reinterpret_cast<float4*>(smem) + (w8 * 9) * 64 + lane;
+    // exchange area: [accumulator row r of the pass (4)][wave (8)][xi (9)][lane (64)] dwords: written as 36 ds_write_b32, read
+    // back conflict-free (lanes consecutive).  (As [wave][xi][lane] float4 the readers' dwords were 4 apart: 4-way bank conflicts
+    // on every one of the 144 reads of an item, 40 % of the kernel's LDS cycles.)
+    float* xw = smem + (w8 * 9) * 64 + lane;
     // reader: the wave of (cout half wn, group g') is w8' = (g' >> 1) * 4 + (g' & 1) * 2 + wn
-    const float* xr = smem + (wn * 9 * 64 + lane) * 4 + grp;
+    const float* xr = smem + (grp * 72 + wn * 9) * 64 + lane;
 #ifdef W44_NO_EPILOGUE
     if (p.N < 0)
 #endif
@@ -341,7 +345,8 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
           rv[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)voff, (int)(s0 + (unsigned)i * drow + (unsigned)j * dcol), 0));
 #pragma unroll
       for (int xi = 0; xi < 9; ++xi)
-        xw[xi * 64] = make_float4(acc[xi][4 * q], acc[xi][4 * q + 1], acc[xi][4 * q + 2], acc[xi][4 * q + 3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xw[(r * 72 + xi) * 64] = acc[xi][4 * q + r];
       __syncthreads();
       float S[6][4];
 #pragma unroll
@@ -351,7 +356,7 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
           const int xi36 = a * 6 + b, gq = xi36 / 9, xq = xi36 - gq * 9;
-          m[b] = xr[(((gq >> 1) * 4 + (gq & 1) * 2) * 9 + xq) * 256];
+          m[b] = xr[(((gq >> 1) * 4 + (gq & 1) * 2) * 9 + xq) * 64];
         }
         at6(m[0], m[1], m[2], m[3], m[4], m[5], S[a]);
       }
