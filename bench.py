@@ -502,9 +502,10 @@ def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=
                     "launches_per_step": cnt / nprof_steps, "avg_launch_ms": round(tsum / cnt * 1e3, 4),
                     "algorithmic_gflop_per_launch": round(xsum / cnt / 1e9, 2),
                     "nominal_gflop_per_launch": round(fsum / cnt / 1e9, 2),
-                    "flop_convention": "achieved / frac price the multiply-adds the kernel issues (Winograd F(2x2,3x3) / "
-                                       "F(3x3,2x2), contrad_conv2d_path == 7: the transform-domain products, 4/9 of the dense "
-                                       "layer's; pixel-major tiles, path 3, skip the tap-positions that read zero padding on "
+                    "flop_convention": "achieved / frac price the multiply-adds the kernel issues (Winograd: the transform-domain "
+                                       "products -- F(4x4,3x3), contrad_conv2d_path == 9: 1/4 of the dense layer's; F(2x2,3x3) / "
+                                       "F(3x3,2x2), path 7: 4/9; F(2x2,2x2) on the phases of the strided layers, path 8: 9/16; "
+                                       "pixel-major tiles, path 3, skip the tap-positions that read zero padding on "
                                        "the 4x4 / 8x8 maps: contrad_conv2d_executed_fraction); nominal_* price the same time on the "
                                        "dense layer 2*N*Ho*Wo*K*C*KH*KW of the reference (SURVEY.md 8d) and may exceed the "
                                        "issued figure; peak = 157.3 TFLOP/s at 2.4 GHz, the clock the counters measured "
@@ -512,8 +513,8 @@ def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=
                     "schema": 2,    # 1 (rounds 1 - 4): achieved / frac on the NOMINAL count; 2: on the multiply-adds issued
                     "bracket": "HIP events around the C-ABI call on its stream" +
                                (" (igemm WGRAD kernel + its wgrad_reduce_kernel)" if "<2," in dom else "") +
-                               (" (wino_filter_kernel + wino_kernel: the filter transform G g G^T is redone by every call)"
-                                if dom.startswith("wino_kernel") else "") +
+                               (" (filter kernel + main kernel: the filter transform G g G^T is redone by every call)"
+                                if dom.startswith(("wino_kernel", "wino22_kernel", "wino44_kernel")) else "") +
                                (" (wino_wgrad_kernel + wgrad_reduce_kernel)" if dom.startswith("wino_wgrad") else "") +
                                ("; the timed region replays one captured hipGraph per step, so the bracketed launches are "
                                 "those of %d eager steps run right after it" % nprof_steps if graph_run else ""),
@@ -685,7 +686,7 @@ def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=
                                                   "nominal_frac": round(n_local / tg * gfpi / 1e12 / PEAK_FP32_MFMA, 4),
                                                   "flop_per_image": gfpi,
                                                   "note": "whole generator step priced at SURVEY.md 8(d)'s nominal FLOPs per "
-                                                          "image against the fp32 MFMA peak (the Winograd layers issue 4/9 of "
+                                                          "image against the fp32 MFMA peak (the Winograd layers issue 1/4 ... 9/16 of "
                                                           "their share)"}},
                       "what": "generator step (G forward with grad -> augment -> D -> loss_G_fn -> backward through D, the "
                               "augmentation and G -> Adam on G), %s, %d timed steps; not part of `value`" % (g_launch, reps)}

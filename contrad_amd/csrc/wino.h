@@ -722,15 +722,23 @@ __device__ __forceinline__ void wbody(const WArgs& p, float* smem) {
     for (int xi = 0; xi < 8; ++xi) {
       if (xi + 1 < 8) frags(xi + 1, (xi + 1) & 1);
       if constexpr (ROLE == 0) {
+#ifndef WINO_WG_ABL_NO_TR
         if (xi == 0) read_raw(1 - P);
         if (xi == 1) { col_stage(0); col_stage(1); }
         if (xi == 2) { col_stage(2); col_stage(3); }
         if (xi >= 3 && xi < 7) row_stage_store(nxt, xi - 3);
+#endif
       } else {
+#ifndef WINO_WG_ABL_NO_RAW
         if (xi == 0) store_raw(P);
         if (xi == 1) load_raw();
+#endif
+#ifndef WINO_WG_ABL_NO_GYT
         if (xi == 3) gy_stage_store(nxt);
+#endif
+#ifndef WINO_WG_ABL_NO_GY
         if (xi == 5) load_gy();
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

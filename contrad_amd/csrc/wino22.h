@@ -243,8 +243,9 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
   // (last: the item's last chunk.  Its prefetch loads are issued AFTER the epilogue instead -- their 28 / 20 registers are what
   // the epilogue's second operand needs; with them in flight across the epilogue the kernel spilled 70 - 100 registers, part
   // of them inside these loops)
-  auto chunk = [&](auto par, const bool last) {
+  auto chunk = [&](auto par, auto last_c) {
     constexpr int P = decltype(par)::value;
+    constexpr bool last = decltype(last_c)::value;
     constexpr int cur = P * BUF, nxt = BUF - cur;
     float4 fa[2], fb[2];
     fa[0] = *reinterpret_cast<const float4*>(smem + cur + rdA);
@@ -255,15 +256,21 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
         fa[(xi + 1) & 1] = *reinterpret_cast<const float4*>(smem + cur + rdA + (xi + 1) * VPL);
         fb[(xi + 1) & 1] = *reinterpret_cast<const float4*>(smem + cur + rdB + (xi + 1) * UPL);
       }
-      if constexpr (ROLE == 0) {
+      if constexpr (ROLE == 0) {      // (W22_ABL_*: ablation switches of tools/dev/ab_variants.sh -- timing only, results wrong)
+#ifndef W22_ABL_NO_TR
         if (xi == 0) read_raw(1 - P);
         if (xi == 2) row_ops();
         if (xi >= 3 && xi < 6) col_ops_store(nxt, xi - 3);
+#endif
+#ifndef W22_ABL_NO_U
         if (xi == 6) store_u(nxt);
         if (xi == 7 && !last) load_u();
+#endif
       } else {
+#ifndef W22_ABL_NO_RAW
         if (xi == 0) store_raw(P);
         if (xi == 1 && !last) load_raw();
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
       const float* a = (const float*)&fa[xi & 1];
@@ -285,44 +292,49 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
   };
 
   for (; w_cur < L; w_cur += nslots) {
-    for (int t = 0; t < NCH; t += 2) {
-      chunk(std::integral_constant<int, 0>{}, false);
-      chunk(std::integral_constant<int, 1>{}, t + 2 >= NCH);
+    for (int t = 0; t + 2 < NCH; t += 2) {
+      chunk(std::integral_constant<int, 0>{}, std::false_type{});
+      chunk(std::integral_constant<int, 1>{}, std::false_type{});
     }
+    chunk(std::integral_constant<int, 0>{}, std::false_type{});      // (the item's last pair: its own copy, no branch inside a chunk)
+    chunk(std::integral_constant<int, 1>{}, std::true_type{});
     // ---- output transform (per lane): s_a = m_a0 + m_a1, s'_a = m_a1 + m_a2;  Y00 = s_0 + s_1, Y10 = s_1 + s_2, Y01 = s'_0 + s'_1, Y11 = s'_1 + s'_2
     const Item it = decode(w_cur);
     const int cout = it.kb * 64 + wn * 32 + l31;
     float* ybase = p.y + (size_t)it.n_first * p.Hout * p.Wout * p.ldo;
     const __amdgpu_buffer_rsrc_t rsY = rsrc(ybase, true);
+    // (no second operand: its loads are off and return zeros -- FWD adds them, DGRAD's two gains are then both 1: no branch)
     const __amdgpu_buffer_rsrc_t rsR = rsrc(p.ref ? p.ref + (size_t)it.n_first * p.Hout * p.Wout * p.ldo : ybase, p.ref != nullptr);
+    const float ga = p.ref ? g1 : 1.f, gb = p.ref ? g0 : 1.f;
     const unsigned dcol = (unsigned)(OS * p.ldo) * 4u, drow = (unsigned)(OS * p.Wout * p.ldo) * 4u;
     const unsigned ph_off = DG ? (unsigned)((((it.ph >> 1) * p.Wout) + (it.ph & 1)) * p.ldo * 4) : 0u;
-    const unsigned lane_off = (lhi ? bit_off(2) : 0u) + ((wm & 1) ? bit_off(5) : 0u) + ((wm & 2) ? bit_off(6) : 0u) + (unsigned)(cout * 4) + ph_off;
+    // byte offset of accumulator row r = lane part (one register) + a wave-uniform part in the instructions' scalar offset
+    const unsigned lane_off = (lhi ? bit_off(2) : 0u) + (unsigned)((wn * 32 + l31) * 4);
+    const unsigned wave_off = ((wm & 1) ? bit_off(5) : 0u) + ((wm & 2) ? bit_off(6) : 0u) + (unsigned)(it.kb * 64 * 4) + ph_off;
     const int lane_img = (wm * 32 + 4 * lhi) >> p.sh_thw;
     const int img_lim = p.N - it.n_first - lane_img;
-    auto row_off = [&](int r) -> unsigned {
-      const int rbits = (r & 3) + 8 * (r >> 2);
-      const unsigned u = ((r & 1) ? bit_off(0) : 0u) + ((r & 2) ? bit_off(1) : 0u) + ((r & 4) ? bit_off(3) : 0u) + ((r & 8) ? bit_off(4) : 0u);
-      return ((rbits >> p.sh_thw) < img_lim) ? lane_off + u : OOB;
-    };
     const float bj = (MODE == MODE_FWD && p.bias) ? p.bias[cout] : 0.f;
+#ifdef W22_ABL_NO_EPI
+    if (p.N < 0)
+#endif
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {       // two halves of 8 accumulator rows: the second operand of 8 rows in flight at a time
-      float rv[8][4];
-      if (p.ref) {
+    for (int h = 0; h < 4; ++h) {       // four quarters of 4 accumulator rows: the second operand of 4 rows in flight at a time
+      float rv[4][4];
+      unsigned vo[4], so[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const unsigned o = row_off(h * 8 + q);
-          rv[q][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)o, 0, 0));
-          rv[q][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)(o + dcol), 0, 0));
-          rv[q][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)(o + drow), 0, 0));
-          rv[q][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)(o + drow + dcol), 0, 0));
-        }
+      for (int q = 0; q < 4; ++q) {
+        const int r = h * 4 + q, rbits = (r & 3) + 8 * (r >> 2);
+        vo[q] = ((rbits >> p.sh_thw) < img_lim) ? lane_off : OOB;
+        so[q] = wave_off + ((r & 1) ? bit_off(0) : 0u) + ((r & 2) ? bit_off(1) : 0u) + ((r & 4) ? bit_off(3) : 0u) + ((r & 8) ? bit_off(4) : 0u);
+        rv[q][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)vo[q], (int)so[q], 0));
+        rv[q][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)vo[q], (int)(so[q] + dcol), 0));
+        rv[q][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)vo[q], (int)(so[q] + drow), 0));
+        rv[q][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)vo[q], (int)(so[q] + drow + dcol), 0));
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < 4; ++q) {
         __builtin_amdgcn_sched_barrier(0);
-        const int r = h * 8 + q;
+        const int r = h * 4 + q;
         float s[3], s2[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -333,18 +345,16 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if constexpr (DG) {
-            if (p.ref) v[e] *= (rv[q][e] > 0.f) ? g1 : g0;
+            v[e] *= (rv[q][e] > 0.f) ? ga : gb;
           } else {
             v[e] += bj;
-            v[e] *= (v[e] > 0.f) ? g1 : g0;
-            if (p.ref) v[e] += rv[q][e];
+            v[e] = __builtin_fmaf(v[e], (v[e] > 0.f) ? g1 : g0, rv[q][e]);
           }
         }
-        const unsigned o = row_off(r);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[0]), rsY, (int)o, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[1]), rsY, (int)(o + dcol), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[2]), rsY, (int)(o + drow), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[3]), rsY, (int)(o + drow + dcol), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[0]), rsY, (int)vo[q], (int)so[q], 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[1]), rsY, (int)vo[q], (int)(so[q] + dcol), 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[2]), rsY, (int)vo[q], (int)(so[q] + drow), 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[3]), rsY, (int)vo[q], (int)(so[q] + drow + dcol), 0);
       }
     }
 #pragma unroll
@@ -630,14 +640,20 @@ __device__ __forceinline__ void wbody(const WArgs& p, float* smem) {
     for (int xi = 0; xi < 9; ++xi) {
       if (xi + 1 < 9) frags(xi + 1, (xi + 1) & 1);
       if constexpr (ROLE == 0) {
+#ifndef W22_ABL_NO_TR
         if (xi == 0) read_raw(1 - P);
         if (xi == 2) row_ops();
         if (xi >= 3 && xi < 6) col_ops_store(nxt, xi - 3);
+#endif
+#ifndef W22_ABL_NO_U
         if (xi == 6) gy_stage_store(nxt);
         if (xi == 7) load_gy();
+#endif
       } else {
+#ifndef W22_ABL_NO_RAW
         if (xi == 0) store_raw(P);
         if (xi == 1) load_raw();
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
