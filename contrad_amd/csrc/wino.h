@@ -231,7 +231,10 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) store_u(0, i);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) load_u(i);           // U 1
+    for (int i = 0; i < 3; ++i) store_raw(1, i);     // (raw stage 1 is read only after the second barrier)
+    load_raw3();                                     // raw 2 -- BEFORE U 1, the order the chunk loop keeps them in flight in: the
+#pragma unroll                                       // compiler's wait counts at the loop head are the merge of both ways in (with
+    for (int i = 0; i < 8; ++i) load_u(i);           // U 1   raw youngest here it drained the queue at the top of every chunk pair)
     step_u();
   }
   __syncthreads();
@@ -241,10 +244,6 @@ __device__ __forceinline__ void body(const Args& p, float* smem) {
     for (int c = 0; c < 4; ++c) col_stage(c);
 #pragma unroll
     for (int i = 0; i < 4; ++i) row_stage_store(0, i);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) store_raw(1, i);
-    load_raw3();                                     // raw 2
   }
   __syncthreads();
 
@@ -543,12 +542,13 @@ __device__ __forceinline__ void wbody(const WArgs& p, float* smem) {
   if constexpr (ROLE == 1) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int item = tid + 256 * i, px = item >> 4, cq = item & 15;
+      // (pieces past the box repeat pieces of its start -- the same load, the same store: no branch around the stores, whose
+      // joins made the compiler wait for gy's loads, in flight behind the raw ones, at the top of every chunk)
+      const int item = (tid + 256 * i) % (npx * 16), px = item >> 4, cq = item & 15;
       const int bhw = p.BH * p.BW;
       ximg[i] = px / bhw;
       const int r2 = px - ximg[i] * bhw;
       xr[i] = r2 / p.BW + p.r_org; xc[i] = r2 - (r2 / p.BW) * p.BW + p.c_org;      // relative to the chunk's first output pixel
-      if (px >= npx) xr[i] = -(1 << 20);                                             // never valid
       xfix[i] = ((ximg[i] * p.H + xr[i]) * p.W + xc[i]) * p.ldx * 4 + (cb * 64 + cq * 4) * 4;
       wrRaw[i] = px * 64 + ((cq ^ ((px & 1) * 8)) * 4);
     }
@@ -578,7 +578,7 @@ __device__ __forceinline__ void wbody(const WArgs& p, float* smem) {
   auto store_raw = [&](int stage) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (tid + 256 * i < npx * 16) *reinterpret_cast<float4*>(smem + W_RAW0 + stage * W_RAWSZ + wrRaw[i]) = rraw[i];
+      *reinterpret_cast<float4*>(smem + W_RAW0 + stage * W_RAWSZ + wrRaw[i]) = rraw[i];
   };
   auto load_gy = [&]() {
     const bool on = sg.q < q_end && sg.ng * p.CNIMG + gimg < p.N;
@@ -688,7 +688,9 @@ __device__ __forceinline__ void wbody(const WArgs& p, float* smem) {
     store_raw(0);
     load_raw();                // raw 1
     gy_stage_store(0);
-    load_gy();                 // gy 1
+    store_raw(1);              // (raw stage 1 is read only after the second barrier)
+    load_raw();                // raw 2 -- BEFORE gy 1, the order the chunk loop keeps them in flight in: the compiler's wait
+    load_gy();                 // gy 1     counts at the loop head are the merge of both ways in (else: vmcnt(0) at every chunk pair)
   }
   __syncthreads();
   if constexpr (ROLE == 0) {
@@ -697,9 +699,6 @@ __device__ __forceinline__ void wbody(const WArgs& p, float* smem) {
     for (int c = 0; c < 4; ++c) col_stage(c);
 #pragma unroll
     for (int i = 0; i < 4; ++i) row_stage_store(0, i);
-  } else {
-    store_raw(1);
-    load_raw();                // raw 2
   }
   __syncthreads();
 
