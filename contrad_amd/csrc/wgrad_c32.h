@@ -19,7 +19,8 @@
 #endif
 
 constexpr int WC_TH = 4, WC_TW = 32, WC_C = 32;
-constexpr int WC_XS = (WC_TH + 2) * (WC_TW + 2) * WC_C;      // floats of the x halo tile
+constexpr int WC_XS = 7 * 256 * 4;                            // floats of the x halo tile: 6 x 34 pixels x 32 channels = 6 528, padded to the
+                                                             // 7 float4 pieces per thread the block stores without a branch
 constexpr int WC_GS = WC_TH * WC_TW * WC_C;                  // floats of the gy tile
 constexpr int WC_MAX_BLOCKS = 512;                           // 2 blocks per CU resident (144 AGPRs + the prefetch registers)
 
@@ -58,26 +59,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_c32_kernel(const WgradC32Args a)
   // MFMAs per tile cover the memory latency inside the block (with load -> barrier -> compute -> barrier the matrix pipe
   // idled a third of the time: 102 TF/s).
   float4 rx[NX], rg[NG];
-  // per-thread pieces of a tile, fixed for the life of the block: element offset relative to the tile origin and which
-  // image borders would make the piece padding (bit 0 top, 1 bottom, 2 left, 3 right) -- no index arithmetic per tile
-  int offx[NX], offg[NG];
-  unsigned padx[NX];
+  // per-thread pieces of a tile, fixed for the life of the block: byte offset relative to the tile's top-left HALO pixel and
+  // which image borders would make the piece padding (4 bits per piece: 0 top, 1 bottom, 2 left, 3 right).  The loads are
+  // buffer loads whose offset becomes out-of-range (hardware zero fill) for padding: no branch per piece -- with `if (...)
+  // load` the fetch was eleven basic blocks, the compiler waited for the queue inside it and spilled four of the prefetched
+  // float4 right behind their loads (i.e. waited for them: the prefetch hid nothing)
+  unsigned offx[NX];
+  unsigned padx = 0;
+  constexpr unsigned WC_OOB = 0x80000000u;
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
     const int e = tid + 256 * i;
     const int q = e & 7, p = e >> 3;
     const int pr = p / (WC_TW + 2), pc = p - pr * (WC_TW + 2);
-    offx[i] = ((pr - 1) * a.W + (pc - 1)) * WC_C + q * 4;
-    padx[i] = (e >= (WC_TH + 2) * (WC_TW + 2) * (WC_C / 4)) ? 16u
-              : ((pr == 0 ? 1u : 0u) | (pr == WC_TH + 1 ? 2u : 0u) | (pc == 0 ? 4u : 0u) | (pc == WC_TW + 1 ? 8u : 0u));
+    offx[i] = (e >= (WC_TH + 2) * (WC_TW + 2) * (WC_C / 4)) ? WC_OOB : (unsigned)(((pr * a.W + pc) * WC_C + q * 4) * 4);
+    padx |= ((pr == 0 ? 1u : 0u) | (pr == WC_TH + 1 ? 2u : 0u) | (pc == 0 ? 4u : 0u) | (pc == WC_TW + 1 ? 8u : 0u)) << (4 * i);
   }
-#pragma unroll
-  for (int i = 0; i < NG; ++i) {
-    const int e = tid + 256 * i;
-    const int q = e & 7, p = e >> 3;
-    const int pr = p / WC_TW, pc = p - pr * WC_TW;
-    offg[i] = (pr * a.W + pc) * WC_C + q * 4;
-  }
+  // gy pieces: e = tid + 256 i -> pixel (row i, column tid >> 3), channel quad tid & 7: one offset + i rows
+  const unsigned offg0 = (unsigned)(((tid >> 3) * WC_C + (tid & 7) * 4) * 4);
+  const unsigned grow = (unsigned)(a.W * WC_C * 4);
   auto fetch = [&](long long t) {
     const int n = (int)(t / tpi);
     const int r = (int)(t - (long long)n * tpi);
@@ -88,16 +88,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_c32_kernel(const WgradC32Args a)
 #endif
     const size_t org = ((size_t)n * a.H * a.W + (size_t)(ty * WC_TH) * a.W + tx * WC_TW) * WC_C;
     const unsigned edge = (ty == 0 ? 1u : 0u) | (ty == a.tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) |
-                          (tx == a.tiles_x - 1 ? 8u : 0u) | 16u;                      // wave-uniform
-    const float* xo = a.x + org;
-    const float* go = a.gy + org;
+                          (tx == a.tiles_x - 1 ? 8u : 0u);                            // wave-uniform
+    // (base of x: the tile's top-left halo pixel -- for the first tile of the tensor a pointer just below it, never dereferenced)
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + org) - (size_t)(a.W + 1) * WC_C, 0, (int)0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy + org), 0, (int)0x80000000u, 0x00020000);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      rx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((padx[i] & edge) == 0) rx[i] = *reinterpret_cast<const float4*>(xo + offx[i]);
+      const unsigned v = ((padx >> (4 * i)) & edge) ? WC_OOB : offx[i];
+      rx[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)v, 0, 0));
     }
 #pragma unroll
-    for (int i = 0; i < NG; ++i) rg[i] = *reinterpret_cast<const float4*>(go + offg[i]);
+    for (int i = 0; i < NG; ++i)
+      rg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsg, (int)offg0, (int)((unsigned)i * grow), 0));
   };
   if (t0 < t1) fetch(t0);
   for (long long t = t0; t < t1; ++t) {
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_c32_kernel(const WgradC32Args a)
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int e = tid + 256 * i;
-      if (e < (WC_TH + 2) * (WC_TW + 2) * (WC_C / 4)) *reinterpret_cast<float4*>(Xs + (e >> 3) * WC_C + (e & 7) * 4) = rx[i];
+      *reinterpret_cast<float4*>(Xs + (e >> 3) * WC_C + (e & 7) * 4) = rx[i];
     }
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
