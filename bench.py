@@ -258,8 +258,9 @@ def _pmc_traffic(config, kernel):
                 # the engine names an instance by its first three
                 want = kernel.replace(' ', '')
                 for k, v in pmc.get('kernels', {}).items():
-                    kk = re.sub(r'wino(22|44)?::', '', k.replace(' ', '').replace('(anonymousnamespace)::', ''))
-                    kk = re.sub(r'^(wino(?:22|44)_kernel<\d+),\d+>', r'\1>', kk)
+                    kk = re.sub(r'wino(22|23|44)?::', '', k.replace(' ', '').replace('(anonymousnamespace)::', ''))
+                    kk = re.sub(r'^(wino(?:22|23|44)_kernel<\d+),\d+>', r'\1>', kk)
+                    kk = re.sub(r'^wino23_kernel<\d+>', 'wino23_kernel', kk)
                     if kk == want or kk == want[:-1] + ',false>':
                         ent = v
                         break

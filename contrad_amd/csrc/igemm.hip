@@ -817,6 +817,7 @@ int launch(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
 #include "wino.h"
 #include "wino22.h"
 #include "wino44.h"
+#include "wino23.h"
 
 // ---------------- Winograd F(2x2, 3x3) path (wino.h): 3x3 stride-1 pad-1 layers, forward and data gradient ----------------
 // Can the shape run on wino_kernel<mode> at all?  (input channels % 16, output channels % 64, power-of-two maps >= 4)
@@ -1043,6 +1044,72 @@ int launch_wino22(const contrad_conv_desc* d, const float* in, const float* wp, 
   if (nraw <= 5) return launch_wino22_inst<MODE, 5>(a, blocks, stream);
   if (nraw == 6) return launch_wino22_inst<MODE, 6>(a, blocks, stream);
   return launch_wino22_inst<MODE, 7>(a, blocks, stream);
+}
+
+// ---------------- F(2x2, 2x2) on the phases of the 3x3 stride-2 pad-0 layers (wino23.h): StyleGAN2's blurred conv2, forward ----------------
+// (input (2 Ho + 1) x (2 Wo + 1), power-of-two output grids >= 4, input channels % 16, output channels % 64; 25 of the dense
+// layer's 36 multiply-adds)
+bool wino23_ok(const contrad_conv_desc* d, int mode) {
+  if (mode != MODE_FWD) return false;
+  if (d->KH != 3 || d->KW != 3 || d->stride != 2 || d->pad != 0) return false;
+  if (d->H != 2 * d->Ho + 1 || d->W != 2 * d->Wo + 1) return false;
+  if (d->Ho < 4 || d->Wo < 4 || (d->Ho & (d->Ho - 1)) || (d->Wo & (d->Wo - 1))) return false;
+  if (d->Wo >= 32 ? d->Ho < 16 : d->Ho != d->Wo) return false;
+  if ((d->C & 15) || (d->K & 63) || (d->ldx & 3) || (d->ldw & 3)) return false;
+  const long long nimg = d->Wo >= 32 ? 1 : 128 / ((d->Ho / 2) * (d->Wo / 2));
+  const long long lim = 1ll << 31;
+  if (nimg * d->H * d->W * std::max(d->ldx, d->ldy) * 4 >= lim) return false;
+  if (4ll * 9 * d->C * d->K * 4 >= lim) return false;
+  return true;
+}
+
+wino23::Args wino23_args(const contrad_conv_desc* d) {
+  wino23::Args a{};
+  a.N = d->N; a.Hi = d->H; a.Wi = d->W; a.GH = d->Ho; a.GW = d->Wo;
+  a.Cin = d->C; a.Cout = d->K; a.ldi = d->ldx; a.ldo = d->ldy;
+  a.TW = d->Wo >= 32 ? 16 : d->Wo / 2; a.TH = d->Wo >= 32 ? 8 : d->Ho / 2;      // patches of 8 x 16 tiles, or whole images
+  a.sh_tw = __builtin_ctz(a.TW); a.sh_thw = __builtin_ctz(a.TH * a.TW);
+  a.NIMG = wino23::TB / (a.TH * a.TW);
+  a.PH = d->Ho / (2 * a.TH); a.PW = d->Wo / (2 * a.TW);
+  a.NP = cdiv(d->N, a.NIMG) * a.PH * a.PW;
+  a.NKB = a.Cout / 64;
+  return a;
+}
+
+bool wino23_planned(const contrad_conv_desc* d, int mode) {
+  static const bool enabled = []() { const char* e = contrad_dev_env("CONTRAD_WINO23"); return !(e && e[0] == '0'); }();
+  if (!enabled || !wino23_ok(d, mode)) return false;
+  const wino23::Args a = wino23_args(d);
+  const long long items = (long long)a.NP * a.NKB;
+  if (items < WINO_CUS) return items >= 230;
+  return cdivll(items, WINO_CUS) * WINO_CUS * 10 <= items * 14;
+}
+
+long long wino23_workspace_bytes(const contrad_conv_desc* d) { return 4ll * 9 * d->C * d->K * (long long)sizeof(float); }
+
+int wino23_grid(const wino23::Args& a) { return 8 * std::min(WINO_CUS / 8, cdiv(a.NP, 8) * a.NKB); }
+
+template <int NRAW>
+int launch_wino23_inst(const wino23::Args& a, hipStream_t stream) {
+  static const hipError_t attr = hipFuncSetAttribute((const void*)wino23::wino23_kernel<NRAW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     wino23::LDS_DWORDS * 4);
+  if (attr != hipSuccess) return (int)attr;
+  hipLaunchKernelGGL((wino23::wino23_kernel<NRAW>), dim3(wino23_grid(a)), dim3(512), wino23::LDS_DWORDS * 4, stream, a);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_wino23(const contrad_conv_desc* d, const float* in, const float* wp, const float* bias, const float* ref,
+                  float* out, float slope, float gain, float* U, hipStream_t stream) {
+  wino23::Args a = wino23_args(d);
+  a.x = in; a.U = U; a.y = out; a.bias = bias; a.ref = ref; a.slope = slope; a.gain = gain;
+  const int quads = 4 * (a.Cin / 4) * a.Cout;
+  hipLaunchKernelGGL(wino23::wino23_filter_kernel, dim3(cdiv(quads, 256)), dim3(256), 0, stream, wp, U, d->C, d->K, d->ldw);
+  CONTRAD_CHECK_LAUNCH();
+  const int nraw = cdiv(2 * a.NIMG * (2 * a.TH + 1) * (2 * a.TW + 1), 256);
+  if (nraw <= 5) return launch_wino23_inst<5>(a, stream);
+  if (nraw == 6) return launch_wino23_inst<6>(a, stream);
+  return launch_wino23_inst<7>(a, stream);
 }
 
 // ---- weight gradient of the 4x4 stride-2 layers on F(2x2, 2x2) (wino22_wgrad_kernel) ----
@@ -1924,6 +1991,7 @@ extern "C" long long contrad_conv2d_fwd_workspace_bytes(const contrad_conv_desc*
   if (wino44_planned(d, MODE_FWD)) return wino44_workspace_bytes(d);
   if (wino_planned(d, MODE_FWD)) return wino_workspace_bytes(d);
   if (wino22_planned(d, MODE_FWD)) return wino22_workspace_bytes(d);
+  if (wino23_planned(d, MODE_FWD)) return wino23_workspace_bytes(d);
   const FwdPlan p = fwd_plan(d);
   if (p.splits <= 1) return 0;
   return (long long)p.splits * d->N * d->Ho * d->Wo * d->K * (long long)sizeof(float);
@@ -1953,6 +2021,10 @@ extern "C" int contrad_conv2d_fwd_add(const contrad_conv_desc* d, const float* x
   if (wino22_planned(d, MODE_FWD) && workspace && workspace_bytes >= wino22_workspace_bytes(d)) {   // F(2x2, 2x2) on the phases, wino22.h
     CONTRAD_ARG(aligned16(x, wp, workspace));
     return launch_wino22<MODE_FWD>(d, x, wp, bias, addend, y, slope, gain, workspace, (hipStream_t)stream);
+  }
+  if (wino23_planned(d, MODE_FWD) && workspace && workspace_bytes >= wino23_workspace_bytes(d)) {   // 3x3 stride 2: F(2x2, 2x2) on the phases, wino23.h
+    CONTRAD_ARG(aligned16(x, wp, workspace));
+    return launch_wino23(d, x, wp, bias, addend, y, slope, gain, workspace, (hipStream_t)stream);
   }
   if (conv_c32_ok(d))   // weight-stationary kernel (conv_c32.h); (alignment is an argument error above, so the dispatch is
                         // exactly what contrad_conv2d_path / _grid_blocks report)
@@ -2130,13 +2202,13 @@ extern "C" int contrad_conv2d_dgrad(const contrad_conv_desc* d, const float* gy,
 extern "C" int contrad_conv2d_wino_ok(const contrad_conv_desc* d, int mode) {
   if (check_desc(d)) return -22;
   if (mode == MODE_WGRAD) return (wino_wgrad_ok(d) || wino22_wgrad_ok(d)) ? 1 : 0;
-  return (wino_ok(d, mode) || wino22_ok(d, mode)) ? 1 : 0;
+  return (wino_ok(d, mode) || wino22_ok(d, mode) || wino23_ok(d, mode)) ? 1 : 0;
 }
 
 extern "C" long long contrad_conv2d_wino_workspace_bytes(const contrad_conv_desc* d, int mode) {
   if (check_desc(d) || mode < 0 || mode > 2) return -22;
   if (mode == MODE_WGRAD) return wino_wgrad_ok(d) ? wino_wgrad_workspace_bytes(d) : wino22_wgrad_ok(d) ? wino22_wgrad_workspace_bytes(d) : -22;
-  return d->KH == 4 ? wino22_workspace_bytes(d) : wino_workspace_bytes(d);
+  return d->KH == 4 ? wino22_workspace_bytes(d) : d->stride == 2 ? wino23_workspace_bytes(d) : wino_workspace_bytes(d);
 }
 
 extern "C" int contrad_conv2d_wino_wgrad(const contrad_conv_desc* d, const float* x, const float* gy, float* dwp,
@@ -2164,6 +2236,10 @@ extern "C" int contrad_conv2d_wino(const contrad_conv_desc* d, int mode, const f
     CONTRAD_ARG(workspace_bytes >= wino22_workspace_bytes(d) && (mode == MODE_FWD || bias == nullptr));
     if (mode == MODE_FWD) return launch_wino22<MODE_FWD>(d, in, wp, bias, ref, out, slope, gain, workspace, (hipStream_t)stream);
     return launch_wino22<MODE_DGRAD>(d, in, wp, nullptr, ref, out, slope, gain, workspace, (hipStream_t)stream);
+  }
+  if (wino23_ok(d, mode)) {        // 3x3 stride 2 pad 0 (forward only): F(2x2, 2x2) on the phases, zero planes skipped (wino23.h)
+    CONTRAD_ARG(workspace_bytes >= wino23_workspace_bytes(d));
+    return launch_wino23(d, in, wp, bias, ref, out, slope, gain, workspace, (hipStream_t)stream);
   }
   CONTRAD_ARG(wino_ok(d, mode) && workspace_bytes >= wino_workspace_bytes(d));
   if (mode == MODE_FWD) return launch_wino<MODE_FWD>(d, in, wp, bias, ref, out, slope, gain, workspace, (hipStream_t)stream);
@@ -2217,6 +2293,7 @@ extern "C" int contrad_conv2d_path(const contrad_conv_desc* d, int mode) {
   if (mode != MODE_WGRAD && wino44_planned(d, mode)) return 9;
   if (mode != MODE_WGRAD && wino_planned(d, mode)) return 7;
   if (mode != MODE_WGRAD && wino22_planned(d, mode)) return 8;
+  if (wino23_planned(d, mode)) return 10;
   if (mode == MODE_WGRAD && wino_wgrad_planned(d)) return 7;
   if (mode == MODE_WGRAD && wino22_wgrad_planned(d)) return 8;
   if (mode != MODE_WGRAD && conv_c32_ok(d)) return 6;
@@ -2244,6 +2321,7 @@ extern "C" double contrad_conv2d_executed_fraction(const contrad_conv_desc* d, i
   if (contrad_conv2d_path(d, mode) == 9) return 0.25;        // 36 transform-domain multiply-adds per 4x4 tile instead of 144
   if (contrad_conv2d_path(d, mode) == 7) return 4.0 / 9.0;   // 16 transform-domain multiply-adds per 2x2 tile instead of 36
   if (contrad_conv2d_path(d, mode) == 8) return 9.0 / 16.0;  // four phases x 9 per 2x2 tile instead of 64
+  if (contrad_conv2d_path(d, mode) == 10) return 25.0 / 36.0; // 9 + 6 + 6 + 4 planes of the four phases per 2x2 tile instead of 36
   if (contrad_conv2d_path(d, mode) != 3) return 1.0;
   return mode == MODE_DGRAD ? dgrad_valid_tap_fraction(d) : fwd_valid_tap_fraction(d);
 }
@@ -2252,6 +2330,7 @@ extern "C" long long contrad_conv2d_grid_blocks(const contrad_conv_desc* d, int 
   if (check_desc(d) || mode < 0 || mode > 2) return -22;
   if (mode != MODE_WGRAD && with_workspace && wino44_planned(d, mode)) return wino44_grid(wino44_args(d, mode));   // (512 threads each)
   if (mode != MODE_WGRAD && with_workspace && wino_planned(d, mode)) return wino_grid(wino_args(d, mode));
+  if (with_workspace && wino23_planned(d, mode)) return wino23_grid(wino23_args(d));
   if (mode != MODE_WGRAD && with_workspace && wino22_planned(d, mode)) {
     const wino22::Args a = wino22_args(d, mode);
     return 8 * std::min(WINO_CUS / 8, cdiv(a.NTB, 8) * a.NKB * (mode == MODE_DGRAD ? 4 : 1));

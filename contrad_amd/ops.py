@@ -92,6 +92,8 @@ def conv_kernel_name(mode, d):
         return 'wino22_wgrad_kernel' if mode == 2 else 'wino22_kernel<%d>' % mode
     if path == 9:
         return 'wino44_kernel<%d>' % mode
+    if path == 10:
+        return 'wino23_kernel'
     if path in (2, 3):
         return 'igemm_lean_kernel<%d, %d, %d>' % (mode, bm.value, bn.value)
     return 'igemm_kernel<%d, %d, %d, %s>' % (mode, bm.value, bn.value, 'true' if path == 1 else 'false')
@@ -184,16 +186,23 @@ def conv2d_dgrad(gy, wp, x_shape, KH, KW, stride, pad, act_ref=None, slope=1.0, 
     return out
 
 
-def conv2d_wino(mode, inp, wp, C, K, bias=None, ref=None, slope=1.0, gain=1.0, out=None, k4s2=False, f44=False):
+def conv2d_wino(mode, inp, wp, C, K, bias=None, ref=None, slope=1.0, gain=1.0, out=None, k4s2=False, f44=False, k3s2=False):
     """Winograd kernels on ANY shape ``contrad_conv2d_wino_ok`` accepts (conv2d_fwd / conv2d_dgrad pick them by themselves for
     launches that fill the chip).  3x3 stride 1 pad 1 (F(2x2,3x3), csrc/wino.h; ``f44``: F(4x4,3x3), csrc/wino44.h, maps of
     16x16 and larger) -- mode 0: inp = x (N,H,W,C) -> y (N,H,W,K);
     mode 1: inp = gy (N,H,W,K) -> dx (N,H,W,C) -- or, ``k4s2``, 4x4 stride 2 pad 1 (F(2x2,2x2) on the four phases,
-    csrc/wino22.h): mode 0: x (N,H,W,C) -> y (N,H/2,W/2,K); mode 1: gy (N,Ho,Wo,K) -> dx (N,2Ho,2Wo,C)."""
+    csrc/wino22.h): mode 0: x (N,H,W,C) -> y (N,H/2,W/2,K); mode 1: gy (N,Ho,Wo,K) -> dx (N,2Ho,2Wo,C) -- or, ``k3s2``, 3x3 stride 2
+    pad 0 on an odd map (F(2x2,2x2) on the phases, zero planes skipped, csrc/wino23.h): mode 0 only, x (N,2G+1,2G+1,C) -> y (N,G,G,K)."""
     _chk(inp, 'inp'); _chk(wp, 'wp'); _chk(bias, 'bias'); _chk(ref, 'ref')
     N, Hi, Wi, _ = inp.shape
     co = K if mode == 0 else C
-    if k4s2:
+    if k3s2:
+        if mode != 0:
+            raise RuntimeError('contrad_hip: the 3x3 stride-2 Winograd kernel is forward only')
+        H, W = Hi, Wi
+        oshape = (N, (H - 1) // 2, (W - 1) // 2, co)
+        geo = (3, 3, 2, 0)
+    elif k4s2:
         H, W = (Hi, Wi) if mode == 0 else (2 * Hi, 2 * Wi)          # the conv's input map
         oshape = (N, H // 2, W // 2, co) if mode == 0 else (N, H, W, co)
         geo = (4, 4, 2, 1)

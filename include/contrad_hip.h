@@ -87,7 +87,11 @@ int contrad_conv2d_dgrad_ws(const contrad_conv_desc* d, const float* gy, const f
  * mode 1: in = gy, out = dx [* act'(ref)], bias must be NULL (semantics of contrad_conv2d_fwd_add / _dgrad_ws).
  * The weight gradient of the same layers (mode 2: F(3x3, 2x2), input AND output channels multiples of 64) runs on
  * wino_wgrad_kernel: contrad_conv2d_wgrad picks it when every CU gets a long enough share of the tiles,
- * contrad_conv2d_wino_wgrad forces it (arguments and results of contrad_conv2d_wgrad, workspace = split slabs). */
+ * contrad_conv2d_wino_wgrad forces it (arguments and results of contrad_conv2d_wgrad, workspace = split slabs).
+ * The same entry points serve the strided layers: 4x4 stride 2 pad 1 (csrc/wino22.h, all three modes) and, mode 0 only, 3x3
+ * stride 2 pad 0 on a (2G + 1) x (2G + 1) map (csrc/wino23.h: StyleGAN2's blurred down-sampling convolution, models/gan/
+ * stylegan2/layers.py:174-198; F(2x2, 2x2) on the four input phases with the structurally zero planes skipped: 25 / 36 of the
+ * dense layer's multiply-adds; contrad_conv2d_path = 10). */
 int contrad_conv2d_wino_ok(const contrad_conv_desc* d, int mode);
 long long contrad_conv2d_wino_workspace_bytes(const contrad_conv_desc* d, int mode);
 int contrad_conv2d_wino_wgrad(const contrad_conv_desc* d, const float* x, const float* gy, float* dwp, float* dbias,
@@ -126,12 +130,13 @@ int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm, int* bn);
  * only: the 512 -> 1 logit of the heads), 6 = the weight-stationary kernel of the 32 -> 32 channel 3x3 stride-1 layers
  * (conv_c32_kernel<mode>, modes 0 and 1), 7 = Winograd F(2x2, 3x3) (wino_kernel<mode>, modes 0 and 1; with a workspace) / F(3x3, 2x2) (wino_wgrad_kernel, mode 2),
  * 8 = F(2x2, 2x2) on the phases of the 4x4 stride-2 layers (wino22_kernel<mode> / wino22_wgrad_kernel), 9 = Winograd F(4x4, 3x3)
- * (wino44_kernel<mode>, modes 0 and 1; with a workspace);  negative = bad descriptor.  Profiling aid. */
+ * (wino44_kernel<mode>, modes 0 and 1; with a workspace), 10 = F(2x2, 2x2) on the phases of a 3x3 stride-2 pad-0 layer with the zero
+ * planes skipped (wino23_kernel, mode 0; with a workspace);  negative = bad descriptor.  Profiling aid. */
 int contrad_conv2d_path(const contrad_conv_desc* d, int mode);
 /* Share of the layer's nominal multiply-adds (2*N*Ho*Wo*K*C*KH*KW, the count every roofline here is quoted on, padding
  * taps included as in the reference's dense layer) that the kernel actually issues: 1 except on pixel-major tiles (path
  * 3), which skip the tap-positions that read padding (0.69 for a 3x3 pad-1 layer on a 4x4 map), and on the Winograd path
- * (7): 4/9, (8): 9/16, (9): 1/4 -- the transform-domain multiply-adds.  (A weight-gradient tile
+ * (7): 4/9, (8): 9/16, (9): 1/4, (10): 25/36 -- the transform-domain multiply-adds.  (A weight-gradient tile
  * that also sums the bias gradient visits everything: not reflected.)  Profiling aid. */
 double contrad_conv2d_executed_fraction(const contrad_conv_desc* d, int mode);
 /* Workgroups (256 threads each) of the main igemm launch this geometry gets for `mode` (with_workspace != 0: the plan the

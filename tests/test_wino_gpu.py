@@ -313,6 +313,63 @@ def test_wino44_channel_sliced_views_determinism_and_rejects():
             ops.conv2d_wino(0, torch.zeros(2, h, h, c, device=dev), torch.zeros(9 * c, k, device=dev), c, k, f44=True)
 
 
+# 3x3 stride-2 pad-0 layers on odd maps (StyleGAN2's blurred conv2, models/gan/stylegan2/layers.py:174-198) on F(2x2, 2x2)
+# over the four phases with the zero planes skipped (csrc/wino23.h): (N, G, C, K), input (2G + 1)^2, output G^2
+S3CASES = [
+    (3, 16, 16, 64),         # 16 x 16 grid: two images per item, ragged; one chunk pair per phase
+    (9, 8, 32, 128),         # 8 x 8 grid: 8 images per item, ragged; two cout blocks
+    (40, 4, 16, 64),         # 4 x 4 grid: 32 images per item, ragged
+    (2, 32, 16, 64),         # 32 x 32 grid: patches of 16 x 32 output pixels, 2 x 1 per image
+    (1, 64, 32, 192),        # 4 x 2 patches per image, three cout blocks
+    (70, 8, 48, 64),         # several items per block; Cin = 48: six chunks per phase
+]
+
+
+@pytest.mark.parametrize('case', S3CASES)
+def test_wino23_forward(case):
+    N, G, C, K = case
+    H = 2 * G + 1
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(N, H, H, C, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.1
+    b = torch.randn(K, generator=g)
+    add = torch.randn(N, G, G, K, generator=g)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, stride=2).permute(0, 2, 3, 1)
+    dev = torch.device('cuda')
+    wp = ops.pack_weight(w).to(dev)
+    y = ops.conv2d_wino(0, x.to(dev), wp, C, K, bias=b.to(dev), slope=0.2, gain=1.4, k3s2=True)
+    assert rel(y.cpu(), F.leaky_relu(ref, 0.2) * 1.4) < TIGHT
+    y = ops.conv2d_wino(0, x.to(dev), wp, C, K, ref=add.to(dev), k3s2=True)
+    assert rel(y.cpu(), F.conv2d(x.permute(0, 3, 1, 2), w, None, stride=2).permute(0, 2, 3, 1) + add) < TIGHT
+
+
+def test_wino23_channel_sliced_views_determinism_and_rejects():
+    N, G, C, K = 5, 16, 32, 64
+    H = 2 * G + 1
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(N, H, H, C, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.1
+    dev = torch.device('cuda')
+    wp = ops.pack_weight(w).to(dev)
+    xb = torch.randn(N, H, H, C + 12, device=dev)
+    xb[..., 4:4 + C] = x.to(dev)
+    yb = torch.full((N, G, G, K + 16), 7.0, device=dev)
+    ops.conv2d_wino(0, xb[..., 4:4 + C], wp, C, K, out=yb[..., 8:8 + K], k3s2=True)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, None, stride=2).permute(0, 2, 3, 1)
+    assert rel(yb[..., 8:8 + K].cpu(), ref) < TIGHT
+    assert (yb[..., :8] == 7.0).all() and (yb[..., 8 + K:] == 7.0).all()
+    y1 = ops.conv2d_wino(0, x.to(dev), wp, C, K, k3s2=True)
+    y2 = ops.conv2d_wino(0, x.to(dev), wp, C, K, k3s2=True)
+    assert torch.equal(y1, y2)
+    y3 = ops.conv2d_wino(0, x[2:4].contiguous().to(dev), wp, C, K, k3s2=True)      # (an item = two images)
+    assert torch.equal(y1[2:4], y3)
+    with pytest.raises(RuntimeError):          # forward only
+        ops.conv2d_wino(1, torch.zeros(2, G, G, K, device=dev), wp, C, K, k3s2=True)
+    for (h, c, k) in ((32, 32, 64), (33, 8, 64), (33, 32, 32), (25, 32, 64), (5, 32, 64)):
+        with pytest.raises(RuntimeError):
+            ops.conv2d_wino(0, torch.zeros(2, h, h, c, device=dev), torch.zeros(9 * c, k, device=dev), c, k, k3s2=True)
+
+
 # the 3x3 stride-1 layers of the BASELINE workloads: (N, H, C) -- SNDCGAN at 3N = 1536, StyleGAN2_512 at 3N = 48
 PLANNED = [(1536, 16, 128), (1536, 8, 256), (48, 128, 128), (48, 64, 256), (48, 32, 512), (48, 256, 64)]
 
