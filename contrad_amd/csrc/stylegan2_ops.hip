@@ -230,6 +230,18 @@ __device__ __forceinline__ void fma4(float4& acc, float w, const float4& v) {
   acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
 }
 
+// Block order of the 4x4-FIR kernels: thread tiles run channel-fastest, then x, then y, and vertically adjacent tiles share 3 of
+// their 6 - 7 input rows.  The dispatcher puts block b on XCD b % 8 (own L2 each): in launch order the row above belongs to
+// another XCD and the shared rows cross the fabric once per XCD (rocprofv3 FETCH_SIZE of the blur: 1.6x the tensor, of the
+// 2x upsampling FIR: 3x).  With each XCD on a contiguous run of blocks instead (common.h xcd_remap; results unchanged), round 6,
+// same box, 48 x 512^2 x 32: blur + decimation 386 -> 360 / 368 us, blur 641 / 653 -> 650 / 668, blur backward 908 / 914 -> 909 /
+// 920, upsampling FIR 1197 / 1210 -> 1229 / 1238; StyleGAN2_512 step 47.73 -> 47.73 ms: the re-fetched rows come out of the
+// 256 MB Infinity Cache and are not what bounds these kernels.  Kept for the decimating kernel only (tools/dev/ab_fir.sh).
+template <bool XCD>
+__device__ __forceinline__ int uf_block() {
+  return XCD ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+}
+
 // up = down = 1: tile of 4 (y) x 2 (x) outputs per thread and 4 channels: 7 x 5 loads feed 8 outputs (4.4 per output
 // instead of 16).  Blur in front of the strided convs and its backward.
 __global__ __launch_bounds__(256) void upfirdn4_u1d1_kernel(UpfirdnArgs a) {
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(256) void upfirdn4_u1d1_kernel(UpfirdnArgs a) {
   const int mv = a.minor >> 2;
   const int sx = (a.out_w + 1) >> 1, sy = (a.out_h + 3) >> 2;
   const long long total = (long long)a.major * sy * sx * mv;
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long e = (long long)uf_block<false>() * blockDim.x + threadIdx.x;
   if (e >= total) return;
   const int c = (int)(e % mv) * 4;
   long long t = e / mv;
@@ -298,7 +310,7 @@ __global__ __launch_bounds__(256) void upfirdn4_u1d2_kernel(UpfirdnArgs a) {
   const int mv = a.minor >> 2;
   const int sx = (a.out_w + 1) >> 1, sy = (a.out_h + 1) >> 1;
   const long long total = (long long)a.major * sy * sx * mv;
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long e = (long long)uf_block<true>() * blockDim.x + threadIdx.x;
   if (e >= total) return;
   const int c = (int)(e % mv) * 4;
   long long t = e / mv;
@@ -389,7 +401,7 @@ __global__ __launch_bounds__(256) void upfirdn4_u2d1_kernel(UpfirdnArgs a) {
   const int mv = a.minor >> 2;
   const int sx = (a.out_w + 1) >> 1, sy = (a.out_h + 1) >> 1;
   const long long total = (long long)a.major * sy * sx * mv;
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long e = (long long)uf_block<false>() * blockDim.x + threadIdx.x;
   if (e >= total) return;
   const int c = (int)(e % mv) * 4;
   long long t = e / mv;
@@ -456,7 +468,7 @@ __global__ __launch_bounds__(256) void upfirdn4_u2d1_planes_kernel(UpfirdnArgs a
   const Fir4 f = load_fir4(a.kernel);
   const int sx = (a.out_w + 1) >> 1, sy = (a.out_h + 1) >> 1;
   const long long total = (long long)a.major * sy * sx;
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long e = (long long)uf_block<false>() * blockDim.x + threadIdx.x;
   if (e >= total) return;
   const int ox0 = (int)(e % sx) * 2;
   const long long t = e / sx;
