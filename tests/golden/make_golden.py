@@ -739,7 +739,10 @@ def gen_stylegan2_r1():
     from models.gan import get_architecture
     torch.manual_seed(0)
     _G, D = get_architecture('stylegan2_512', (512, 512, 3))
-    N = 2
+    N = 4        # one whole minibatch-stddev group (discriminator.py:22-33: groups of four, as in a training batch of 16): with N = 2
+                 # the conv-bias gradients -- which reach r1 through sqrt(var + 1e-8) of the group alone -- are fp32-ill-conditioned
+                 # (the reference's own fp32 result is 0.6e-3 ... 1.4e-3 from its float64 evaluation; at N = 4: 0.6e-4 ... 2.4e-4,
+                 # tools/dev/r1_conditioning.py)
     aug_r1 = seeded_images(N, 512, 9004)
     out = _r1_fixture(D, S, 512, False, 1.0, 513, 0.3, aug_r1, N)
     out['seed_r1'] = 9004

@@ -4,11 +4,11 @@ import sys, torch
 import os; R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 from oracle import stylegan2_oracle as S
 from sg2_inputs import seeded_images
-torch.set_num_threads(16)
+torch.set_num_threads(8)
 size=512
 shapes=S.d_param_shapes(512, False, 1.0)
 sd=S.det_fill_d(shapes, seed=513, head_std=0.3)
-aug=seeded_images(2,512,9004)
+NIMG=int(os.environ.get("R1_N","2")); aug=seeded_images(NIMG,512,9004)
 res={}
 for dt in (torch.float32, torch.float64):
     osd={k:v.clone().to(dt) for k,v in sd.items()}
