@@ -144,15 +144,28 @@ def test_config4_stylegan2_32_step_with_r1_at_batch_64_against_oracle(margin):
         margin('config4/gradnorm/' + k, _relerr(prm.grad.norm().item(), osd[k].grad.norm().item()), TOL)
 
 
+def _config5_batch():
+    """16 (BASELINE configs[4]'s per-GPU batch) when the host has the memory and cores for the oracle at that size, else 4."""
+    if os.environ.get('CONTRAD_CONFIG5_N'):
+        return int(os.environ['CONTRAD_CONFIG5_N'])
+    try:
+        with open('/proc/meminfo') as f:
+            avail_gb = int(next(l for l in f if l.startswith('MemAvailable')).split()[1]) / 2 ** 20
+    except (OSError, StopIteration, ValueError):
+        avail_gb = 0.0
+    return 16 if avail_gb >= 128 and (os.cpu_count() or 1) >= 32 else 4
+
+
 def test_config5_stylegan2_512_step_at_512_against_oracle(margin):
     """BASELINE configs[4] at the AFHQ resolution, simclr_hq, the call structure of train_stylegan2_contraD.py (fakes N and
     real views 2N through D separately, r1 on its own call, weight (0.5 * lbd_r1) * d_reg_every = 80 as in the lazy-R1
-    step): the three losses, d_real / d_gen, r1 AND every parameter-gradient norm of the whole step.  N = 4 keeps the
-    oracle's 512^2 forward + R1 double backward + backward at about a minute and a half of host time (8 cores: 80 s;
-    N = 16 would take five); the N = 16 step itself is checked for finiteness / bitwise determinism in
-    tests/test_stylegan2_512_gpu.py and its gradient ENTRIES against the reference golden at N = 2."""
+    step): the three losses, d_real / d_gen, r1 AND every parameter-gradient norm of the whole step, at BASELINE's per-GPU
+    batch N = 16 where the host can hold the oracle (its 512^2 forward + R1 double backward + backward peak at 43 GB of
+    host memory; two minutes on the GPU box's 256 cores; round 6: worst margin 0.34 of the tolerance,
+    profiles/r06_config5_n16_margins.txt), at N = 4 (11 GB, 80 s on 8 cores) on smaller hosts; CONTRAD_CONFIG5_N overrides.
+    The gradient ENTRIES are checked against the reference golden at N = 2 in tests/test_stylegan2_512_gpu.py."""
     _threads()
-    N = 4
+    N = _config5_batch()
     w_r1 = (0.5 * 10.0) * 16
     hq = dict(scale=(0.08, 1.0), brightness=0.8, contrast=0.8, saturation=0.8, hue=0.2, p_blur=0.5,
               sigma_range=(0.1, 2.0))
