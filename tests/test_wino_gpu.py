@@ -343,6 +343,20 @@ def test_wino23_forward(case):
     assert rel(y.cpu(), F.conv2d(x.permute(0, 3, 1, 2), w, None, stride=2).permute(0, 2, 3, 1) + add) < TIGHT
 
 
+def test_wino23_forward_on_a_non_square_map():
+    """33 x 129 -> 16 x 64: one patch high, two wide (the models' maps are square; the kernel's patch walk is not)."""
+    N, C, K = 3, 16, 64
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(N, 33, 129, C, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.1
+    b = torch.randn(K, generator=g)
+    dev = torch.device('cuda')
+    y = ops.conv2d_wino(0, x.to(dev), ops.pack_weight(w).to(dev), C, K, bias=b.to(dev), slope=0.2, gain=1.0, k3s2=True)
+    ref = F.leaky_relu(F.conv2d(x.permute(0, 3, 1, 2), w, b, stride=2), 0.2).permute(0, 2, 3, 1)
+    assert tuple(y.shape) == (N, 16, 64, K)
+    assert rel(y.cpu(), ref) < TIGHT
+
+
 def test_wino23_channel_sliced_views_determinism_and_rejects():
     N, G, C, K = 5, 16, 32, 64
     H = 2 * G + 1
@@ -419,3 +433,31 @@ def test_the_plan_takes_winograd_at_the_baseline_shapes_and_matches_torch(shape)
     F.conv2d(xs2.permute(0, 3, 1, 2), w0, None, padding=1).backward(ys2.permute(0, 3, 1, 2))
     dws = ops.unpack_weight(ops.conv2d_wino_wgrad(xd[:nb], y[:nb]), K, C, 3, 3).cpu()
     assert rel(dws, w0.grad) < TIGHT
+
+
+# the blurred 3x3 stride-2 layers of StyleGAN2_512 at 3N = 48 that the plan gives to csrc/wino23.h: (N, G, C, K)
+PLANNED23 = [(48, 256, 32, 64), (48, 128, 64, 128), (48, 64, 128, 256), (48, 32, 256, 512)]
+
+
+@pytest.mark.parametrize('shape', PLANNED23)
+def test_the_plan_takes_the_strided_3x3_winograd_forward_at_the_baseline_shapes(shape):
+    """conv2d_fwd (the call ResBlock.conv2 makes, with the skip path's addend) at full size: path 10, 25 / 36 of the dense
+    products, first and last image against PyTorch-CPU; data and weight gradient of the same layer stay on the direct engine."""
+    N, G, C, K = shape
+    H = 2 * G + 1
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(N, H, H, C, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.05
+    b = torch.randn(K, generator=g)
+    add = torch.randn(N, G, G, K, generator=g)
+    wp = ops.pack_weight(w).to(dev)
+    d = ops.make_desc(N, H, H, C, K, 3, 3, 2, 0, C, K, wp.stride(0))
+    assert lib().raw('contrad_conv2d_path')(ctypes.byref(d), 0) == 10
+    assert abs(lib().raw('contrad_conv2d_executed_fraction')(ctypes.byref(d), 0) - 25.0 / 36.0) < 1e-12
+    assert 0 <= lib().raw('contrad_conv2d_path')(ctypes.byref(d), 1) < 7          # (direct engine)
+    assert 0 <= lib().raw('contrad_conv2d_path')(ctypes.byref(d), 2) < 7
+    y = ops.conv2d_fwd(x.to(dev), wp, b.to(dev), K, 3, 3, 2, 0, slope=0.2, gain=1.0, addend=add.to(dev))
+    sel = [0, N - 1]
+    ref = F.leaky_relu(F.conv2d(x[sel].permute(0, 3, 1, 2), w, b, stride=2), 0.2).permute(0, 2, 3, 1) + add[sel]
+    assert rel(y[sel].cpu(), ref) < TIGHT
