@@ -303,6 +303,111 @@ __global__ __launch_bounds__(256) void upfirdn4_u1d1_kernel(UpfirdnArgs a) {
         uf_store4(a, (((size_t)m * a.out_h + oy0 + r) * a.out_w + ox0 + q) * a.minor + c, acc[r][q]);
 }
 
+// ---- branch-free forms of the three 4x4-FIR kernels (round 6) ----
+// The kernels above guard every tap load and every store with its own bounds test: 75 loads in 210 exec-mask regions with 49
+// vmcnt(0) waits (168 VGPRs) in the blur.  Here one image = grid.y, so the image base is wave-uniform and all accesses are raw
+// buffer instructions on per-image resources: a tap outside the image is an out-of-range offset (the hardware returns zeros),
+// a pixel outside the output an out-of-range store (dropped), an absent addend / act_ref / out / out2 a resource of zero
+// records.  One basic block from the first load to the last store.
+constexpr unsigned UF_OOB = 0x80000000u;
+// offset if ok, else out of range -- as a select on a value computed on every lane (left to itself the compiler sinks the address
+// arithmetic into an exec-masked region per tap: dozens of tiny basic blocks)
+__device__ __forceinline__ unsigned uf_sel(unsigned off, bool ok) {
+  asm volatile("" : "+v"(off));
+  return ok ? off : UF_OOB;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uf_rsrc(const float* base, size_t img_elems, int m, bool on) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(on ? base + img_elems * (size_t)m : base), 0,
+                                           on ? (int)(unsigned)(img_elems * 4) : 0, 0x00020000);
+}
+__device__ __forceinline__ float4 uf_bld4(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+}
+template <int AUX>
+__device__ __forceinline__ void uf_bst4(__amdgpu_buffer_rsrc_t r, unsigned voff, float4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), r, (int)voff, 0, AUX);
+}
+// the fused epilogue of uf_store on NT output pixels (byte offsets voff[], UF_OOB = no such pixel) of one thread
+template <int NT, int AUX>
+__device__ __forceinline__ void uf_epilogue(const UpfirdnArgs& a, int m, size_t out_elems, const unsigned* voff, float4* acc) {
+  const __amdgpu_buffer_rsrc_t rA = uf_rsrc(a.addend, out_elems, m, a.addend != nullptr);
+  const __amdgpu_buffer_rsrc_t rR = uf_rsrc(a.act_ref, out_elems, m, a.out2 != nullptr);
+  const __amdgpu_buffer_rsrc_t rO = uf_rsrc(a.out, out_elems, m, a.out != nullptr);
+  const __amdgpu_buffer_rsrc_t rO2 = uf_rsrc(a.out2, out_elems, m, a.out2 != nullptr);
+  const float neg = a.slope * a.gain;
+  if (a.addend) {        // (uniform: scalar branches; an absent operand costs no memory instructions)
+    float4 t[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) t[i] = uf_bld4(rA, voff[i]);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) { acc[i].x += t[i].x; acc[i].y += t[i].y; acc[i].z += t[i].z; acc[i].w += t[i].w; }
+  }
+  if (a.out) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) uf_bst4<AUX>(rO, voff[i], acc[i]);
+  }
+  if (a.out2) {
+    float4 rf[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) rf[i] = uf_bld4(rR, voff[i]);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      float4 w;
+      w.x = acc[i].x * (rf[i].x > 0.f ? a.gain : neg); w.y = acc[i].y * (rf[i].y > 0.f ? a.gain : neg);
+      w.z = acc[i].z * (rf[i].z > 0.f ? a.gain : neg); w.w = acc[i].w * (rf[i].w > 0.f ? a.gain : neg);
+      uf_bst4<AUX>(rO2, voff[i], w);
+    }
+  }
+}
+
+// up = down = 1 (blur and its backward): 4 x 2 outputs per thread and 4 channels, grid = (tiles of an image / 256, images)
+__global__ __launch_bounds__(256) void upfirdn4_u1d1_buf_kernel(UpfirdnArgs a) {
+  const Fir4 f = load_fir4(a.kernel);
+  const int mv = a.minor >> 2;
+  const int sx = (a.out_w + 1) >> 1, sy = (a.out_h + 3) >> 2;
+  const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  const int m = (int)blockIdx.y;
+  const bool live = e < sy * sx * mv;
+  const int c = (e % mv) * 4;
+  const int t = e / mv;
+  const int ox0 = (t % sx) * 2, oy0 = (t / sx) * 4;
+  const int ix0 = ox0 - a.pad_x0, iy0 = oy0 - a.pad_y0;
+  const size_t in_elems = (size_t)a.in_h * a.in_w * a.minor, out_elems = (size_t)a.out_h * a.out_w * a.minor;
+  const __amdgpu_buffer_rsrc_t rI = uf_rsrc(a.in, in_elems, m, true);
+  float4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int off0 = ((iy0 * a.in_w + ix0) * a.minor + c) * 4;
+  const int rowb = a.in_w * a.minor * 4, colb = a.minor * 4;
+#pragma unroll
+  for (int dy = 0; dy < 7; ++dy) {
+    const bool vy = live && (unsigned)(iy0 + dy) < (unsigned)a.in_h;
+    float4 v[5];
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx)
+      v[dx] = uf_bld4(rI, uf_sel((unsigned)(off0 + dy * rowb + dx * colb), vy && (unsigned)(ix0 + dx) < (unsigned)a.in_w));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ky = dy - r;
+      if (ky >= 0 && ky < 4) {
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+          fma4(acc[2 * r], f.w[ky * 4 + kx], v[kx]);
+          fma4(acc[2 * r + 1], f.w[ky * 4 + kx], v[kx + 1]);
+        }
+      }
+    }
+  }
+  unsigned voff[8];
+  const int oo0 = ((oy0 * a.out_w + ox0) * a.minor + c) * 4, orow = a.out_w * a.minor * 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      voff[2 * r + q] = uf_sel((unsigned)(oo0 + r * orow + q * colb), live && oy0 + r < a.out_h && ox0 + q < a.out_w);
+  if (a.nt_store) uf_epilogue<8, 2>(a, m, out_elems, voff, acc); else uf_epilogue<8, 0>(a, m, out_elems, voff, acc);
+}
+
 // up = 1, down = 2: out[oy][ox] = sum k[ky][kx] in[2 oy + ky - pad][2 ox + kx - pad]; tile of 2 x 2 outputs per thread:
 // 6 x 6 loads feed 4 outputs (9 per output instead of 16).  Blur + decimation of the residual skip path.
 __global__ __launch_bounds__(256) void upfirdn4_u1d2_kernel(UpfirdnArgs a) {
@@ -429,6 +534,120 @@ __global__ __launch_bounds__(256) void upfirdn4_u2d1_kernel(UpfirdnArgs a) {
     for (int q = 0; q < 2; ++q)
       if (oy0 + r < a.out_h && ox0 + q < a.out_w)
         uf_store4(a, (((size_t)m * a.out_h + oy0 + r) * a.out_w + ox0 + q) * a.minor + c, acc[r][q]);
+}
+
+// branch-free forms of the decimating and the upsampling FIR (see upfirdn4_u1d1_buf_kernel): grid = (quads of an image / 256, images)
+__global__ __launch_bounds__(256) void upfirdn4_u1d2_buf_kernel(UpfirdnArgs a) {
+  const Fir4 f = load_fir4(a.kernel);
+  const int mv = a.minor >> 2;
+  const int sx = (a.out_w + 1) >> 1, sy = (a.out_h + 1) >> 1;
+  const int e = xcd_remap((int)blockIdx.x, (int)gridDim.x) * 256 + (int)threadIdx.x;
+  const int m = (int)blockIdx.y;
+  const bool live = e < sy * sx * mv;
+  const int c = (e % mv) * 4;
+  const int t = e / mv;
+  const int ox0 = (t % sx) * 2, oy0 = (t / sx) * 2;
+  const int ix0 = 2 * ox0 - a.pad_x0, iy0 = 2 * oy0 - a.pad_y0;
+  const size_t in_elems = (size_t)a.in_h * a.in_w * a.minor, out_elems = (size_t)a.out_h * a.out_w * a.minor;
+  const __amdgpu_buffer_rsrc_t rI = uf_rsrc(a.in, in_elems, m, true);
+  float4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int off0 = ((iy0 * a.in_w + ix0) * a.minor + c) * 4;
+  const int rowb = a.in_w * a.minor * 4, colb = a.minor * 4;
+#pragma unroll
+  for (int dy = 0; dy < 6; ++dy) {
+    const bool vy = live && (unsigned)(iy0 + dy) < (unsigned)a.in_h;
+    float4 v[6];
+#pragma unroll
+    for (int dx = 0; dx < 6; ++dx)
+      v[dx] = uf_bld4(rI, uf_sel((unsigned)(off0 + dy * rowb + dx * colb), vy && (unsigned)(ix0 + dx) < (unsigned)a.in_w));
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int ky = dy - 2 * r;
+      if (ky >= 0 && ky < 4) {
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+          fma4(acc[2 * r], f.w[ky * 4 + kx], v[kx]);
+          fma4(acc[2 * r + 1], f.w[ky * 4 + kx], v[kx + 2]);
+        }
+      }
+    }
+  }
+  unsigned voff[4];
+  const int oo0 = ((oy0 * a.out_w + ox0) * a.minor + c) * 4, orow = a.out_w * a.minor * 4;
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      voff[2 * r + q] = uf_sel((unsigned)(oo0 + r * orow + q * colb), live && oy0 + r < a.out_h && ox0 + q < a.out_w);
+  if (a.nt_store) uf_epilogue<4, 2>(a, m, out_elems, voff, acc); else uf_epilogue<4, 0>(a, m, out_elems, voff, acc);
+}
+
+template <int PY, int PX>
+__device__ __forceinline__ void upfirdn4_u2d1_buf_body(const UpfirdnArgs& a, const Fir4& f, __amdgpu_buffer_rsrc_t rI, bool live, int c,
+                                                       int iy_lo, int ix_lo, float4* acc) {
+  const int off0 = ((iy_lo * a.in_w + ix_lo) * a.minor + c) * 4;
+  const int rowb = a.in_w * a.minor * 4, colb = a.minor * 4;
+  float4 v[3][3];
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      // (pixels that reach no output of the quad -- both tap indices out of range -- are not loaded at all)
+      const bool used_y = (PY + 2 * dy >= 0 && PY + 2 * dy <= 3) || (PY + 2 * dy - 1 >= 0 && PY + 2 * dy - 1 <= 3);
+      const bool used_x = (PX + 2 * dx >= 0 && PX + 2 * dx <= 3) || (PX + 2 * dx - 1 >= 0 && PX + 2 * dx - 1 <= 3);
+      if (!(used_y && used_x)) continue;
+      v[dy][dx] = uf_bld4(rI, uf_sel((unsigned)(off0 + dy * rowb + dx * colb),
+                                     live && (unsigned)(iy_lo + dy) < (unsigned)a.in_h && (unsigned)(ix_lo + dx) < (unsigned)a.in_w));
+    }
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int ky = PY + 2 * dy - r;
+        if (ky < 0 || ky > 3) continue;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int kx = PX + 2 * dx - q;
+          if (kx < 0 || kx > 3) continue;
+          fma4(acc[2 * r + q], f.w[ky * 4 + kx], v[dy][dx]);
+        }
+      }
+}
+
+__global__ __launch_bounds__(256) void upfirdn4_u2d1_buf_kernel(UpfirdnArgs a) {
+  const Fir4 f = load_fir4(a.kernel);
+  const int mv = a.minor >> 2;
+  const int sx = (a.out_w + 1) >> 1, sy = (a.out_h + 1) >> 1;
+  const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  const int m = (int)blockIdx.y;
+  const bool live = e < sy * sx * mv;
+  const int c = (e % mv) * 4;
+  const int t = e / mv;
+  const int ox0 = (t % sx) * 2, oy0 = (t / sx) * 2;
+  const int py_lo = oy0 - a.pad_y0, px_lo = ox0 - a.pad_x0;
+  const int iy_lo = (py_lo + 1) >> 1, ix_lo = (px_lo + 1) >> 1;         // arithmetic shift == floor for negatives
+  const size_t in_elems = (size_t)a.in_h * a.in_w * a.minor, out_elems = (size_t)a.out_h * a.out_w * a.minor;
+  const __amdgpu_buffer_rsrc_t rI = uf_rsrc(a.in, in_elems, m, true);
+  float4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int par = ((a.pad_y0 & 1) << 1) | (a.pad_x0 & 1);              // (uniform over the launch: a scalar branch)
+  if (par == 0) upfirdn4_u2d1_buf_body<0, 0>(a, f, rI, live, c, iy_lo, ix_lo, acc);
+  else if (par == 1) upfirdn4_u2d1_buf_body<0, 1>(a, f, rI, live, c, iy_lo, ix_lo, acc);
+  else if (par == 2) upfirdn4_u2d1_buf_body<1, 0>(a, f, rI, live, c, iy_lo, ix_lo, acc);
+  else upfirdn4_u2d1_buf_body<1, 1>(a, f, rI, live, c, iy_lo, ix_lo, acc);
+  unsigned voff[4];
+  const int oo0 = ((oy0 * a.out_w + ox0) * a.minor + c) * 4, orow = a.out_w * a.minor * 4, colo = a.minor * 4;
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      voff[2 * r + q] = uf_sel((unsigned)(oo0 + r * orow + q * colo), live && oy0 + r < a.out_h && ox0 + q < a.out_w);
+  if (a.nt_store) uf_epilogue<4, 2>(a, m, out_elems, voff, acc); else uf_epilogue<4, 0>(a, m, out_elems, voff, acc);
 }
 
 // The same op on single-channel planes (minor == 1: the generator's RGB skip is upsampled as B * 3 planes, generator.py:
@@ -854,7 +1073,15 @@ static int upfirdn2d_launch(const float* input, const float* kernel, float* out,
   hipStream_t s = (hipStream_t)stream;
   const bool vec = (minor & 3) == 0;
   const bool fir4 = vec && kh == 4 && kw == 4 && up_x == up_y && down_x == down_y;
+  // the branch-free forms: one image per grid.y, 32-bit byte offsets inside an image
+  const bool buf_ok = major <= 65535 && (long long)in_h * in_w * minor * 4 < (1ll << 31) && (long long)a.out_h * a.out_w * minor * 4 < (1ll << 31);
   if (fir4 && up_x == 1 && down_x == 1) {
+    if (!mc && buf_ok) {
+      const long long per = (long long)((a.out_h + 3) / 4) * ((a.out_w + 1) / 2) * (minor / 4);
+      hipLaunchKernelGGL(upfirdn4_u1d1_buf_kernel, dim3((unsigned)cdivll(per, 256), (unsigned)major), dim3(256), 0, s, a);
+      CONTRAD_CHECK_LAUNCH();
+      return 0;
+    }
     const long long tot = (long long)major * ((a.out_h + 3) / 4) * ((a.out_w + 1) / 2) * (minor / 4);
     hipLaunchKernelGGL(upfirdn4_u1d1_kernel, dim3((unsigned)cdivll(tot, 256)), dim3(256), 0, s, a);
     CONTRAD_CHECK_LAUNCH();
@@ -862,8 +1089,13 @@ static int upfirdn2d_launch(const float* input, const float* kernel, float* out,
   }
   CONTRAD_ARG(!mc);          // the modulated-conv epilogue exists on the 4x4-FIR blur path only
   if (fir4 && ((up_x == 1 && down_x == 2) || (up_x == 2 && down_x == 1))) {
-    const long long tot = (long long)major * ((a.out_h + 1) / 2) * ((a.out_w + 1) / 2) * (minor / 4);
-    if (down_x == 2) hipLaunchKernelGGL(upfirdn4_u1d2_kernel, dim3((unsigned)cdivll(tot, 256)), dim3(256), 0, s, a);
+    const long long per = (long long)((a.out_h + 1) / 2) * ((a.out_w + 1) / 2) * (minor / 4);
+    const long long tot = (long long)major * per;
+    if (buf_ok) {
+      const dim3 g((unsigned)cdivll(per, 256), (unsigned)major);
+      if (down_x == 2) hipLaunchKernelGGL(upfirdn4_u1d2_buf_kernel, g, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(upfirdn4_u2d1_buf_kernel, g, dim3(256), 0, s, a);
+    } else if (down_x == 2) hipLaunchKernelGGL(upfirdn4_u1d2_kernel, dim3((unsigned)cdivll(tot, 256)), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(upfirdn4_u2d1_kernel, dim3((unsigned)cdivll(tot, 256)), dim3(256), 0, s, a);
     CONTRAD_CHECK_LAUNCH();
     return 0;
