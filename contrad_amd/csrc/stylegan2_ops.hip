@@ -360,6 +360,7 @@ __device__ __forceinline__ void uf_epilogue(const UpfirdnArgs& a, int m, size_t 
   }
 }
 
+// (152 VGPRs = 3 waves per SIMD with all 35 taps in flight; forced to 4 / 5 waves the loads spill: 600 -> 1040 / 1830 us)
 // up = down = 1 (blur and its backward): 4 x 2 outputs per thread and 4 channels, grid = (tiles of an image / 256, images)
 __global__ __launch_bounds__(256) void upfirdn4_u1d1_buf_kernel(UpfirdnArgs a) {
   const Fir4 f = load_fir4(a.kernel);
@@ -405,6 +406,15 @@ __global__ __launch_bounds__(256) void upfirdn4_u1d1_buf_kernel(UpfirdnArgs a) {
 #pragma unroll
     for (int q = 0; q < 2; ++q)
       voff[2 * r + q] = uf_sel((unsigned)(oo0 + r * orow + q * colb), live && oy0 + r < a.out_h && ox0 + q < a.out_w);
+  if (a.mc_bias) {       // uniform: the generator's upsampling StyledConv tail (blur -> demod + noise + bias + lrelu)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (live && oy0 + r < a.out_h && ox0 + q < a.out_w)
+          mc_store4(a, m, ((size_t)m * a.out_h + oy0 + r) * a.out_w + ox0 + q, c, acc[2 * r + q]);
+    return;
+  }
   if (a.nt_store) uf_epilogue<8, 2>(a, m, out_elems, voff, acc); else uf_epilogue<8, 0>(a, m, out_elems, voff, acc);
 }
 
@@ -1076,7 +1086,7 @@ static int upfirdn2d_launch(const float* input, const float* kernel, float* out,
   // the branch-free forms: one image per grid.y, 32-bit byte offsets inside an image
   const bool buf_ok = major <= 65535 && (long long)in_h * in_w * minor * 4 < (1ll << 31) && (long long)a.out_h * a.out_w * minor * 4 < (1ll << 31);
   if (fir4 && up_x == 1 && down_x == 1) {
-    if (!mc && buf_ok) {
+    if (buf_ok) {
       const long long per = (long long)((a.out_h + 3) / 4) * ((a.out_w + 1) / 2) * (minor / 4);
       hipLaunchKernelGGL(upfirdn4_u1d1_buf_kernel, dim3((unsigned)cdivll(per, 256), (unsigned)major), dim3(256), 0, s, a);
       CONTRAD_CHECK_LAUNCH();
