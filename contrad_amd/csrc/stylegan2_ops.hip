@@ -308,7 +308,11 @@ __global__ __launch_bounds__(256) void upfirdn4_u1d1_kernel(UpfirdnArgs a) {
 // vmcnt(0) waits (168 VGPRs) in the blur.  Here one image = grid.y, so the image base is wave-uniform and all accesses are raw
 // buffer instructions on per-image resources: a tap outside the image is an out-of-range offset (the hardware returns zeros),
 // a pixel outside the output an out-of-range store (dropped), an absent addend / act_ref / out / out2 a resource of zero
-// records.  One basic block from the first load to the last store.
+// records.  One basic block from the first load to the last store.  Same box, 48 x 512^2 x 32 (profiles/r06_ab_fir_branch_free.txt):
+// blur 678 -> 594 us, its backward with act' 917 -> 813, decimating blur 386 -> 345, upsampling FIR 1197 -> 1099 (5.4 - 6.2 TB/s of
+// algorithmic bytes); StyleGAN2_512 step 47.13 -> 46.61 ms, StyleGAN2-32 12.46 -> 12.36.  Absent operands are scalar branches:
+// as zero-record resources their dropped loads and stores still cost address cycles (blur 650 -> 745 us).  The pointer forms above
+// remain for tensors beyond 2^31 bytes per image / 65535 images.
 constexpr unsigned UF_OOB = 0x80000000u;
 // offset if ok, else out of range -- as a select on a value computed on every lane (left to itself the compiler sinks the address
 // arithmetic into an exec-masked region per tap: dozens of tiny basic blocks)
