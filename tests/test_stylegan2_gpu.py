@@ -372,6 +372,28 @@ def test_fir4_specialisations_against_plain_torch(cfg, shape):
     assert none is None and rel(o2b, want * torch.where(ref > 0, 1.0, 0.2)) < 1e-5
 
 
+@pytest.mark.parametrize('cfg', [(1, 1, (2, 1, 1, 2)), (1, 2, (1, 1, 1, 1)), (2, 1, (2, 1, 2, 1))])
+def test_fir4_pointer_forms_beyond_65535_images(cfg):
+    """More images than a grid's y dimension holds: the launch falls back from the branch-free kernels (one image per
+    grid.y) to the pointer forms; same contract, and the same values as the branch-free kernels give on a slice."""
+    up, down, pad = cfg
+    g = torch.Generator().manual_seed(77 + up + down)
+    x = torch.randn(65600, 5, 6, 4, generator=g)
+    k = torch.rand(4, 4, generator=g)
+    want = _upfirdn_ref(x, k, up, down, pad)
+    addend = torch.randn(want.shape, generator=g)
+    ref = torch.randn(want.shape, generator=g)
+    o1, o2 = ops.upfirdn2d_fused(x.to(DEV), k.to(DEV), up, down, pad, addend=addend.to(DEV), act_ref=ref.to(DEV),
+                                 slope=0.2, gain=1.3, want_out=True, want_out2=True)
+    v = want + addend
+    assert rel(o1, v) < 1e-5
+    assert rel(o2, v * torch.where(ref > 0, 1.3, 0.2 * 1.3)) < 1e-5
+    sl = slice(65000, 65600)
+    s1, s2 = ops.upfirdn2d_fused(x[sl].contiguous().to(DEV), k.to(DEV), up, down, pad, addend=addend[sl].contiguous().to(DEV),
+                                 act_ref=ref[sl].contiguous().to(DEV), slope=0.2, gain=1.3, want_out=True, want_out2=True)
+    assert torch.equal(o1[sl], s1) and torch.equal(o2[sl], s2)
+
+
 @pytest.mark.parametrize('size,small32,N', [(32, True, 8), (64, False, 4)])
 def test_fused_trunk_equals_the_node_per_op_graph(size, small32, N):
     """_TrunkFn (one first-order node: folded 1/sqrt2, activation derivatives and gradient sums in the blur epilogues)
