@@ -505,7 +505,7 @@ def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=
                     "nominal_gflop_per_launch": round(fsum / cnt / 1e9, 2),
                     "flop_convention": "achieved / frac price the multiply-adds the kernel issues (Winograd: the transform-domain "
                                        "products -- F(4x4,3x3), contrad_conv2d_path == 9: 1/4 of the dense layer's; F(2x2,3x3) / "
-                                       "F(3x3,2x2), path 7: 4/9; F(2x2,2x2) on the phases of the strided layers, path 8: 9/16; "
+                                       "F(3x3,2x2), path 7: 4/9; F(2x2,2x2) on the phases of the strided layers, path 8: 9/16 (4x4 stride 2), path 10: 25/36 (3x3 stride 2, zero planes skipped); "
                                        "pixel-major tiles, path 3, skip the tap-positions that read zero padding on "
                                        "the 4x4 / 8x8 maps: contrad_conv2d_executed_fraction); nominal_* price the same time on the "
                                        "dense layer 2*N*Ho*Wo*K*C*KH*KW of the reference (SURVEY.md 8d) and may exceed the "
