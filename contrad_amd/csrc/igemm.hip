@@ -817,6 +817,7 @@ int launch(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
 #include "wino.h"
 #include "wino22.h"
 #include "wino44.h"
+#include "wino44n.h"
 #include "wino23.h"
 
 // ---------------- Winograd F(2x2, 3x3) path (wino.h): 3x3 stride-1 pad-1 layers, forward and data gradient ----------------
@@ -889,14 +890,16 @@ int wino_grid(const wino::Args& a) {
 
 
 // ---------------- Winograd F(4x4, 3x3) path (wino44.h): the same layers as wino.h on maps of 8x8 and larger ----------------
-// (input channels % 32, output channels % 64, power-of-two maps >= 8; 2.25 multiply-adds per output instead of 4)
+// (input channels % 32, output channels % 64 -- or an odd multiple of 32: wino44n.h --, power-of-two maps >= 8; 2.25 multiply-adds per
+// output instead of 4)
 bool wino44_ok(const contrad_conv_desc* d, int mode) {
   if (mode != MODE_FWD && mode != MODE_DGRAD) return false;
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1) return false;
   if (d->H < 8 || d->W < 8 || (d->H & (d->H - 1)) || (d->W & (d->W - 1)) || (d->W < 32 ? d->H != d->W : d->H < 16)) return false;
   const int cin = mode == MODE_FWD ? d->C : d->K, cout = mode == MODE_FWD ? d->K : d->C;
   const int ldi = mode == MODE_FWD ? d->ldx : d->ldy, ldo = mode == MODE_FWD ? d->ldy : d->ldx;
-  if ((cin & 31) || (cout & 63) || (ldi & 3) || (d->ldw & 3)) return false;
+  // (output channels: whole 64-wide blocks -- wino44_kernel -- or an odd number of 32-wide ones -- wino44n_kernel, wino44n.h)
+  if ((cin & 31) || (cout & 31) || (ldi & 3) || (d->ldw & 3)) return false;
   const long long lim = 1ll << 31;
   const long long nimg = d->W >= 32 ? 1 : d->W == 16 ? 2 : 8;
   if (nimg * d->H * d->W * std::max(ldi, ldo) * 4 >= lim) return false;     // block-relative byte offsets
@@ -916,7 +919,7 @@ wino44::Args wino44_args(const contrad_conv_desc* d, int mode) {
   a.NIMG = 32 / (a.TH * a.TW);
   a.PH = d->H / (4 * a.TH); a.PW = d->W / (4 * a.TW);
   a.NP = cdiv(d->N, a.NIMG) * a.PH * a.PW;
-  a.NKB = a.Cout / 64;
+  a.NKB = (a.Cout & 63) ? a.Cout / 32 : a.Cout / 64;      // 32-wide cout blocks: the items of wino44n_kernel
   a.BH = 4 * a.TH + 2; a.BW = 4 * a.TW + 2;       // raw box: always with the halo
   return a;
 }
@@ -932,6 +935,8 @@ bool wino44_planned(const contrad_conv_desc* d, int mode) {
   static const bool enabled = []() { const char* e = contrad_dev_env("CONTRAD_WINO44"); return !(e && e[0] == '0'); }();
   static const bool enabled2 = []() { const char* e = contrad_dev_env("CONTRAD_WINO"); return !(e && e[0] == '0'); }();
   if (!enabled || !enabled2 || !wino44_ok(d, mode)) return false;
+  static const bool enabled_n = []() { const char* e = contrad_dev_env("CONTRAD_WINO44N"); return !(e && e[0] == '0'); }();
+  if (!enabled_n && ((mode == MODE_FWD ? d->K : d->C) & 63)) return false;       // (32-wide cout blocks: wino44n.h)
   const long long items = wino44_items(d, mode);
   static const long long min_items = []() { const char* e = contrad_dev_env("CONTRAD_WINO44_MIN_ITEMS"); return e ? atoll(e) : 230ll; }();
   if (items < WINO_CUS) return items >= min_items;
@@ -955,6 +960,16 @@ int launch_wino44_inst(const wino44::Args& a, hipStream_t stream) {
   return 0;
 }
 
+template <int MODE, int BOXW>
+int launch_wino44n_inst(const wino44::Args& a, hipStream_t stream) {
+  static const hipError_t attr = hipFuncSetAttribute((const void*)wino44n::wino44n_kernel<MODE, BOXW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     wino44::LDS_DWORDS * 4);
+  if (attr != hipSuccess) return (int)attr;
+  hipLaunchKernelGGL((wino44n::wino44n_kernel<MODE, BOXW>), dim3(wino44_grid(a)), dim3(512), wino44::LDS_DWORDS * 4, stream, a);
+  CONTRAD_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int MODE>
 int launch_wino44(const contrad_conv_desc* d, const float* in, const float* wp, const float* bias, const float* ref,
                   float* out, float slope, float gain, float* U, hipStream_t stream) {
@@ -963,6 +978,8 @@ int launch_wino44(const contrad_conv_desc* d, const float* in, const float* wp, 
   const int quads = (a.Cin / 4) * a.Cout;
   hipLaunchKernelGGL(wino44::wino44_filter_kernel<MODE>, dim3(cdiv(quads, 256)), dim3(256), 0, stream, wp, U, d->C, d->K, d->ldw);
   CONTRAD_CHECK_LAUNCH();
+  if (a.Cout & 63)
+    return a.BW == 34 ? launch_wino44n_inst<MODE, 34>(a, stream) : a.BW == 18 ? launch_wino44n_inst<MODE, 18>(a, stream) : launch_wino44n_inst<MODE, 10>(a, stream);
   return a.BW == 34 ? launch_wino44_inst<MODE, 34>(a, stream) : a.BW == 18 ? launch_wino44_inst<MODE, 18>(a, stream) : launch_wino44_inst<MODE, 10>(a, stream);
 }
 

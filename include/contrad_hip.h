@@ -101,11 +101,12 @@ int contrad_conv2d_wino(const contrad_conv_desc* d, int mode, const float* in, c
                         long long workspace_bytes, contrad_stream_t stream);
 
 /* Winograd F(4x4, 3x3) in fp32 (csrc/wino44.h) for the same 3x3 stride-1 pad-1 layers on power-of-two maps >= 16x16 whose
- * input channels are a multiple of 32 and output channels a multiple of 64: 2.25 multiply-adds per output instead of 4
+ * input channels and output channels are multiples of 32 (output channels in whole 64-wide blocks: wino44_kernel; an odd number
+ * of 32-wide blocks -- StyleGAN2_512's 32 -> 32 channel layers -- csrc/wino44n.h): 2.25 multiply-adds per output instead of 4
  * (F(2x2, 3x3)) or 9 (direct); standard interpolation points (0, +-1, +-2, inf), round-off rel-L2 1 - 5e-6 against fp64 (the
  * contract of this path is 1e-3; reference as above: F.conv2d of models/gan/sndcgan.py:91-109, stylegan2/layers.py:115-121).
  * contrad_conv2d_fwd_add / contrad_conv2d_dgrad_ws choose it ahead of F(2x2, 3x3) for launches of a full round of its items
- * (512 output pixels x 64 output channels per CU) -- their *_workspace_bytes then cover 36 * C * K floats --;
+ * (512 output pixels x 64 or 32 output channels per CU) -- their *_workspace_bytes then cover 36 * C * K floats --;
  * contrad_conv2d_wino44 forces it on any shape contrad_conv2d_wino44_ok accepts (arguments and semantics of
  * contrad_conv2d_wino, modes 0 and 1). */
 int contrad_conv2d_wino44_ok(const contrad_conv_desc* d, int mode);

@@ -291,6 +291,48 @@ def test_wino44_data_gradient(case):
     assert rel(dx.cpu(), ref * torch.where(act > 0, 1.5, 0.3)) < TIGHT44
 
 
+# F(4x4, 3x3) with 32-wide cout blocks (csrc/wino44n.h: StyleGAN2_512's 32 -> 32 channel layers): (N, H, W, C, K), K an odd multiple of 32
+CASES44N = [
+    (3, 16, 16, 32, 32),      # two images per item, ragged; four chunks (two pairs)
+    (9, 8, 8, 32, 32),        # eight images per item, ragged
+    (2, 32, 64, 32, 96),      # patches of 16 x 32 pixels, 2 x 2 per image; three cout blocks
+    (1, 128, 64, 64, 32),     # 8 x 2 patches: boxes with real halos on every side; eight chunks
+    (40, 16, 16, 32, 32),     # several items per block of the persistent grid
+]
+
+
+@pytest.mark.parametrize('case', CASES44N)
+def test_wino44n_forward(case):
+    N, H, W, C, K = case
+    x, w, b = _inputs(N, H, W, C, K, 41)
+    add = torch.randn(N, H, W, K, generator=torch.Generator().manual_seed(42))
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1).permute(0, 2, 3, 1)
+    dev = torch.device('cuda')
+    wp = ops.pack_weight(w).to(dev)
+    y = ops.conv2d_wino(0, x.to(dev), wp, C, K, bias=b.to(dev), slope=0.2, gain=1.3, f44=True)
+    assert rel(y.cpu(), F.leaky_relu(ref, 0.2) * 1.3) < TIGHT44
+    y = ops.conv2d_wino(0, x.to(dev), wp, C, K, bias=None, ref=add.to(dev), slope=1.0, gain=1.0, f44=True)
+    assert rel(y.cpu(), F.conv2d(x.permute(0, 3, 1, 2), w, None, padding=1).permute(0, 2, 3, 1) + add) < TIGHT44
+    y2 = ops.conv2d_wino(0, x.to(dev), wp, C, K, bias=None, ref=add.to(dev), slope=1.0, gain=1.0, f44=True)
+    assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize('case', CASES44N)
+def test_wino44n_data_gradient(case):
+    N, H, W, K, C = case          # (roles swapped: gy has K channels -- a multiple of 32 --, dx has C -- an odd multiple of 32)
+    g = torch.Generator().manual_seed(43)
+    gy = torch.randn(N, H, W, K, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.1
+    act = torch.randn(N, H, W, C, generator=g)
+    ref = F.conv_transpose2d(gy.permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1)
+    dev = torch.device('cuda')
+    wp = ops.pack_weight(w).to(dev)
+    dx = ops.conv2d_wino(1, gy.to(dev), wp, C, K, f44=True)
+    assert rel(dx.cpu(), ref) < TIGHT44
+    dx = ops.conv2d_wino(1, gy.to(dev), wp, C, K, ref=act.to(dev), slope=0.2, gain=1.5, f44=True)
+    assert rel(dx.cpu(), ref * torch.where(act > 0, 1.5, 0.3)) < TIGHT44
+
+
 def test_wino44_channel_sliced_views_determinism_and_rejects():
     N, H, W, C, K = 6, 16, 16, 32, 64
     x, w, b = _inputs(N, H, W, C, K, 25)
@@ -308,7 +350,7 @@ def test_wino44_channel_sliced_views_determinism_and_rejects():
     assert torch.equal(y1, y2)
     y3 = ops.conv2d_wino(0, x[2:4].contiguous().to(dev), wp, C, K, bias=b.to(dev), f44=True)     # (an item = two images)
     assert torch.equal(y1[2:4], y3)
-    for (h, c, k) in ((4, 32, 64), (16, 16, 64), (16, 32, 32), (12, 32, 64)):
+    for (h, c, k) in ((4, 32, 64), (16, 16, 64), (16, 32, 48), (12, 32, 64)):
         with pytest.raises(RuntimeError):
             ops.conv2d_wino(0, torch.zeros(2, h, h, c, device=dev), torch.zeros(9 * c, k, device=dev), c, k, f44=True)
 
