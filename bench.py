@@ -258,8 +258,8 @@ def _pmc_traffic(config, kernel):
                 # the engine names an instance by its first three
                 want = kernel.replace(' ', '')
                 for k, v in pmc.get('kernels', {}).items():
-                    kk = re.sub(r'wino(22|23|44)?::', '', k.replace(' ', '').replace('(anonymousnamespace)::', ''))
-                    kk = re.sub(r'^(wino(?:22|23|44)_kernel<\d+),\d+>', r'\1>', kk)
+                    kk = re.sub(r'wino(22|23|44n?)?::', '', k.replace(' ', '').replace('(anonymousnamespace)::', ''))
+                    kk = re.sub(r'^(wino(?:22|23|44n?)_kernel<\d+),\d+>', r'\1>', kk)
                     kk = re.sub(r'^wino23_kernel<\d+>', 'wino23_kernel', kk)
                     if kk == want or kk == want[:-1] + ',false>':
                         ent = v
@@ -504,7 +504,7 @@ def run_config(name, args, world, rank, dev, multi, keep=None, arm=None, disarm=
                     "algorithmic_gflop_per_launch": round(xsum / cnt / 1e9, 2),
                     "nominal_gflop_per_launch": round(fsum / cnt / 1e9, 2),
                     "flop_convention": "achieved / frac price the multiply-adds the kernel issues (Winograd: the transform-domain "
-                                       "products -- F(4x4,3x3), contrad_conv2d_path == 9: 1/4 of the dense layer's; F(2x2,3x3) / "
+                                       "products -- F(4x4,3x3), contrad_conv2d_path == 9 / 11: 1/4 of the dense layer's; F(2x2,3x3) / "
                                        "F(3x3,2x2), path 7: 4/9; F(2x2,2x2) on the phases of the strided layers, path 8: 9/16 (4x4 stride 2), path 10: 25/36 (3x3 stride 2, zero planes skipped); "
                                        "pixel-major tiles, path 3, skip the tap-positions that read zero padding on "
                                        "the 4x4 / 8x8 maps: contrad_conv2d_executed_fraction); nominal_* price the same time on the "

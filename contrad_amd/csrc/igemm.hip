@@ -895,17 +895,22 @@ int wino_grid(const wino::Args& a) {
 bool wino44_ok(const contrad_conv_desc* d, int mode) {
   if (mode != MODE_FWD && mode != MODE_DGRAD) return false;
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1) return false;
-  if (d->H < 8 || d->W < 8 || (d->H & (d->H - 1)) || (d->W & (d->W - 1)) || (d->W < 32 ? d->H != d->W : d->H < 16)) return false;
+  // (4x4 maps: wino44n_kernel only -- a tile is an image, 32 images per item)
+  if (d->H < 4 || d->W < 4 || (d->H & (d->H - 1)) || (d->W & (d->W - 1)) || (d->W < 32 ? d->H != d->W : d->H < 16)) return false;
   const int cin = mode == MODE_FWD ? d->C : d->K, cout = mode == MODE_FWD ? d->K : d->C;
   const int ldi = mode == MODE_FWD ? d->ldx : d->ldy, ldo = mode == MODE_FWD ? d->ldy : d->ldx;
   // (output channels: whole 64-wide blocks -- wino44_kernel -- or an odd number of 32-wide ones -- wino44n_kernel, wino44n.h)
   if ((cin & 31) || (cout & 31) || (ldi & 3) || (d->ldw & 3)) return false;
   const long long lim = 1ll << 31;
-  const long long nimg = d->W >= 32 ? 1 : d->W == 16 ? 2 : 8;
+  const long long nimg = d->W >= 32 ? 1 : d->W == 16 ? 2 : d->W == 8 ? 8 : 32;
   if (nimg * d->H * d->W * std::max(ldi, ldo) * 4 >= lim) return false;     // block-relative byte offsets
   if (36ll * cin * cout * 4 >= lim) return false;
   return true;
 }
+
+// wino44n_kernel (items of 32 tiles x 32 couts) instead of wino44_kernel (x 64): output channels that are not whole 64-wide blocks,
+// and the 4x4 maps (1536 images x 512 couts: 768 items = three full rounds where 64-wide blocks give one and a half)
+static inline bool wino44_n32(int cout, int W) { return (cout & 63) != 0 || W == 4; }
 
 wino44::Args wino44_args(const contrad_conv_desc* d, int mode) {
   wino44::Args a{};
@@ -919,7 +924,7 @@ wino44::Args wino44_args(const contrad_conv_desc* d, int mode) {
   a.NIMG = 32 / (a.TH * a.TW);
   a.PH = d->H / (4 * a.TH); a.PW = d->W / (4 * a.TW);
   a.NP = cdiv(d->N, a.NIMG) * a.PH * a.PW;
-  a.NKB = (a.Cout & 63) ? a.Cout / 32 : a.Cout / 64;      // 32-wide cout blocks: the items of wino44n_kernel
+  a.NKB = wino44_n32(a.Cout, d->W) ? a.Cout / 32 : a.Cout / 64;      // 32-wide cout blocks: the items of wino44n_kernel
   a.BH = 4 * a.TH + 2; a.BW = 4 * a.TW + 2;       // raw box: always with the halo
   return a;
 }
@@ -936,7 +941,7 @@ bool wino44_planned(const contrad_conv_desc* d, int mode) {
   static const bool enabled2 = []() { const char* e = contrad_dev_env("CONTRAD_WINO"); return !(e && e[0] == '0'); }();
   if (!enabled || !enabled2 || !wino44_ok(d, mode)) return false;
   static const bool enabled_n = []() { const char* e = contrad_dev_env("CONTRAD_WINO44N"); return !(e && e[0] == '0'); }();
-  if (!enabled_n && ((mode == MODE_FWD ? d->K : d->C) & 63)) return false;       // (32-wide cout blocks: wino44n.h)
+  if (!enabled_n && wino44_n32(mode == MODE_FWD ? d->K : d->C, d->W)) return false;       // (32-wide cout blocks: wino44n.h)
   const long long items = wino44_items(d, mode);
   static const long long min_items = []() { const char* e = contrad_dev_env("CONTRAD_WINO44_MIN_ITEMS"); return e ? atoll(e) : 230ll; }();
   if (items < WINO_CUS) return items >= min_items;
@@ -978,8 +983,9 @@ int launch_wino44(const contrad_conv_desc* d, const float* in, const float* wp, 
   const int quads = (a.Cin / 4) * a.Cout;
   hipLaunchKernelGGL(wino44::wino44_filter_kernel<MODE>, dim3(cdiv(quads, 256)), dim3(256), 0, stream, wp, U, d->C, d->K, d->ldw);
   CONTRAD_CHECK_LAUNCH();
-  if (a.Cout & 63)
-    return a.BW == 34 ? launch_wino44n_inst<MODE, 34>(a, stream) : a.BW == 18 ? launch_wino44n_inst<MODE, 18>(a, stream) : launch_wino44n_inst<MODE, 10>(a, stream);
+  if (wino44_n32(a.Cout, a.W))
+    return a.BW == 34 ? launch_wino44n_inst<MODE, 34>(a, stream) : a.BW == 18 ? launch_wino44n_inst<MODE, 18>(a, stream)
+           : a.BW == 10 ? launch_wino44n_inst<MODE, 10>(a, stream) : launch_wino44n_inst<MODE, 6>(a, stream);
   return a.BW == 34 ? launch_wino44_inst<MODE, 34>(a, stream) : a.BW == 18 ? launch_wino44_inst<MODE, 18>(a, stream) : launch_wino44_inst<MODE, 10>(a, stream);
 }
 
@@ -2307,7 +2313,7 @@ extern "C" int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm
 extern "C" int contrad_conv2d_path(const contrad_conv_desc* d, int mode) {
   if (check_desc(d) || mode < 0 || mode > 2) return -22;
   if (mode == MODE_FWD && fwd_k1_ok(d)) return 5;
-  if (mode != MODE_WGRAD && wino44_planned(d, mode)) return 9;
+  if (mode != MODE_WGRAD && wino44_planned(d, mode)) return wino44_n32(mode == MODE_FWD ? d->K : d->C, d->W) ? 11 : 9;
   if (mode != MODE_WGRAD && wino_planned(d, mode)) return 7;
   if (mode != MODE_WGRAD && wino22_planned(d, mode)) return 8;
   if (wino23_planned(d, mode)) return 10;
@@ -2335,7 +2341,7 @@ extern "C" int contrad_conv2d_path(const contrad_conv_desc* d, int mode) {
 
 extern "C" double contrad_conv2d_executed_fraction(const contrad_conv_desc* d, int mode) {
   if (check_desc(d) || mode < 0 || mode > 2) return -22.0;
-  if (contrad_conv2d_path(d, mode) == 9) return 0.25;        // 36 transform-domain multiply-adds per 4x4 tile instead of 144
+  if (contrad_conv2d_path(d, mode) == 9 || contrad_conv2d_path(d, mode) == 11) return 0.25;        // 36 transform-domain multiply-adds per 4x4 tile instead of 144
   if (contrad_conv2d_path(d, mode) == 7) return 4.0 / 9.0;   // 16 transform-domain multiply-adds per 2x2 tile instead of 36
   if (contrad_conv2d_path(d, mode) == 8) return 9.0 / 16.0;  // four phases x 9 per 2x2 tile instead of 64
   if (contrad_conv2d_path(d, mode) == 10) return 25.0 / 36.0; // 9 + 6 + 6 + 4 planes of the four phases per 2x2 tile instead of 36

@@ -21,8 +21,14 @@ using wino44::RAW0; using wino44::LDS_DWORDS; using wino44::OOB;
 // by constants
 template <int MODE, int ROLE, int BOXW>
 __device__ __forceinline__ void body_n32(const Args& p, float* smem) {
-  constexpr int TW = (BOXW == 34) ? 8 : (BOXW == 18) ? 4 : 2, TH = (BOXW == 10) ? 2 : 4, NIMG = 32 / (TH * TW), BH = 4 * TH + 2;
-  constexpr int SH_TW = (BOXW == 34) ? 3 : (BOXW == 18) ? 2 : 1, SH_THW = SH_TW + ((BOXW == 10) ? 1 : 2);
+  constexpr int TW = (BOXW == 34) ? 8 : (BOXW == 18) ? 4 : (BOXW == 10) ? 2 : 1, TH = (BOXW == 6) ? 1 : (BOXW == 10) ? 2 : 4;
+  constexpr int NIMG = 32 / (TH * TW), BH = 4 * TH + 2;
+  constexpr int SH_TW = (BOXW == 34) ? 3 : (BOXW == 18) ? 2 : (BOXW == 10) ? 1 : 0, SH_THW = SH_TW + ((BOXW == 6) ? 0 : (BOXW == 10) ? 1 : 2);
+  // BOXW 6 (4x4 maps, this variant only: a tile is an image, 32 images per item): 32 boxes of 6 x 6 do not fit a raw stage, and all
+  // they add to the 4 x 4 interiors is zeros -- the boxes share their halos: rows of 5 pixels (a row's right halo is the next
+  // row's left one), images of 5 rows (an image's bottom halo row is the next image's top one), 8 dwords per pixel: image
+  // pitch 200 dwords = 8 banks, the four tiles of a 32-lane read group stay conflict-free
+  constexpr int RPSB = (BOXW == 6) ? 8 : RPS, ROWP = (BOXW == 6) ? 5 : BOXW, IMGP = (BOXW == 6) ? 25 : BH * BOXW;
   // BOXW 18 / 10: the whole image sits in the box (16x16 / 8x8 maps, 2 / 8 images per block): the movers fetch its interior
   // only (512 pixels) and the halo of both raw stages is zeroed once;  BOXW 34: 18 x 34 pixels of a larger image, all fetched
   // (outside the image: hardware zero fills)
@@ -92,8 +98,8 @@ __device__ __forceinline__ void body_n32(const Args& p, float* smem) {
 #pragma unroll
   for (int i = 0; i < NRAW; ++i) {
     const int piece = tid + 256 * i, px = piece >> 1;
-    const int bpx = INTERIOR ? ((px / (IH * IW)) * BH + (px / IW) % IH + 1) * BOXW + px % IW + 1 : px;
-    wraw[i] = bpx * RPS + (piece & 1) * 4;         // (BOXW 34: pieces past the box land in the stage's padding: no branch)
+    const int bpx = INTERIOR ? (px / (IH * IW)) * IMGP + ((px / IW) % IH + 1) * ROWP + px % IW + 1 : px;
+    wraw[i] = bpx * RPSB + (piece & 1) * 4;         // (BOXW 34: pieces past the box land in the stage's padding: no branch)
   }
   auto store_raw = [&](int stage) {
 #pragma unroll
@@ -109,9 +115,9 @@ __device__ __forceinline__ void body_n32(const Args& p, float* smem) {
   int rd0 = 0;
   if constexpr (ROLE == 0) {
     const int img = ttile >> SH_THW, ty = (ttile >> SH_TW) & (TH - 1), tx = ttile & (TW - 1);
-    rd0 = RAW0 + ((img * BH + 4 * ty) * BOXW + 4 * tx) * RPS + tch;
+    rd0 = RAW0 + (img * IMGP + 4 * ty * ROWP + 4 * tx) * RPSB + tch;
   }
-  constexpr int rowstep = BOXW * RPS;
+  constexpr int rowstep = ROWP * RPSB;
   const int wrV = (tch >> 2) * KQS + ttile * 4 + (tch & 3);
   float d[6][6];
   auto tr_read = [&](int rstage) {                    // the thread's 6x6 raw window
@@ -119,7 +125,7 @@ __device__ __forceinline__ void body_n32(const Args& p, float* smem) {
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-      for (int j = 0; j < 6; ++j) d[i][j] = src[i * rowstep + j * RPS];
+      for (int j = 0; j < 6; ++j) d[i][j] = src[i * rowstep + j * RPSB];
   };
   auto tr_cols = [&](int j0) {                        // B^T d, columns j0 .. j0 + 2
 #pragma unroll

@@ -92,6 +92,8 @@ def conv_kernel_name(mode, d):
         return 'wino22_wgrad_kernel' if mode == 2 else 'wino22_kernel<%d>' % mode
     if path == 9:
         return 'wino44_kernel<%d>' % mode
+    if path == 11:
+        return 'wino44n_kernel<%d>' % mode
     if path == 10:
         return 'wino23_kernel'
     if path in (2, 3):

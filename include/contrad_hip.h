@@ -132,12 +132,13 @@ int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm, int* bn);
  * (conv_c32_kernel<mode>, modes 0 and 1), 7 = Winograd F(2x2, 3x3) (wino_kernel<mode>, modes 0 and 1; with a workspace) / F(3x3, 2x2) (wino_wgrad_kernel, mode 2),
  * 8 = F(2x2, 2x2) on the phases of the 4x4 stride-2 layers (wino22_kernel<mode> / wino22_wgrad_kernel), 9 = Winograd F(4x4, 3x3)
  * (wino44_kernel<mode>, modes 0 and 1; with a workspace), 10 = F(2x2, 2x2) on the phases of a 3x3 stride-2 pad-0 layer with the zero
- * planes skipped (wino23_kernel, mode 0; with a workspace);  negative = bad descriptor.  Profiling aid. */
+ * planes skipped (wino23_kernel, mode 0; with a workspace), 11 = F(4x4, 3x3) with 32-wide output-channel blocks (wino44n_kernel<mode>:
+ * output channels not a multiple of 64, and the 4x4 maps; with a workspace);  negative = bad descriptor.  Profiling aid. */
 int contrad_conv2d_path(const contrad_conv_desc* d, int mode);
 /* Share of the layer's nominal multiply-adds (2*N*Ho*Wo*K*C*KH*KW, the count every roofline here is quoted on, padding
  * taps included as in the reference's dense layer) that the kernel actually issues: 1 except on pixel-major tiles (path
  * 3), which skip the tap-positions that read padding (0.69 for a 3x3 pad-1 layer on a 4x4 map), and on the Winograd path
- * (7): 4/9, (8): 9/16, (9): 1/4, (10): 25/36 -- the transform-domain multiply-adds.  (A weight-gradient tile
+ * (7): 4/9, (8): 9/16, (9) and (11): 1/4, (10): 25/36 -- the transform-domain multiply-adds.  (A weight-gradient tile
  * that also sums the bias gradient visits everything: not reflected.)  Profiling aid. */
 double contrad_conv2d_executed_fraction(const contrad_conv_desc* d, int mode);
 /* Workgroups (256 threads each) of the main igemm launch this geometry gets for `mode` (with_workspace != 0: the plan the

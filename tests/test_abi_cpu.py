@@ -72,18 +72,19 @@ def test_launch_plans_are_host_logic(built):
             # the direct kernel (pixel-major tiles, padding taps skipped) is faster
             Ho = (H + 2 * p - k) // s + 1
             # ... and, later in round 6, forward and data gradient of the 3x3 layers on 16x16 / 8x8 maps on F(4x4, 3x3) (path 9,
-            # csrc/wino44.h: 1536 / 768 items of 512 pixels x 64 channels; the 4x4 maps stay on F(2x2, 3x3): 384 items there)
+            # csrc/wino44.h: 1536 / 768 items of 512 pixels x 64 channels); the 4x4 maps on its variant with 32-wide cout blocks
+            # (path 11, csrc/wino44n.h: 768 items of 32 images x 32 channels = three rounds where 64-wide blocks give 1.5)
             if k == 3:
-                want = 9 if (mode != 2 and H >= 8) else 7   # (the weight gradient: wino_wgrad_kernel, F(3x3, 2x2), one block per CU over split tile ranges)
+                want = (9 if H >= 8 else 11) if mode != 2 else 7   # (the weight gradient: wino_wgrad_kernel, F(3x3, 2x2), one block per CU over split tile ranges)
             elif not (mode == 0 and C == 256):
                 want = 8
             else:
                 want = 3
             assert path(ctypes.byref(d), mode) == want, (H, C, K, mode)
-            if want in (7, 8, 9):
+            if want in (7, 8, 9, 11):
                 assert built.raw('contrad_conv2d_grid_blocks')(ctypes.byref(d), mode, 1) == 256
-                frac = 0.25 if want == 9 else 4.0 / 9.0 if want == 7 else (9.0 / 16.0 if mode != 2 else 1.0)
-                if want == 9:
+                frac = 0.25 if want in (9, 11) else 4.0 / 9.0 if want == 7 else (9.0 / 16.0 if mode != 2 else 1.0)
+                if want in (9, 11):
                     assert built.raw('contrad_conv2d_wino44_ok')(ctypes.byref(d), mode) == 1
                 if mode != 2 or want == 7:
                     assert abs(built.raw('contrad_conv2d_executed_fraction')(ctypes.byref(d), mode) - frac) < 1e-12
@@ -93,13 +94,13 @@ def test_launch_plans_are_host_logic(built):
             want_bn = 64 if (mode == 1 and C == 64) else 128        # dgrad's columns are the input channels
             assert (bm.value, bn.value) == (128, want_bn), (H, C, K, mode, bm.value, bn.value)
         want_ws = 16 * C * K * 4 if k == 3 else 36 * C * K * 4       # the transformed filter: 16 planes / 4 phases x 9 planes
-        plan_ws = 36 * C * K * 4 if (k == 3 and H >= 8) else want_ws  # (F(4x4, 3x3): 36 planes)
+        plan_ws = 36 * C * K * 4 if k == 3 else want_ws  # (F(4x4, 3x3): 36 planes)
         assert built.raw('contrad_conv2d_fwd_workspace_bytes')(ctypes.byref(d)) == (plan_ws if not (k == 4 and C == 256) else 0)
         assert built.raw('contrad_conv2d_dgrad_workspace_bytes')(ctypes.byref(d)) == plan_ws
         assert built.raw('contrad_conv2d_wino_workspace_bytes')(ctypes.byref(d), 0) == want_ws
         if k == 3:
             assert built.raw('contrad_conv2d_wino44_workspace_bytes')(ctypes.byref(d)) == 36 * C * K * 4
-            assert built.raw('contrad_conv2d_wino44_ok')(ctypes.byref(d), 0) == (1 if H >= 8 else 0)
+            assert built.raw('contrad_conv2d_wino44_ok')(ctypes.byref(d), 0) == 1      # (4x4 maps too since csrc/wino44n.h)
         # weight gradient: 256 / (row blocks x 64-wide k blocks) split slabs of the packed gradient + the bias partials
         splits = 256 // ((C // 64) * (K // 64)) if k == 3 else 256 // ((4 * C // 128) * (K // 64))
         assert built.raw('contrad_conv2d_wgrad_workspace_bytes')(ctypes.byref(d)) == splits * (k * k * C + 1) * K * 4
@@ -138,7 +139,13 @@ def test_launch_plans_are_host_logic(built):
     assert path(ctypes.byref(_desc(256, 16, 128, 128, 3, 1, 1)), 0) == 9 and path(ctypes.byref(_desc(256, 16, 128, 128, 3, 1, 1)), 1) == 9   # 256 items
     assert path(ctypes.byref(_desc(16, 64, 256, 256, 3, 1, 1)), 0) == 9         # StyleGAN2_512, 64x64 maps of 16 images: 512 items
     assert path(ctypes.byref(_desc(16, 16, 512, 512, 3, 1, 1)), 0) != 9         # 64 items
-    assert w44(ctypes.byref(_desc(8, 16, 48, 64, 3, 1, 1)), 0) == 0 and w44(ctypes.byref(_desc(8, 4, 64, 64, 3, 1, 1)), 0) == 0
+    assert w44(ctypes.byref(_desc(8, 16, 48, 64, 3, 1, 1)), 0) == 0 and w44(ctypes.byref(_desc(8, 2, 64, 64, 3, 1, 1)), 0) == 0
+    # ... its variant with 32-wide cout blocks (path 11, csrc/wino44n.h): output channels that are not whole 64-wide blocks, and the 4x4 maps
+    assert w44(ctypes.byref(_desc(8, 4, 64, 64, 3, 1, 1)), 0) == 1 and w44(ctypes.byref(_desc(8, 16, 32, 96, 3, 1, 1)), 0) == 1
+    assert w44(ctypes.byref(_desc(8, 16, 32, 48, 3, 1, 1)), 0) == 0
+    assert path(ctypes.byref(_desc(48, 512, 32, 32, 3, 1, 1)), 0) == 11 and path(ctypes.byref(_desc(16, 512, 32, 32, 3, 1, 1)), 1) == 11
+    assert path(ctypes.byref(_desc(1536, 4, 512, 512, 3, 1, 1)), 0) == 11 and path(ctypes.byref(_desc(1536, 8, 256, 256, 3, 1, 1)), 0) == 9
+    assert abs(built.raw('contrad_conv2d_executed_fraction')(ctypes.byref(_desc(48, 512, 32, 32, 3, 1, 1)), 0) - 0.25) < 1e-12
     assert w44(ctypes.byref(_desc(8, 8, 64, 64, 3, 1, 1)), 0) == 1 and w44(ctypes.byref(_desc(8, 8, 64, 64, 3, 1, 1)), 2) == 0
     assert built.raw('contrad_conv2d_dgrad_workspace_bytes')(ctypes.byref(_desc(192, 8, 260, 512, 4, 2, 1))) == 0   # strided (not F(2x2,2x2): Cin)
     # contrastive column splits: ~256 blocks
@@ -166,9 +173,9 @@ def test_padding_skipping_tile_plans_without_gpu(built):
     bm, bn = ctypes.c_int(0), ctypes.c_int(0)
     N = 1536
     seen = set()
-    # (the 3x3 stride-1 layers with channel counts the Winograd kernel does not take -- it needs output channels % 64 --: the
+    # (the 3x3 stride-1 layers with channel counts no Winograd kernel takes -- they need output channels % 32 --: the
     # direct kernels and their padding-skipping tiles serve them as they served 128 / 256 / 512 channels until round 5)
-    nowino = [(H, C - 32, K - 32, k, s, p) for (H, C, K, k, s, p) in _SNDCGAN]
+    nowino = [(H, C - 16, K - 16, k, s, p) for (H, C, K, k, s, p) in _SNDCGAN]
     for (H, C, K, k, s, p) in nowino:
         d = _desc(N, H, C, K, k, s, p)
         Ho = (H + 2 * p - k) // s + 1

@@ -298,6 +298,8 @@ CASES44N = [
     (2, 32, 64, 32, 96),      # patches of 16 x 32 pixels, 2 x 2 per image; three cout blocks
     (1, 128, 64, 64, 32),     # 8 x 2 patches: boxes with real halos on every side; eight chunks
     (40, 16, 16, 32, 32),     # several items per block of the persistent grid
+    (40, 4, 4, 32, 64),       # 4x4 maps (this variant whatever the cout count): a tile is an image, 32 per item, ragged; shared halos
+    (70, 4, 4, 64, 96),       # three items per cout block, three cout blocks
 ]
 
 
@@ -350,7 +352,7 @@ def test_wino44_channel_sliced_views_determinism_and_rejects():
     assert torch.equal(y1, y2)
     y3 = ops.conv2d_wino(0, x[2:4].contiguous().to(dev), wp, C, K, bias=b.to(dev), f44=True)     # (an item = two images)
     assert torch.equal(y1[2:4], y3)
-    for (h, c, k) in ((4, 32, 64), (16, 16, 64), (16, 32, 48), (12, 32, 64)):
+    for (h, c, k) in ((2, 32, 64), (16, 16, 64), (16, 32, 48), (12, 32, 64)):
         with pytest.raises(RuntimeError):
             ops.conv2d_wino(0, torch.zeros(2, h, h, c, device=dev), torch.zeros(9 * c, k, device=dev), c, k, f44=True)
 
@@ -427,7 +429,7 @@ def test_wino23_channel_sliced_views_determinism_and_rejects():
 
 
 # the 3x3 stride-1 layers of the BASELINE workloads: (N, H, C) -- SNDCGAN at 3N = 1536, StyleGAN2_512 at 3N = 48
-PLANNED = [(1536, 16, 128), (1536, 8, 256), (48, 128, 128), (48, 64, 256), (48, 32, 512), (48, 256, 64)]
+PLANNED = [(1536, 16, 128), (1536, 8, 256), (1536, 4, 512), (48, 128, 128), (48, 64, 256), (48, 32, 512), (48, 256, 64)]
 
 
 @pytest.mark.parametrize('shape', PLANNED)
@@ -443,8 +445,9 @@ def test_the_plan_takes_winograd_at_the_baseline_shapes_and_matches_torch(shape)
     b = torch.randn(K, generator=g)
     wp = ops.pack_weight(w).to(dev)
     d = ops.make_desc(N, H, H, C, K, 3, 3, 1, 1, C, K, wp.stride(0))
-    assert lib().raw('contrad_conv2d_path')(ctypes.byref(d), 0) == 9      # (F(4x4, 3x3) on all of them: maps >= 8x8, full rounds)
-    assert lib().raw('contrad_conv2d_path')(ctypes.byref(d), 1) == 9
+    want = 11 if H == 4 else 9      # (F(4x4, 3x3) on all of them; the 4x4 maps on its variant with 32-wide cout blocks: full rounds)
+    assert lib().raw('contrad_conv2d_path')(ctypes.byref(d), 0) == want
+    assert lib().raw('contrad_conv2d_path')(ctypes.byref(d), 1) == want
     assert abs(lib().raw('contrad_conv2d_executed_fraction')(ctypes.byref(d), 0) - 0.25) < 1e-12
     xd = x.to(dev)
     y = ops.conv2d_fwd(xd, wp, b.to(dev), K, 3, 3, 1, 1, slope=0.1, gain=1.0)
@@ -475,6 +478,32 @@ def test_the_plan_takes_winograd_at_the_baseline_shapes_and_matches_torch(shape)
     F.conv2d(xs2.permute(0, 3, 1, 2), w0, None, padding=1).backward(ys2.permute(0, 3, 1, 2))
     dws = ops.unpack_weight(ops.conv2d_wino_wgrad(xd[:nb], y[:nb]), K, C, 3, 3).cpu()
     assert rel(dws, w0.grad) < TIGHT
+
+
+def test_the_plan_takes_winograd_for_the_32_channel_layers_at_512():
+    """StyleGAN2_512's 32 -> 32 channel 3x3 layers (3N = 48 images at 512^2): forward and data gradient on F(4x4, 3x3) with 32-wide
+    cout blocks (csrc/wino44n.h), the weight gradient on its dedicated direct kernel; computed here on 4 images."""
+    N, H, C, K = 4, 512, 32, 32
+    dev = torch.device('cuda')
+    wp0 = torch.zeros(9 * C, K)
+    for n in (48, 16, N):
+        d = ops.make_desc(n, H, H, C, K, 3, 3, 1, 1, C, K, wp0.stride(0))
+        assert lib().raw('contrad_conv2d_path')(ctypes.byref(d), 0) == 11
+        assert lib().raw('contrad_conv2d_path')(ctypes.byref(d), 1) == 11
+        assert 0 <= lib().raw('contrad_conv2d_path')(ctypes.byref(d), 2) < 7
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(N, H, H, C, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.05
+    b = torch.randn(K, generator=g)
+    wp = ops.pack_weight(w).to(dev)
+    xd = x.to(dev)
+    y = ops.conv2d_fwd(xd, wp, b.to(dev), K, 3, 3, 1, 1, slope=0.2, gain=1.0)
+    sel = [0, N - 1]
+    ref = F.leaky_relu(F.conv2d(x[sel].permute(0, 3, 1, 2), w, b, padding=1), 0.2).permute(0, 2, 3, 1)
+    assert rel(y[sel].cpu(), ref) < TIGHT44
+    dx = ops.conv2d_dgrad(y, wp, (N, H, H, C), 3, 3, 1, 1, act_ref=xd, slope=0.2, gain=1.0)
+    refd = F.conv_transpose2d(y[sel].cpu().permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1) * torch.where(x[sel] > 0, 1.0, 0.2)
+    assert rel(dx[sel].cpu(), refd) < TIGHT44
 
 
 # the blurred 3x3 stride-2 layers of StyleGAN2_512 at 3N = 48 that the plan gives to csrc/wino23.h: (N, G, C, K)

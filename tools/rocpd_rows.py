@@ -26,17 +26,17 @@ def short(name):
 
 def norm(k):
     k = re.sub(r'\s+', '', k)
-    k = re.sub(r'wino(22|23|44)?::', '', k)    # (csrc/wino.h / wino22.h live in namespaces; the engine names its kernels without them)
+    k = re.sub(r'wino(22|23|44n?)?::', '', k)    # (csrc/wino.h / wino22.h live in namespaces; the engine names its kernels without them)
     # igemm_lean_kernel<MODE,BM,BN,false|true>: the 4th argument is the balanced block order of the strided data gradient
     # (round 4); the shape table names the instance by (MODE, BM, BN) only
     k = re.sub(r'^wino23_kernel<\d+>', 'wino23_kernel', k)           # (<raw pieces per mover>)
-    k = re.sub(r'^(wino(?:22|23|44)_kernel<\d+),\d+>', r'\1>', k)     # (<MODE, raw pieces per mover | raw box width>: named by MODE)
+    k = re.sub(r'^(wino(?:22|23|44n?)_kernel<\d+),\d+>', r'\1>', k)     # (<MODE, raw pieces per mover | raw box width>: named by MODE)
     return re.sub(r'^(igemm_lean_kernel<\d+,\d+,\d+),(?:false|true)>', r'\1>', k)
 
 
 # kernels the conv engine's C-ABI entry points launch as their MAIN dispatch (contrad_conv2d_path), i.e. the rows of
 # bench.py's shape table; their reduce kernels are separate trace rows
-CONV_KERNELS = ('igemm', 'wgrad_c32_kernel', 'fwd_k1_kernel', 'conv_c32_kernel', 'wino_kernel', 'wino_wgrad_kernel', 'wino22_kernel', 'wino22_wgrad_kernel', 'wino44_kernel', 'wino23_kernel')
+CONV_KERNELS = ('igemm', 'wgrad_c32_kernel', 'fwd_k1_kernel', 'conv_c32_kernel', 'wino_kernel', 'wino_wgrad_kernel', 'wino22_kernel', 'wino22_wgrad_kernel', 'wino44_kernel', 'wino44n_kernel', 'wino23_kernel')
 
 
 def main(db_path, table_path):
