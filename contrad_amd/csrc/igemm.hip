@@ -908,9 +908,33 @@ bool wino44_ok(const contrad_conv_desc* d, int mode) {
   return true;
 }
 
-// wino44n_kernel (items of 32 tiles x 32 couts) instead of wino44_kernel (x 64): output channels that are not whole 64-wide blocks,
-// and the 4x4 maps (1536 images x 512 couts: 768 items = three full rounds where 64-wide blocks give one and a half)
-static inline bool wino44_n32(int cout, int W) { return (cout & 63) != 0 || W == 4; }
+// Does a launch of `items` whole-CU items fill the chip well enough?  A single round from 230 items, else a last round that is not
+// mostly empty (rounds x CUs <= 1.4 x items).
+static inline bool wino44_round_ok(long long items) {
+  static const long long min_items = []() { const char* e = contrad_dev_env("CONTRAD_WINO44_MIN_ITEMS"); return e ? atoll(e) : 230ll; }();
+  if (items < WINO_CUS) return items >= min_items;
+  return cdivll(items, WINO_CUS) * WINO_CUS * 10 <= items * 14;
+}
+
+// patches (32 tiles each) of a launch: images / images per item x patches per image
+static inline long long wino44_patches(const contrad_conv_desc* d) {
+  const int TW = std::min(8, d->W / 4), TH = std::min(4, d->H / 4);
+  return (long long)cdiv(d->N, 32 / (TH * TW)) * (d->H / (4 * TH)) * (d->W / (4 * TW));
+}
+
+// wino44n_kernel (items of 32 tiles x 32 couts) instead of wino44_kernel (x 64): output channels that are not whole 64-wide blocks;
+// the 4x4 maps (1536 images x 512 couts: 768 items = three full rounds where 64-wide blocks give one and a half); and launches
+// whose 64-wide items do not fill the chip while twice as many half items do (192 images of 8 x 8 x 512: 192 -> 384 items, 0.30 ->
+// 0.24 ms; of 16 x 16 x 128: 0.095 -> 0.079 ms -- with enough items the 64-wide blocks are 10 - 25 % faster: one exchange and one
+// transform of V per 64 couts instead of per 32, profiles/r06_ab_wino44n_plan.txt)
+static inline bool wino44_n32(const contrad_conv_desc* d, int mode) {
+  static const bool all = []() { const char* e = contrad_dev_env("CONTRAD_WINO44N_ALL"); return e && e[0] == '1'; }();      // (dev: every shape on it)
+  static const bool fill = []() { const char* e = contrad_dev_env("CONTRAD_WINO44N_FILL"); return !(e && e[0] == '0'); }();  // (dev: the third rule off)
+  const int cout = mode == MODE_FWD ? d->K : d->C;
+  if ((cout & 63) != 0 || d->W == 4 || all) return true;
+  const long long items64 = wino44_patches(d) * (cout / 64);
+  return fill && !wino44_round_ok(items64) && wino44_round_ok(2 * items64);
+}
 
 wino44::Args wino44_args(const contrad_conv_desc* d, int mode) {
   wino44::Args a{};
@@ -919,12 +943,13 @@ wino44::Args wino44_args(const contrad_conv_desc* d, int mode) {
   a.Cout = mode == MODE_FWD ? d->K : d->C;
   a.ldi = mode == MODE_FWD ? d->ldx : d->ldy;
   a.ldo = mode == MODE_FWD ? d->ldy : d->ldx;
-  a.TW = std::min(8, d->W / 4); a.TH = std::min(4, d->H / 4);      // 4x4-pixel tiles per image part of an item: 4 x 8, 4 x 4 (16x16 maps), 2 x 2 (8x8)
+  a.TW = std::min(8, d->W / 4); a.TH = std::min(4, d->H / 4);      // 4x4-pixel tiles per image part of an item: 4 x 8, 4 x 4 (16x16 maps), 2 x 2 (8x8), 1 (4x4)
   a.sh_tw = __builtin_ctz(a.TW); a.sh_thw = __builtin_ctz(a.TH * a.TW);
   a.NIMG = 32 / (a.TH * a.TW);
   a.PH = d->H / (4 * a.TH); a.PW = d->W / (4 * a.TW);
   a.NP = cdiv(d->N, a.NIMG) * a.PH * a.PW;
-  a.NKB = wino44_n32(a.Cout, d->W) ? a.Cout / 32 : a.Cout / 64;      // 32-wide cout blocks: the items of wino44n_kernel
+  a.n32 = wino44_n32(d, mode) ? 1 : 0;
+  a.NKB = a.n32 ? a.Cout / 32 : a.Cout / 64;      // 32-wide cout blocks: the items of wino44n_kernel
   a.BH = 4 * a.TH + 2; a.BW = 4 * a.TW + 2;       // raw box: always with the halo
   return a;
 }
@@ -934,18 +959,15 @@ long long wino44_items(const contrad_conv_desc* d, int mode) {
   return (long long)a.NP * a.NKB;
 }
 
-// An item is 512 output pixels x 64 couts x all channels on a whole CU: twice wino.h's.  The plan takes F(4x4, 3x3) when the
+// An item is 512 output pixels x 64 (32) couts x all channels on a whole CU: twice wino.h's.  The plan takes F(4x4, 3x3) when the
 // launch has a full round of them and its last round is not mostly empty; else the layer falls through to wino_planned.
 bool wino44_planned(const contrad_conv_desc* d, int mode) {
   static const bool enabled = []() { const char* e = contrad_dev_env("CONTRAD_WINO44"); return !(e && e[0] == '0'); }();
   static const bool enabled2 = []() { const char* e = contrad_dev_env("CONTRAD_WINO"); return !(e && e[0] == '0'); }();
   if (!enabled || !enabled2 || !wino44_ok(d, mode)) return false;
   static const bool enabled_n = []() { const char* e = contrad_dev_env("CONTRAD_WINO44N"); return !(e && e[0] == '0'); }();
-  if (!enabled_n && wino44_n32(mode == MODE_FWD ? d->K : d->C, d->W)) return false;       // (32-wide cout blocks: wino44n.h)
-  const long long items = wino44_items(d, mode);
-  static const long long min_items = []() { const char* e = contrad_dev_env("CONTRAD_WINO44_MIN_ITEMS"); return e ? atoll(e) : 230ll; }();
-  if (items < WINO_CUS) return items >= min_items;
-  return cdivll(items, WINO_CUS) * WINO_CUS * 10 <= items * 14;
+  if (!enabled_n && wino44_n32(d, mode)) return false;       // (32-wide cout blocks: wino44n.h)
+  return wino44_round_ok(wino44_items(d, mode));
 }
 
 long long wino44_workspace_bytes(const contrad_conv_desc* d) { return 36ll * d->C * d->K * (long long)sizeof(float); }
@@ -983,7 +1005,7 @@ int launch_wino44(const contrad_conv_desc* d, const float* in, const float* wp, 
   const int quads = (a.Cin / 4) * a.Cout;
   hipLaunchKernelGGL(wino44::wino44_filter_kernel<MODE>, dim3(cdiv(quads, 256)), dim3(256), 0, stream, wp, U, d->C, d->K, d->ldw);
   CONTRAD_CHECK_LAUNCH();
-  if (wino44_n32(a.Cout, a.W))
+  if (a.n32)
     return a.BW == 34 ? launch_wino44n_inst<MODE, 34>(a, stream) : a.BW == 18 ? launch_wino44n_inst<MODE, 18>(a, stream)
            : a.BW == 10 ? launch_wino44n_inst<MODE, 10>(a, stream) : launch_wino44n_inst<MODE, 6>(a, stream);
   return a.BW == 34 ? launch_wino44_inst<MODE, 34>(a, stream) : a.BW == 18 ? launch_wino44_inst<MODE, 18>(a, stream) : launch_wino44_inst<MODE, 10>(a, stream);
@@ -2313,7 +2335,7 @@ extern "C" int contrad_conv2d_tile(const contrad_conv_desc* d, int mode, int* bm
 extern "C" int contrad_conv2d_path(const contrad_conv_desc* d, int mode) {
   if (check_desc(d) || mode < 0 || mode > 2) return -22;
   if (mode == MODE_FWD && fwd_k1_ok(d)) return 5;
-  if (mode != MODE_WGRAD && wino44_planned(d, mode)) return wino44_n32(mode == MODE_FWD ? d->K : d->C, d->W) ? 11 : 9;
+  if (mode != MODE_WGRAD && wino44_planned(d, mode)) return wino44_n32(d, mode) ? 11 : 9;
   if (mode != MODE_WGRAD && wino_planned(d, mode)) return 7;
   if (mode != MODE_WGRAD && wino22_planned(d, mode)) return 8;
   if (wino23_planned(d, mode)) return 10;

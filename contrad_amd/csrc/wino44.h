@@ -59,6 +59,7 @@ struct Args {
   int PH, PW;          // patches per image
   int NP, NKB;         // patches (image groups x PH x PW), 64-wide cout blocks
   int BH, BW;          // raw box per image part = (4 TH + 2) x (4 TW + 2): always with the halo (outside the image: zero fills)
+  int n32;             // host side: the launch runs on wino44n_kernel (wino44n.h: 32-wide cout blocks, NKB = Cout / 32)
 };
 
 __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
