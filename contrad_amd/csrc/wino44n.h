@@ -7,6 +7,11 @@
 // waves 0-3 (the transform waves) five each, waves 4-7 (the movers) four each -- waves s and s + 4 share SIMD s, nine planes
 // per SIMD.  80 / 64 accumulator registers; the U ring holds a whole chunk pair.  Exchange area [row (8)][plane (36)][lane (64)]
 // = both V stages, two passes of eight accumulator rows; in pass q wave w owns row 8 q + w.
+// Where the time goes (ablations W44N_NO_*: timing only, results wrong; kernel alone, ms): 48 x 512^2 x 32 -> 32 forward 1.34: without the
+// epilogue 0.96, without the input transform 1.07, without the raw stream 1.10, without all three 0.55 (the layer moves 3.2 GB: 0.6 ms
+// at the rate the FIR kernels reach); 1536 x 4^2 x 512 -> 512 forward 0.45: 0.43 / 0.28 / 0.41 / 0.28 -- there the transform waves' five
+// slots per chunk are the limiter.  Issuing every load of the epilogue and of the next item's start before the first store (the
+// vector-memory counter retires in order) changed nothing: the passes do not wait for their stores.
 #pragma once
 
 namespace wino44n {
@@ -192,14 +197,18 @@ __device__ __forceinline__ void body_n32(const Args& p, float* smem) {
       const int P = s / NPW, xi = s - NPW * P;
       if (xi + 1 < NPW) fa[(s + 1) & 1] = *reinterpret_cast<const float4*>(smem + P * V_SZ + rdA + (xi + 1) * PL);
       if constexpr (ROLE == 1) {
+#ifndef W44N_NO_RAW
         if (xi == 0) store_raw(P);
         if (xi == 1 && !(P == 1 && LAST)) load_raw(t + P + 3);
+#endif
       } else if (!(P == 1 && LAST)) {
+#ifndef W44N_NO_TRANSFORM
         if (xi == 0) tr_read(1 - P);
         if (xi == 1) { tr_cols(0); tr_cols(3); }
         if (xi == 2) { tr_row(1 - P, 0); tr_row(1 - P, 1); }
         if (xi == 3) { tr_row(1 - P, 2); tr_row(1 - P, 3); }
         if (xi == 4) { tr_row(1 - P, 4); tr_row(1 - P, 5); }
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
       const float* a = (const float*)&fa[s & 1];
@@ -219,11 +228,13 @@ __device__ __forceinline__ void body_n32(const Args& p, float* smem) {
 
   for (; w_cur < L; w_cur += nslots) {
     __syncthreads();                 // raw 0 (and 1) of this item are in LDS; the exchange area is free again
+#ifndef W44N_NO_TRANSFORM
     if constexpr (ROLE == 0) {
       tr_read(0); tr_cols(0); tr_cols(3);
 #pragma unroll
       for (int i = 0; i < 6; ++i) tr_row(0, i);
     }
+#endif
     __syncthreads();
 
     for (int t = 0; t + 2 < NCH; t += 2) pair(std::false_type{}, t);
@@ -250,6 +261,9 @@ __device__ __forceinline__ void body_n32(const Args& p, float* smem) {
     const float ga = p.ref ? g1 : 1.f, gb = p.ref ? g0 : 1.f;
     float* xw = smem + plane0 * 64 + lane;
     const float* xr = smem + (w8 * 36) * 64 + lane;
+#ifdef W44N_NO_EPILOGUE
+    if (p.N < 0)
+#endif
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       // (the element's image exists?  per lane only where a half-wave step of four tiles crosses images: 8x8 maps)
