@@ -44,8 +44,12 @@ __device__ __forceinline__ void body_n32(const Args& p, float* smem) {
   const int tid = threadIdx.x & 255, lane = threadIdx.x & 63;
   const int w8 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // (wave-uniform: scalar registers)
   const int l31 = lane & 31, lhi = lane >> 5;
-  constexpr int NPW = ROLE == 0 ? 5 : 4;           // planes of this wave: waves 0-3 five each (0 .. 19), waves 4-7 four each (20 .. 35)
-  const int plane0 = ROLE == 0 ? 5 * (w8 & 3) : 20 + 4 * (w8 & 3);      // (waves s and s + 4 share SIMD s: nine planes per SIMD)
+#ifndef W44N_SWAP
+#define W44N_SWAP 0
+#endif
+  constexpr int NP0 = W44N_SWAP ? 4 : 5;           // planes of a transform wave (dev knob W44N_SWAP: the movers take five -- same times on both layer kinds)
+  constexpr int NPW = ROLE == 0 ? NP0 : 9 - NP0;   // planes of this wave: waves 0-3 five each (0 .. 19), waves 4-7 four each (20 .. 35)
+  const int plane0 = ROLE == 0 ? NP0 * (w8 & 3) : 4 * NP0 + (9 - NP0) * (w8 & 3);      // (waves s and s + 4 share SIMD s: nine planes per SIMD)
   const int NKB = p.NKB;
   const int NCH = p.Cin >> 3;                      // (>= 4, even)
   const int ppi = p.PH * p.PW;
@@ -125,19 +129,34 @@ __device__ __forceinline__ void body_n32(const Args& p, float* smem) {
   constexpr int rowstep = ROWP * RPSB;
   const int wrV = (tch >> 2) * KQS + ttile * 4 + (tch & 3);
   float d[6][6];
+  // BOXW 6: the window's border ring is the zero halo of a 4x4 image -- known at compile time: 16 reads instead of 36, and B^T d
+  // with d0 = d5 = 0 on four columns instead of six (the transform waves' share of a chunk is what limits the 4x4-map layers)
+  constexpr bool ZB = BOXW == 6;
+  auto bt6z = [](float& d0, float& d1, float& d2, float& d3, float& d4, float& d5) {      // bt6 with d0 = d5 = 0 on entry
+    const float t0 = __builtin_fmaf(-5.f, d2, d4);
+    const float p_ = __builtin_fmaf(-4.f, d2, d4), q_ = __builtin_fmaf(-4.f, d1, d3);
+    const float r_ = d4 - d2, s_ = d3 - d1;
+    const float t5 = __builtin_fmaf(-5.f, d3, 4.f * d1);
+    d0 = t0; d1 = p_ + q_; d2 = p_ - q_; d3 = __builtin_fmaf(2.f, s_, r_); d4 = __builtin_fmaf(-2.f, s_, r_); d5 = t5;
+  };
   auto tr_read = [&](int rstage) {                    // the thread's 6x6 raw window
     const float* src = smem + rd0 + rstage * RAW_SZ;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-      for (int j = 0; j < 6; ++j) d[i][j] = src[i * rowstep + j * RPSB];
+      for (int j = 0; j < 6; ++j)
+        d[i][j] = (ZB && (i == 0 || i == 5 || j == 0 || j == 5)) ? 0.f : src[i * rowstep + j * RPSB];
   };
   auto tr_cols = [&](int j0) {                        // B^T d, columns j0 .. j0 + 2
 #pragma unroll
-    for (int j = j0; j < j0 + 3; ++j) bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);
+    for (int j = j0; j < j0 + 3; ++j) {
+      if constexpr (ZB) { if (j != 0 && j != 5) bt6z(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]); }      // (columns 0 and 5 stay zero)
+      else bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);
+    }
   };
   auto tr_row = [&](int vstage, int i) {              // (.) B for row i, six planes out
-    bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
+    if constexpr (ZB) bt6z(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
+    else bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
     float* dst = smem + vstage * V_SZ + wrV + i * 6 * PL;
 #pragma unroll
     for (int j = 0; j < 6; ++j) dst[j * PL] = d[i][j];
@@ -205,9 +224,14 @@ __device__ __forceinline__ void body_n32(const Args& p, float* smem) {
 #ifndef W44N_NO_TRANSFORM
         if (xi == 0) tr_read(1 - P);
         if (xi == 1) { tr_cols(0); tr_cols(3); }
-        if (xi == 2) { tr_row(1 - P, 0); tr_row(1 - P, 1); }
-        if (xi == 3) { tr_row(1 - P, 2); tr_row(1 - P, 3); }
-        if (xi == 4) { tr_row(1 - P, 4); tr_row(1 - P, 5); }
+        if constexpr (NPW == 5) {
+          if (xi == 2) { tr_row(1 - P, 0); tr_row(1 - P, 1); }
+          if (xi == 3) { tr_row(1 - P, 2); tr_row(1 - P, 3); }
+          if (xi == 4) { tr_row(1 - P, 4); tr_row(1 - P, 5); }
+        } else {
+          if (xi == 2) { tr_row(1 - P, 0); tr_row(1 - P, 1); tr_row(1 - P, 2); }
+          if (xi == 3) { tr_row(1 - P, 3); tr_row(1 - P, 4); tr_row(1 - P, 5); }
+        }
 #endif
       }
       __builtin_amdgcn_sched_barrier(0);
