@@ -366,60 +366,64 @@ __device__ __forceinline__ void uf_epilogue(const UpfirdnArgs& a, int m, size_t 
 
 // (152 VGPRs = 3 waves per SIMD with all 35 taps in flight; forced to 4 / 5 waves the loads spill: 600 -> 1040 / 1830 us)
 // up = down = 1 (blur and its backward): 4 x 2 outputs per thread and 4 channels, grid = (tiles of an image / 256, images)
+#ifndef UF_TX
+#define UF_TX 2      // output columns per thread of the blur (dev knob: 4 = 7 x 7 loads for 16 outputs, 3.1 instead of 4.4 loads per
+                     // output but 221 registers = 2 waves per SIMD: 597 -> 639 us, backward 812 -> 844: the tap loads are not the limiter)
+#endif
+template <int TX>
 __global__ __launch_bounds__(256) void upfirdn4_u1d1_buf_kernel(UpfirdnArgs a) {
   const Fir4 f = load_fir4(a.kernel);
   const int mv = a.minor >> 2;
-  const int sx = (a.out_w + 1) >> 1, sy = (a.out_h + 3) >> 2;
+  const int sx = (a.out_w + TX - 1) / TX, sy = (a.out_h + 3) >> 2;
   const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
   const int m = (int)blockIdx.y;
   const bool live = e < sy * sx * mv;
   const int c = (e % mv) * 4;
   const int t = e / mv;
-  const int ox0 = (t % sx) * 2, oy0 = (t / sx) * 4;
+  const int ox0 = (t % sx) * TX, oy0 = (t / sx) * 4;
   const int ix0 = ox0 - a.pad_x0, iy0 = oy0 - a.pad_y0;
   const size_t in_elems = (size_t)a.in_h * a.in_w * a.minor, out_elems = (size_t)a.out_h * a.out_w * a.minor;
   const __amdgpu_buffer_rsrc_t rI = uf_rsrc(a.in, in_elems, m, true);
-  float4 acc[8];
+  float4 acc[4 * TX];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < 4 * TX; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int off0 = ((iy0 * a.in_w + ix0) * a.minor + c) * 4;
   const int rowb = a.in_w * a.minor * 4, colb = a.minor * 4;
 #pragma unroll
   for (int dy = 0; dy < 7; ++dy) {
     const bool vy = live && (unsigned)(iy0 + dy) < (unsigned)a.in_h;
-    float4 v[5];
+    float4 v[TX + 3];
 #pragma unroll
-    for (int dx = 0; dx < 5; ++dx)
+    for (int dx = 0; dx < TX + 3; ++dx)
       v[dx] = uf_bld4(rI, uf_sel((unsigned)(off0 + dy * rowb + dx * colb), vy && (unsigned)(ix0 + dx) < (unsigned)a.in_w));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ky = dy - r;
       if (ky >= 0 && ky < 4) {
 #pragma unroll
-        for (int kx = 0; kx < 4; ++kx) {
-          fma4(acc[2 * r], f.w[ky * 4 + kx], v[kx]);
-          fma4(acc[2 * r + 1], f.w[ky * 4 + kx], v[kx + 1]);
-        }
+        for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+          for (int q = 0; q < TX; ++q) fma4(acc[TX * r + q], f.w[ky * 4 + kx], v[kx + q]);
       }
     }
   }
-  unsigned voff[8];
+  unsigned voff[4 * TX];
   const int oo0 = ((oy0 * a.out_w + ox0) * a.minor + c) * 4, orow = a.out_w * a.minor * 4;
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-      voff[2 * r + q] = uf_sel((unsigned)(oo0 + r * orow + q * colb), live && oy0 + r < a.out_h && ox0 + q < a.out_w);
+    for (int q = 0; q < TX; ++q)
+      voff[TX * r + q] = uf_sel((unsigned)(oo0 + r * orow + q * colb), live && oy0 + r < a.out_h && ox0 + q < a.out_w);
   if (a.mc_bias) {       // uniform: the generator's upsampling StyledConv tail (blur -> demod + noise + bias + lrelu)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
+      for (int q = 0; q < TX; ++q)
         if (live && oy0 + r < a.out_h && ox0 + q < a.out_w)
-          mc_store4(a, m, ((size_t)m * a.out_h + oy0 + r) * a.out_w + ox0 + q, c, acc[2 * r + q]);
+          mc_store4(a, m, ((size_t)m * a.out_h + oy0 + r) * a.out_w + ox0 + q, c, acc[TX * r + q]);
     return;
   }
-  if (a.nt_store) uf_epilogue<8, 2>(a, m, out_elems, voff, acc); else uf_epilogue<8, 0>(a, m, out_elems, voff, acc);
+  if (a.nt_store) uf_epilogue<4 * TX, 2>(a, m, out_elems, voff, acc); else uf_epilogue<4 * TX, 0>(a, m, out_elems, voff, acc);
 }
 
 // up = 1, down = 2: out[oy][ox] = sum k[ky][kx] in[2 oy + ky - pad][2 ox + kx - pad]; tile of 2 x 2 outputs per thread:
@@ -1091,8 +1095,8 @@ static int upfirdn2d_launch(const float* input, const float* kernel, float* out,
   const bool buf_ok = major <= 65535 && (long long)in_h * in_w * minor * 4 < (1ll << 31) && (long long)a.out_h * a.out_w * minor * 4 < (1ll << 31);
   if (fir4 && up_x == 1 && down_x == 1) {
     if (buf_ok) {
-      const long long per = (long long)((a.out_h + 3) / 4) * ((a.out_w + 1) / 2) * (minor / 4);
-      hipLaunchKernelGGL(upfirdn4_u1d1_buf_kernel, dim3((unsigned)cdivll(per, 256), (unsigned)major), dim3(256), 0, s, a);
+      const long long per = (long long)((a.out_h + 3) / 4) * ((a.out_w + UF_TX - 1) / UF_TX) * (minor / 4);
+      hipLaunchKernelGGL(upfirdn4_u1d1_buf_kernel<UF_TX>, dim3((unsigned)cdivll(per, 256), (unsigned)major), dim3(256), 0, s, a);
       CONTRAD_CHECK_LAUNCH();
       return 0;
     }
